@@ -1,0 +1,93 @@
+"""ctypes binding of ``libgd_raster.so`` (C-ABI declared in ``include/gd_raster.h``).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, every
+entry point raises.  (The CPU oracle under ``oracle/`` is test infrastructure and is never
+imported from this package.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgd_raster.so")
+_lib = None
+
+GD_MAX_VIEWS = 16
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+_vp = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "depths", "clamped", "radii", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "point_offsets",
+        "block_sums", "ranges", "n_contrib", "point_list", "point_list_alt", "keys", "keys_alt", "sort_hist")]
+
+
+# symbol -> (restype, argtypes); mirrors include/gd_raster.h one to one
+_PF = C.POINTER(_f)
+SIGNATURES = {
+    "gd_raster_geom_bytes": (C.c_size_t, [_i, _i]),
+    "gd_raster_image_bytes": (C.c_size_t, [_i, _i, _i]),
+    "gd_raster_binning_bytes": (C.c_size_t, [C.c_int64]),
+    "gd_raster_backward_scratch_bytes": (C.c_size_t, [_i, _i]),
+    "gd_raster_forward": (_i, [_vp] + [ALLOC_FN, _vp] * 3      # stream, 3 x (allocator, user)
+                          + [_i] * 3 + [_vp] + [_i] * 2          # P D M, background, width height
+                          + [_vp] * 5 + [_f] + [_vp] * 5         # means3D shs colors opac scales | mod | rot cov view proj campos
+                          + [_f] * 2 + [_i] + [_vp] * 4 + [_i]), # tanx tany, prefiltered, color depth alpha radii, debug
+    "gd_raster_backward": (_i, [_vp] + [_i] * 4 + [_vp] + [_i] * 2  # stream, P D M R, background, width height
+                           + [_vp] * 5 + [_f] + [_vp] * 5            # means3D shs colors alphas scales | mod | rot cov view proj campos
+                           + [_f] * 2 + [_vp] * 5                     # tanx tany, radii geom binning image bwd_scratch
+                           + [_vp] * 3 + [_vp] * 10 + [_i]),          # dL_dpix/depth/alpha, 10 outputs, debug
+    "gd_raster_mark_visible": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "gd_raster_forward_batched": (_i, [_vp, _i] + [ALLOC_FN, _vp] * 3
+                                  + [_i] * 3 + [_vp] + [_i] * 2
+                                  + [_vp] * 5 + [_f] + [_vp] * 5
+                                  + [_PF] * 2 + [_i] + [_vp] * 4 + [_i]),
+    "gd_raster_backward_batched": (_i, [_vp, _i] + [_i] * 4 + [_vp] + [_i] * 2
+                                   + [_vp] * 5 + [_f] + [_vp] * 5
+                                   + [_PF] * 2 + [_vp] * 5
+                                   + [_vp] * 3 + [_vp] * 8 + [_i]),   # 8 outputs (no dL_dconic / dL_ddepth)
+    "gd_raster_get_layout": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, C.POINTER(Layout)]),
+    "gd_raster_sort_bits": (_i, [_i, _i, _i]),
+    "gd_raster_last_error": (C.c_char_p, []),
+    "gd_raster_build_info": (C.c_char_p, []),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def lib():
+    """Load libgd_raster.so (once).  Raises NativeLibraryError if it is absent -- no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise NativeLibraryError(
+                f"{_LIB_PATH} not found: build it with `python -m garmentdreamer_amd._build` "
+                "(hipcc --offload-arch=gfx950). The HIP rasterizer has no CPU fallback.")
+        try:
+            L = C.CDLL(_LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 missing
+            raise NativeLibraryError(f"cannot load {_LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here == ABI drift; let it surface
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(ret: int, what: str) -> int:
+    if ret < 0:
+        msg = lib().gd_raster_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed ({ret}): {msg}")
+    return ret

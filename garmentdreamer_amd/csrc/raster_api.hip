@@ -1,0 +1,403 @@
+// raster_api.hip -- C-ABI entry points (include/gd_raster.h) and host orchestration.
+//
+// Orchestration follows CudaRasterizer::Rasterizer::forward / backward
+// (DGR/cuda_rasterizer/rasterizer_impl.cu:197-339, 343-446) with these MI355X-side changes:
+//   * every launch goes to the caller's stream (the reference uses the legacy default stream);
+//   * scratch lives wherever the caller's allocator puts it (the reference hard-wires
+//     torch::kCUDA device 0, rasterize_points.cu:73-77);
+//   * V views of the same Gaussians can be rendered by ONE launch set (batched entry): at 512^2 a
+//     single view is only 1024 workgroups -- half of what 256 CUs can hold -- and each view
+//     would cost its own blocking read-back of num_rendered;
+//   * backward writes every output element, so the caller never pre-zeroes ten tensors.
+#include <stdio.h>
+#include <string.h>
+
+#include "raster_common.h"
+
+namespace gd {
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* detail = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define GD_HIP(expr)                                                          \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) return fail(GD_ERR_HIP, #expr ": %s", hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+void obtain(char*& chunk, T*& ptr, size_t count, size_t alignment = 128)
+{
+    size_t off = (reinterpret_cast<uintptr_t>(chunk) + alignment - 1) & ~(alignment - 1);
+    ptr = reinterpret_cast<T*>(off);
+    chunk = reinterpret_cast<char*>(ptr + count);
+}
+
+int check_debug(hipStream_t s, int debug, const char* where)
+{
+    if (!debug) return GD_OK;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "[HIP ERROR] after %s: %s", where, hipGetErrorString(e));
+        return GD_ERR_HIP;
+    }
+    return GD_OK;
+}
+
+}  // namespace
+
+GeomState carve_geom(char* chunk, size_t VP, size_t* used)
+{
+    char* p = chunk;
+    GeomState g;
+    obtain(p, g.clamped, VP * 3);
+    obtain(p, g.radii, VP);
+    obtain(p, g.means2D, VP);
+    obtain(p, g.cov3D, VP * 6);
+    obtain(p, g.conic_opacity, VP);
+    obtain(p, g.rgbd, VP);
+    obtain(p, g.tiles_touched, VP);
+    obtain(p, g.point_offsets, VP);
+    obtain(p, g.block_sums, (VP + kGaussBlock - 1) / kGaussBlock + 1);
+    if (used) *used = (size_t)(p - chunk);
+    return g;
+}
+
+ImageState carve_image(char* chunk, size_t tiles_total, size_t pixels_total, size_t* used)
+{
+    char* p = chunk;
+    ImageState im;
+    obtain(p, im.ranges, tiles_total);
+    obtain(p, im.n_contrib, pixels_total);
+    if (used) *used = (size_t)(p - chunk);
+    return im;
+}
+
+BinningState carve_binning(char* chunk, size_t R, size_t* used)
+{
+    char* p = chunk;
+    BinningState b;
+    obtain(p, b.point_list, R);
+    obtain(p, b.point_list_alt, R);
+    obtain(p, b.keys, R);
+    obtain(p, b.keys_alt, R);
+    const size_t nblk = (R + kSortTile - 1) / kSortTile;
+    obtain(p, b.sort_hist, ((size_t)1 << kMaxDigitBits) * (nblk + 1));
+    if (used) *used = (size_t)(p - chunk);
+    return b;
+}
+
+namespace {
+
+struct Dims {
+    int tiles_x, tiles_y;
+    uint32_t tiles_total;
+    size_t pixels_total;
+};
+Dims make_dims(int W, int H, int V)
+{
+    Dims d;
+    d.tiles_x = (W + kTile - 1) / kTile;
+    d.tiles_y = (H + kTile - 1) / kTile;
+    d.tiles_total = (uint32_t)V * d.tiles_x * d.tiles_y;
+    d.pixels_total = (size_t)V * W * H;
+    return d;
+}
+
+ViewScalars make_views(int V, const float* tanx, const float* tany, int W, int H)
+{
+    ViewScalars vs;
+    memset(&vs, 0, sizeof(vs));
+    vs.V = V;
+    for (int v = 0; v < V; v++) {
+        vs.tan_fovx[v] = tanx[v];
+        vs.tan_fovy[v] = tany[v];
+        vs.focal_y[v] = H / (2.0f * tany[v]);  // rasterizer_impl.cu:223-224
+        vs.focal_x[v] = W / (2.0f * tanx[v]);
+    }
+    return vs;
+}
+
+int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_user, gd_alloc_fn binning_alloc,
+                 void* binning_user, gd_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                 const float* background, int W, int H, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* cam_pos, const float* tanx, const float* tany,
+                 int prefiltered, float* out_color, float* out_depth, float* out_alpha, int* radii, int debug)
+{
+    g_err[0] = 0;
+    if (V < 1 || V > GD_MAX_VIEWS) return fail(GD_ERR_INVALID_ARG, "V must be in [1, %s]", "GD_MAX_VIEWS");
+    if (P < 0 || W <= 0 || H <= 0) return fail(GD_ERR_INVALID_ARG, "%s", "P, width, height must be positive");
+    if (!geom_alloc || !binning_alloc || !image_alloc) return fail(GD_ERR_INVALID_ARG, "%s", "allocator callbacks are required");
+    if (!out_color || !out_depth || !out_alpha) return fail(GD_ERR_INVALID_ARG, "%s", "output images are required");
+    const size_t HW = (size_t)W * H;
+    if (P == 0) {
+        // rasterize_points.cu:83: P == 0 leaves the zero-initialised outputs untouched
+        GD_HIP(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * HW * V, stream));
+        GD_HIP(hipMemsetAsync(out_depth, 0, sizeof(float) * HW * V, stream));
+        GD_HIP(hipMemsetAsync(out_alpha, 0, sizeof(float) * HW * V, stream));
+        return 0;
+    }
+    if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !cam_pos)
+        return fail(GD_ERR_INVALID_ARG, "%s", "means3D, opacities, background, viewmatrix, projmatrix, cam_pos are required");
+    if (!shs && !colors_precomp)  // NUM_CHANNELS is 3, so this is the only way to have no colour
+        return fail(GD_ERR_NON_RGB, "%s", "provide SHs or precomputed colours");
+    if (!cov3D_precomp && (!scales || !rotations))
+        return fail(GD_ERR_INVALID_ARG, "%s", "provide scales+rotations or a precomputed 3D covariance");
+
+    const size_t VP = (size_t)V * P;
+    const Dims dm = make_dims(W, H, V);
+    const ViewScalars vs = make_views(V, tanx, tany, W, H);
+
+    char* geom_chunk = geom_alloc(geom_user, gd_raster_geom_bytes(P, V));
+    char* img_chunk = image_alloc(image_user, gd_raster_image_bytes(W, H, V));
+    if (!geom_chunk || !img_chunk) return fail(GD_ERR_ALLOC, "%s", "scratch allocator returned NULL");
+    GeomState geom = carve_geom(geom_chunk, VP, nullptr);
+    ImageState img = carve_image(img_chunk, dm.tiles_total, dm.pixels_total, nullptr);
+    if (radii == nullptr) radii = geom.radii;
+
+    launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+                      colors_precomp, viewmatrix, projmatrix, cam_pos, W, H, vs, radii, geom, dm.tiles_x, dm.tiles_y,
+                      prefiltered != 0);
+    if (int e = check_debug(stream, debug, "preprocess")) return e;
+    const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
+    launch_scan_block_sums(stream, geom.block_sums, nblk);
+    if (int e = check_debug(stream, debug, "scan")) return e;
+
+    // the one host sync of the forward pass (rasterizer_impl.cu:282)
+    uint32_t num_rendered = 0;
+    GD_HIP(hipMemcpyAsync(&num_rendered, geom.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GD_HIP(hipStreamSynchronize(stream));
+    if (num_rendered > 0x7fffffffu) return fail(GD_ERR_INVALID_ARG, "%s", "num_rendered exceeds int32");
+
+    char* bin_chunk = binning_alloc(binning_user, gd_raster_binning_bytes(num_rendered));
+    if (!bin_chunk) return fail(GD_ERR_ALLOC, "%s", "binning allocator returned NULL");
+    BinningState bin = carve_binning(bin_chunk, num_rendered, nullptr);
+
+    const SortPlan plan = plan_sort(dm.tiles_total);
+    const bool start_in_alt = (plan.passes & 1) != 0;
+    launch_duplicate(stream, (int)VP, P, radii, geom, start_in_alt ? bin.keys_alt : bin.keys,
+                     start_in_alt ? bin.point_list_alt : bin.point_list, dm.tiles_x, dm.tiles_y);
+    if (int e = check_debug(stream, debug, "duplicate")) return e;
+    launch_radix_sort(stream, bin, num_rendered, plan, start_in_alt);
+    if (int e = check_debug(stream, debug, "sort")) return e;
+    launch_tile_ranges(stream, bin.keys, num_rendered, img.ranges, dm.tiles_total);
+    if (int e = check_debug(stream, debug, "ranges")) return e;
+    launch_render_forward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
+                          out_color, out_depth, out_alpha, img.n_contrib);
+    if (int e = check_debug(stream, debug, "render")) return e;
+    GD_HIP(hipGetLastError());
+    return (int)num_rendered;
+}
+
+int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const float* background, int W, int H,
+                  const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
+                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                  const float* viewmatrix, const float* projmatrix, const float* campos, const float* tanx,
+                  const float* tany, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                  char* bwd_scratch, const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dalphas,
+                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
+{
+    g_err[0] = 0;
+    if (V < 1 || V > GD_MAX_VIEWS) return fail(GD_ERR_INVALID_ARG, "V must be in [1, %s]", "GD_MAX_VIEWS");
+    if (P == 0) return GD_OK;
+    if (!geom_buffer || !binning_buffer || !image_buffer || !bwd_scratch)
+        return fail(GD_ERR_INVALID_ARG, "%s", "geom/binning/image/backward scratch buffers are required");
+    if (!dL_dpix || !dL_dpix_depth || !dL_dalphas || !alphas)
+        return fail(GD_ERR_INVALID_ARG, "%s", "dL_dpix, dL_dpix_depth, dL_dalphas and alphas are required");
+    if (!dL_dmean3D || !dL_dopacity) return fail(GD_ERR_INVALID_ARG, "%s", "dL_dmean3D and dL_dopacity are required");
+    const size_t VP = (size_t)V * P;
+    const Dims dm = make_dims(W, H, V);
+    const ViewScalars vs = make_views(V, tanx, tany, W, H);
+    GeomState geom = carve_geom(geom_buffer, VP, nullptr);
+    BinningState bin = carve_binning(binning_buffer, (size_t)R, nullptr);
+    ImageState img = carve_image(image_buffer, dm.tiles_total, dm.pixels_total, nullptr);
+    if (radii == nullptr) radii = geom.radii;
+
+    float* acc = nullptr;
+    {
+        char* p = bwd_scratch;
+        obtain(p, acc, VP * 10);
+    }
+    GD_HIP(hipMemsetAsync(acc, 0, sizeof(float) * VP * 10, stream));
+    if (R > 0)
+        launch_render_backward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
+                               alphas, img.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc);
+    if (int e = check_debug(stream, debug, "render backward")) return e;
+
+    const float* cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
+    const size_t cov_stride = cov3D_precomp ? 0 : (size_t)P * 6;
+    launch_preprocess_backward(stream, P, D, M, V, means3D, radii, shs, geom.clamped, scales, rotations,
+                               scale_modifier, cov3D, cov_stride, viewmatrix, projmatrix, campos, vs, acc,
+                               colors_precomp != nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth,
+                               dL_dmean3D, dL_dcov3D, shs ? dL_dsh : nullptr, scales ? dL_dscale : nullptr,
+                               scales ? dL_drot : nullptr, nullptr);
+    if (int e = check_debug(stream, debug, "preprocess backward")) return e;
+    GD_HIP(hipGetLastError());
+    return GD_OK;
+}
+
+}  // namespace
+
+}  // namespace gd
+
+using namespace gd;
+
+extern "C" {
+
+size_t gd_raster_geom_bytes(int P, int V)
+{
+    size_t used = 0;
+    carve_geom(nullptr, (size_t)P * (size_t)(V < 1 ? 1 : V), &used);
+    return used + 128;
+}
+size_t gd_raster_image_bytes(int width, int height, int V)
+{
+    size_t used = 0;
+    const Dims d = make_dims(width, height, V < 1 ? 1 : V);
+    carve_image(nullptr, d.tiles_total, d.pixels_total, &used);
+    return used + 128;
+}
+size_t gd_raster_binning_bytes(int64_t R)
+{
+    size_t used = 0;
+    carve_binning(nullptr, (size_t)(R < 0 ? 0 : R), &used);
+    return used + 128;
+}
+size_t gd_raster_backward_scratch_bytes(int P, int V) { return (size_t)P * (size_t)(V < 1 ? 1 : V) * 10 * sizeof(float) + 128; }
+
+int gd_raster_forward(void* stream, gd_alloc_fn geom_alloc, void* geom_user, gd_alloc_fn binning_alloc,
+                      void* binning_user, gd_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                      const float* background, int width, int height, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales,
+                      float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                      float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_alpha,
+                      int* radii, int debug)
+{
+    return forward_impl((hipStream_t)stream, 1, geom_alloc, geom_user, binning_alloc, binning_user, image_alloc,
+                        image_user, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
+                        scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, &tan_fovx,
+                        &tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug);
+}
+
+int gd_raster_forward_batched(void* stream, int V, gd_alloc_fn geom_alloc, void* geom_user,
+                              gd_alloc_fn binning_alloc, void* binning_user, gd_alloc_fn image_alloc,
+                              void* image_user, int P, int D, int M, const float* background, int width,
+                              int height, const float* means3D, const float* shs, const float* colors_precomp,
+                              const float* opacities, const float* scales, float scale_modifier,
+                              const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                              const float* projmatrix, const float* cam_pos, const float* tan_fovx,
+                              const float* tan_fovy, int prefiltered, float* out_color, float* out_depth,
+                              float* out_alpha, int* radii, int debug)
+{
+    if (!tan_fovx || !tan_fovy) return fail(GD_ERR_INVALID_ARG, "%s", "tan_fovx / tan_fovy host arrays are required");
+    return forward_impl((hipStream_t)stream, V, geom_alloc, geom_user, binning_alloc, binning_user, image_alloc,
+                        image_user, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
+                        scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                        tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug);
+}
+
+int gd_raster_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
+                       const float* scales, float scale_modifier, const float* rotations,
+                       const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                       const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer,
+                       char* binning_buffer, char* image_buffer, char* bwd_scratch, const float* dL_dpix,
+                       const float* dL_dpix_depth, const float* dL_dalphas, float* dL_dmean2D, float* dL_dconic,
+                       float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+                       float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
+{
+    return backward_impl((hipStream_t)stream, 1, P, D, M, R, background, width, height, means3D, shs, colors_precomp,
+                         alphas, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos,
+                         &tan_fovx, &tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, bwd_scratch, dL_dpix,
+                         dL_dpix_depth, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth,
+                         dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
+}
+
+int gd_raster_backward_batched(void* stream, int V, int P, int D, int M, int R, const float* background,
+                               int width, int height, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* alphas, const float* scales,
+                               float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                               const float* viewmatrix, const float* projmatrix, const float* campos,
+                               const float* tan_fovx, const float* tan_fovy, const int* radii, char* geom_buffer,
+                               char* binning_buffer, char* image_buffer, char* bwd_scratch, const float* dL_dpix,
+                               const float* dL_dpix_depth, const float* dL_dalphas, float* dL_dmean2D,
+                               float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                               float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
+{
+    if (!tan_fovx || !tan_fovy) return fail(GD_ERR_INVALID_ARG, "%s", "tan_fovx / tan_fovy host arrays are required");
+    return backward_impl((hipStream_t)stream, V, P, D, M, R, background, width, height, means3D, shs, colors_precomp,
+                         alphas, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos,
+                         tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, bwd_scratch, dL_dpix,
+                         dL_dpix_depth, dL_dalphas, dL_dmean2D, nullptr, dL_dopacity, dL_dcolor, nullptr, dL_dmean3D,
+                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
+}
+
+int gd_raster_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
+                           const float* projmatrix, uint8_t* present)
+{
+    (void)projmatrix;  // in_frustum only tests view-space z (auxiliary.h:153)
+    g_err[0] = 0;
+    if (P == 0) return GD_OK;
+    if (!means3D || !viewmatrix || !present) return fail(GD_ERR_INVALID_ARG, "%s", "means3D, viewmatrix, present are required");
+    launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
+    GD_HIP(hipGetLastError());
+    return GD_OK;
+}
+
+int gd_raster_get_layout(const char* geom_base, const char* image_base, const char* binning_base, int P, int V,
+                         int width, int height, int64_t R, gd_raster_layout* out)
+{
+    if (!out) return GD_ERR_INVALID_ARG;
+    const size_t VP = (size_t)P * V;
+    const Dims d = make_dims(width, height, V);
+    GeomState g = carve_geom(const_cast<char*>(geom_base), VP, nullptr);
+    ImageState im = carve_image(const_cast<char*>(image_base), d.tiles_total, d.pixels_total, nullptr);
+    BinningState b = carve_binning(const_cast<char*>(binning_base), (size_t)R, nullptr);
+#define OFF(base, p) ((size_t)(reinterpret_cast<const char*>(p) - (base)))
+    out->depths = OFF(geom_base, g.rgbd) + 12;  // depth is the .w of rgbd (stride 16 B)
+    out->clamped = OFF(geom_base, g.clamped);
+    out->radii = OFF(geom_base, g.radii);
+    out->means2D = OFF(geom_base, g.means2D);
+    out->cov3D = OFF(geom_base, g.cov3D);
+    out->conic_opacity = OFF(geom_base, g.conic_opacity);
+    out->rgb = OFF(geom_base, g.rgbd);
+    out->tiles_touched = OFF(geom_base, g.tiles_touched);
+    out->point_offsets = OFF(geom_base, g.point_offsets);
+    out->block_sums = OFF(geom_base, g.block_sums);
+    out->ranges = OFF(image_base, im.ranges);
+    out->n_contrib = OFF(image_base, im.n_contrib);
+    out->point_list = OFF(binning_base, b.point_list);
+    out->point_list_alt = OFF(binning_base, b.point_list_alt);
+    out->keys = OFF(binning_base, b.keys);
+    out->keys_alt = OFF(binning_base, b.keys_alt);
+    out->sort_hist = OFF(binning_base, b.sort_hist);
+#undef OFF
+    return GD_OK;
+}
+
+int gd_raster_sort_bits(int width, int height, int V)
+{
+    const Dims d = make_dims(width, height, V < 1 ? 1 : V);
+    return plan_sort(d.tiles_total).total_bits;
+}
+
+const char* gd_raster_last_error(void) { return g_err; }
+
+const char* gd_raster_build_info(void)
+{
+    return "garmentdreamer_amd rasterizer: gfx950 (CDNA4), wave64, 16x16 tiles, HIP " __VERSION__;
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+// raster_binning.hip -- tile binning of the gfx950 rasterizer: offsets, instance duplication,
+// stable LSD radix sort of (tile | depth) keys, per-tile ranges.
+//
+//   scan_block_sums_kernel  second half of the InclusiveSum (rasterizer_impl.cu:278); the first
+//                           half (per-workgroup totals) is fused into the preprocess kernel and
+//                           the intra-workgroup scan into the duplicate kernel, so the scan costs
+//                           one tiny launch instead of a device-wide pass.
+//   duplicate_kernel        duplicateWithKeys (rasterizer_impl.cu:70-111)
+//   radix_*                 replaces cub::DeviceRadixSort::SortPairs (rasterizer_impl.cu:304-309).
+//                           Hand-written for wave64: per-wave digit matching with 64-bit ballots,
+//                           digits up to 11 bits (2048 bins live in LDS) so the 43..46 key bits
+//                           take 4-5 passes instead of cub's 6.  The result is the unique stable
+//                           order, i.e. bit-identical to any other stable sort on the same bits.
+//   tile_ranges_kernel      identifyTileRanges (rasterizer_impl.cu:116-138)
+//
+// All of this is integer / byte work bounded by HBM and launch latency, not by ALU.
+#include "raster_common.h"
+
+namespace gd {
+
+uint32_t higher_msb(uint32_t n)  // getHigherMsb, rasterizer_impl.cu:35-50
+{
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step;
+        else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+SortPlan plan_sort(uint32_t tiles_total)
+{
+    SortPlan p;
+    p.total_bits = 32 + (int)higher_msb(tiles_total);
+    p.passes = (p.total_bits + kMaxDigitBits - 1) / kMaxDigitBits;
+    p.digit_bits = (p.total_bits + p.passes - 1) / p.passes;
+    if (p.digit_bits < 8) p.digit_bits = 8;
+    return p;
+}
+
+namespace {
+
+// Exclusive scan of block_sums[0..n) in place; block_sums[n] receives the grand total (= R).
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ sums, uint32_t n)
+{
+    __shared__ uint32_t wave_incl[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < n ? sums[i] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        if (lane == 63) wave_incl[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < wave; w++) wave_off += wave_incl[w];
+        const uint32_t carry = carry_s;
+        if (i < n) sums[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) sums[n] = carry_s;
+}
+
+__global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, const int* __restrict__ radii,
+                                                                GeomState gs, uint64_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out, uint32_t gx,
+                                                                uint32_t gy)
+{
+    __shared__ uint32_t wave_incl[kGaussBlock / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vp = blockIdx.x * kGaussBlock + tid;
+    const uint32_t touched = vp < VP ? gs.tiles_touched[vp] : 0;
+    uint32_t incl = touched;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += t;
+    }
+    if (lane == 63) wave_incl[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (uint32_t w = 0; w < wave; w++) wave_off += wave_incl[w];
+    const uint32_t incl_global = gs.block_sums[blockIdx.x] + wave_off + incl;
+    if (vp >= VP) return;
+    gs.point_offsets[vp] = incl_global;  // inclusive, as the reference stores it
+    const int r = radii[vp];
+    if (r > 0) {
+        uint32_t off = incl_global - touched;
+        const float2 xy = gs.means2D[vp];
+        uint32_t x0, y0, x1, y1;
+        tile_rect(xy.x, xy.y, r, gx, gy, x0, y0, x1, y1);
+        const uint32_t depth_bits = __float_as_uint(gs.rgbd[vp].w);
+        const uint32_t view_tile0 = (uint32_t)(vp / P) * gx * gy;
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) {
+                uint64_t key = (uint64_t)(view_tile0 + y * gx + x);
+                key <<= 32;
+                key |= depth_bits;
+                keys_out[off] = key;
+                vals_out[off] = (uint32_t)vp;
+                off++;
+            }
+    }
+}
+
+// ---------------- radix sort ----------------
+// Element i of a workgroup tile belongs to wave i / (64*kSortItems); inside the wave the order
+// is (step, lane).  Stability follows from ranking in exactly that order.
+
+template <int BITS>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift,
+                                                         uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk)
+{
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t h[BINS];
+    for (int i = threadIdx.x; i < BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t idx = base + k * 256 + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BINS; i += 256) hist[(size_t)i * nblk + blockIdx.x] = h[i];
+}
+
+// One workgroup per digit: exclusive scan of hist[d][0..nblk) in place, digit total -> totals[d].
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ hist, uint32_t nblk,
+                                                         uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t wave_incl[4];
+    __shared__ uint32_t carry_s;
+    uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblk; base += 256) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < nblk ? row[i] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        if (lane == 63) wave_incl[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < wave; w++) wave_off += wave_incl[w];
+        const uint32_t carry = carry_s;
+        if (i < nblk) row[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (tid == 255) carry_s = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) totals[blockIdx.x] = carry_s;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
+                                                            const uint32_t* __restrict__ vals_in,
+                                                            uint64_t* __restrict__ keys_out,
+                                                            uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                            uint32_t mask, const uint32_t* __restrict__ hist,
+                                                            const uint32_t* __restrict__ totals, uint32_t nblk)
+{
+    constexpr int BINS = 1 << BITS;
+    constexpr int PER_THREAD = BINS / 256;
+    __shared__ uint32_t cnt[4][BINS];    // per-wave running digit counts, later wave bases
+    __shared__ uint32_t dbase[BINS];     // global base of digit d for this workgroup
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // exclusive scan of digit totals (BINS entries) + this workgroup's offset inside each digit
+    uint32_t loc[PER_THREAD];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; k++) {
+        loc[k] = totals[tid * PER_THREAD + k];
+        sum += loc[k];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    for (int i = tid; i < 4 * BINS; i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < wave; w++) run += wave_tot[w];
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; k++) {
+        const int d = tid * PER_THREAD + k;
+        dbase[d] = run + hist[(size_t)d * nblk + blockIdx.x];
+        run += loc[k];
+    }
+    __syncthreads();
+
+    // rank every key inside its wave
+    const uint32_t base = blockIdx.x * kSortTile + wave * (64 * kSortItems);
+    uint64_t key[kSortItems];
+    uint32_t rank[kSortItems];
+    volatile uint32_t* wc = cnt[wave];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int s = 0; s < kSortItems; s++) {
+        const uint32_t idx = base + s * 64 + lane;
+        const bool valid = idx < n;
+        key[s] = valid ? keys_in[idx] : ~0ull;
+        const uint32_t d = (uint32_t)(key[s] >> shift) & mask;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < BITS; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+        uint32_t r = 0;
+        if (valid) {
+            const uint32_t c = wc[d];
+            r = c + before;
+            if (before == 0) wc[d] = c + (uint32_t)__popcll(peers);
+        }
+        rank[s] = r;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // turn per-wave counts into per-wave bases (exclusive over waves) + global digit base
+    for (int d = tid; d < BINS; d += 256) {
+        uint32_t run2 = dbase[d];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t c = cnt[w][d];
+            cnt[w][d] = run2;
+            run2 += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kSortItems; s++) {
+        const uint32_t idx = base + s * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = (uint32_t)(key[s] >> shift) & mask;
+            const uint32_t pos = cnt[wave][d] + rank[s];
+            keys_out[pos] = key[s];
+            vals_out[pos] = vals_in[idx];
+        }
+    }
+}
+
+__global__ void tile_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t L, uint2* __restrict__ ranges)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (cur != prev) {
+            ranges[prev].y = idx;
+            ranges[cur].x = idx;
+        }
+    }
+    if (idx == L - 1) ranges[cur].y = L;
+}
+
+template <int BITS>
+void sort_pass(hipStream_t s, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, uint32_t n,
+               int shift, int width, uint32_t* hist, uint32_t nblk)
+{
+    constexpr int BINS = 1 << BITS;
+    uint32_t* totals = hist + (size_t)BINS * nblk;
+    const uint32_t mask = (1u << width) - 1u;
+    hipLaunchKernelGGL(radix_hist_kernel<BITS>, dim3(nblk), dim3(256), 0, s, kin, n, shift, mask, hist, nblk);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(BINS), dim3(256), 0, s, hist, nblk, totals);
+    hipLaunchKernelGGL(radix_scatter_kernel<BITS>, dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout, n, shift, mask,
+                       hist, totals, nblk);
+}
+
+}  // namespace
+
+void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks)
+{
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nblocks);
+}
+
+void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* keys_out,
+                      uint32_t* vals_out, int tiles_x, int tiles_y)
+{
+    const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
+    hipLaunchKernelGGL(duplicate_kernel, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, keys_out, vals_out,
+                       (uint32_t)tiles_x, (uint32_t)tiles_y);
+}
+
+// Sorts (keys, vals) of length R on the low plan.total_bits bits.  The unsorted input sits in
+// the *_alt buffers when start_in_alt, else in the primary buffers; the caller picks that so
+// the final pass lands in b.keys / b.point_list.
+void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan, bool start_in_alt)
+{
+    if (R == 0) return;
+    const uint32_t nblk = (R + kSortTile - 1) / kSortTile;
+    uint64_t* k[2] = {b.keys, b.keys_alt};
+    uint32_t* v[2] = {b.point_list, b.point_list_alt};
+    int cur = start_in_alt ? 1 : 0;
+    for (int p = 0; p < plan.passes; p++) {
+        const int shift = p * plan.digit_bits;
+        int width = plan.total_bits - shift;
+        if (width > plan.digit_bits) width = plan.digit_bits;
+        switch (plan.digit_bits) {
+            case 8: sort_pass<8>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk); break;
+            case 9: sort_pass<9>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk); break;
+            case 10: sort_pass<10>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk); break;
+            default: sort_pass<11>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk); break;
+        }
+        cur ^= 1;
+    }
+}
+
+void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total)
+{
+    (void)hipMemsetAsync(ranges, 0, (size_t)tiles_total * sizeof(uint2), s);
+    if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges);
+}
+
+}  // namespace gd

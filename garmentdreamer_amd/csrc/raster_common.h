@@ -1,0 +1,100 @@
+// raster_common.h -- shared declarations of the gfx950 Gaussian rasterizer kernels.
+// Internal to garmentdreamer_amd/csrc; the public boundary is include/gd_raster.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/gd_raster.h"
+
+namespace gd {
+
+constexpr int kTile = 16;        // BLOCK_X = BLOCK_Y = 16 is part of the parity contract
+constexpr int kTilePix = 256;    // (DGR/cuda_rasterizer/config.h:16-17)
+constexpr int kGaussBlock = 256; // Gaussians per workgroup in per-Gaussian kernels
+
+// Per-view scalars passed by value as a kernel argument (no device round trip).
+struct ViewScalars {
+    int V;
+    float tan_fovx[GD_MAX_VIEWS];
+    float tan_fovy[GD_MAX_VIEWS];
+    float focal_x[GD_MAX_VIEWS];
+    float focal_y[GD_MAX_VIEWS];
+};
+
+// Scratch carved from the caller's byte buffers; index vp = view * P + gaussian.
+struct GeomState {
+    uint8_t* clamped;         // [VP*3]
+    int* radii;               // [VP] (used when the caller passes radii == NULL)
+    float2* means2D;          // [VP]
+    float* cov3D;             // [VP*6]
+    float4* conic_opacity;    // [VP]
+    float4* rgbd;             // [VP] colour (SH-evaluated or precomputed) + view-space depth
+    uint32_t* tiles_touched;  // [VP]
+    uint32_t* point_offsets;  // [VP] inclusive scan of tiles_touched
+    uint32_t* block_sums;     // [ceil(VP/256) + 1] exclusive-scanned block totals, last = R
+};
+struct ImageState {
+    uint2* ranges;        // [V*tiles]
+    uint32_t* n_contrib;  // [V*H*W]
+};
+struct BinningState {
+    uint32_t* point_list;      // [R] sorted values (vp indices)
+    uint32_t* point_list_alt;  // [R]
+    uint64_t* keys;            // [R] sorted keys
+    uint64_t* keys_alt;        // [R]
+    uint32_t* sort_hist;       // [bins * nblk + bins]
+};
+
+GeomState carve_geom(char* chunk, size_t VP, size_t* used);
+ImageState carve_image(char* chunk, size_t tiles_total, size_t pixels_total, size_t* used);
+BinningState carve_binning(char* chunk, size_t R, size_t* used);
+
+uint32_t higher_msb(uint32_t n);
+struct SortPlan { int total_bits, passes, digit_bits; };
+SortPlan plan_sort(uint32_t tiles_total);
+constexpr int kSortItems = 8;                      // keys per thread
+constexpr int kSortTile = 256 * kSortItems;        // keys per workgroup
+constexpr int kMaxDigitBits = 11;
+
+// getRect (DGR/cuda_rasterizer/auxiliary.h:46-56): tile rectangle of a splat, clamped to the grid.
+__device__ __forceinline__ void tile_rect(float px, float py, int max_radius, uint32_t gx, uint32_t gy,
+                                          uint32_t& x0, uint32_t& y0, uint32_t& x1, uint32_t& y1)
+{
+    x0 = min(gx, (uint32_t)max(0, (int)((px - max_radius) / kTile)));
+    y0 = min(gy, (uint32_t)max(0, (int)((py - max_radius) / kTile)));
+    x1 = min(gx, (uint32_t)max(0, (int)((px + max_radius + kTile - 1) / kTile)));
+    y1 = min(gy, (uint32_t)max(0, (int)((py + max_radius + kTile - 1) / kTile)));
+}
+
+// ---- launchers (one per translation unit) ----
+void launch_preprocess(hipStream_t s, int P, int D, int M, const float* means3D, const float* scales,
+                       float scale_modifier, const float* rotations, const float* opacities, const float* shs,
+                       const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
+                       const float* projmatrix, const float* cam_pos, int W, int H, const ViewScalars& vs,
+                       int* radii, GeomState g, int tiles_x, int tiles_y, bool prefiltered);
+void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present);
+void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const float* means3D, const int* radii,
+                                const float* shs, const uint8_t* clamped, const float* scales,
+                                const float* rotations, float scale_modifier, const float* cov3D,
+                                size_t cov3D_view_stride, const float* viewmatrix, const float* projmatrix,
+                                const float* campos, const ViewScalars& vs, const float* acc /*[VP][10]*/,
+                                bool colors_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
+                                float* dL_dsh, float* dL_dscale, float* dL_drot, float* view_partials);
+
+void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks);
+void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* keys_out,
+                      uint32_t* vals_out, int tiles_x, int tiles_y);
+void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan, bool start_in_alt);
+void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total);
+
+void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
+                           const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
+                           float* out_depth, float* out_alpha, uint32_t* n_contrib);
+void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
+                            const uint32_t* point_list, const GeomState& g, const float* bg, const float* alphas,
+                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
+                            const float* dL_dalphas, float* acc /*[VP][10], zeroed*/);
+
+}  // namespace gd

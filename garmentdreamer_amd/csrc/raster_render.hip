@@ -1,0 +1,317 @@
+// raster_render.hip -- per-tile alpha blending (forward) and its reverse-order gradient pass
+// for gfx950.
+//
+//   render_forward_kernel   <- renderCUDA forward  (DGR/cuda_rasterizer/forward.cu:261-381)
+//   render_backward_kernel  <- renderCUDA backward (DGR/cuda_rasterizer/backward.cu:415-601)
+//
+// Mapping to CDNA4.  A 16x16 tile is one 256-thread workgroup = 4 wave64s, each wave owning
+// 4 rows x 16 columns of pixels.  Per round of 256 list entries the workgroup stages
+// xy (8 B), conic+opacity (16 B) and colour+depth (16 B) of each entry in LDS once -- the
+// reference re-gathers colour and depth from global memory per contributing pair
+// (forward.cu:359-361).  All lanes then read the same LDS address (broadcast, conflict free).
+//
+// Backward: the reference issues 10 fp32 atomicAdd per contributing (pixel, Gaussian) pair
+// (backward.cu:555-598).  Here the 10 partials are first summed over the 64 lanes of a wave
+// with DPP row operations (no LDS traffic), the 4 waves of the tile combine through LDS
+// atomics (ds_add_f32), and each workgroup then issues at most one global atomic per
+// (tile, entry, component): a 256x cut of L2 atomic traffic.  Entries no pixel of the wave
+// touches are skipped before the reduction, and list entries behind every pixel's last
+// contributor are never visited at all.  The accumulation target is an interleaved
+// acc[vp][10] row (40 B, one or two cache lines per Gaussian) instead of five separate arrays.
+//
+// Blocks are mapped to tiles so that each XCD (private 4 MiB L2) works on a contiguous band
+// of tiles: neighbouring tiles share most of their Gaussian lists.
+//
+// Numerics: same operation order as the reference per pixel; FMA contraction is allowed here
+// (pixel / gradient parity is a tolerance), expf is the accurate libm form so that
+// the 1/255 and 1e-4 thresholds (and therefore n_contrib) agree with the oracle.
+#include "raster_common.h"
+
+namespace gd {
+
+namespace {
+
+__device__ __forceinline__ uint32_t block_to_tile(uint32_t b, uint32_t n)
+{
+    // workgroup b is observed to run on XCD b % 8 (placement is a speed hint only)
+    if ((n & 7u) == 0) {
+        const uint32_t per = n >> 3;
+        return (b & 7u) * per + (b >> 3);
+    }
+    return b;
+}
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_term(float v)
+{
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+
+// Sum over the 64 lanes of a wave; the total is valid in lane 63.
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v += dpp_term<0xB1, 0xf, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_term<0x4E, 0xf, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_term<0x141, 0xf, 0xf>(v);  // row_half_mirror
+    v += dpp_term<0x140, 0xf, 0xf>(v);  // row_mirror      -> every lane holds its row's sum
+    v += dpp_term<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1,3
+    v += dpp_term<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = total
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(kTilePix) void render_forward_kernel(
+    int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
+    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
+    float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    uint32_t* __restrict__ n_contrib)
+{
+    __shared__ float2 s_xy[kTilePix];
+    __shared__ float4 s_co[kTilePix];
+    __shared__ float4 s_fd[kTilePix];
+
+    const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
+    const uint32_t tpv = gx * gy;
+    const uint32_t view = tile / tpv;
+    const uint32_t lt = tile - view * tpv;
+    const uint32_t ty = lt / gx, tx = lt - ty * gx;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + (tid >> 4);
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)W * py + px;
+    const float pixf_x = (float)px, pixf_y = (float)py;
+
+    bool done = !inside;
+    const uint2 range = ranges[tile];
+    const int rounds = (int)((range.y - range.x + kTilePix - 1) / kTilePix);
+    int toDo = (int)(range.y - range.x);
+
+    float T = 1.0f;
+    uint32_t contributor = 0, last_contributor = 0;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f;
+
+    for (int i = 0; i < rounds; i++, toDo -= kTilePix) {
+        if (__syncthreads_count(done) == kTilePix) break;
+        const uint32_t progress = (uint32_t)i * kTilePix + tid;
+        if (range.x + progress < range.y) {
+            const uint32_t id = point_list[range.x + progress];
+            s_xy[tid] = means2D[id];
+            s_co[tid] = conic_opacity[id];
+            s_fd[tid] = rgbd[id];
+        }
+        __syncthreads();
+        const int n = min(kTilePix, toDo);
+        for (int j = 0; !done && j < n; j++) {
+            contributor++;
+            const float2 xy = s_xy[j];
+            const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
+            const float4 co = s_co[j];
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, co.w * expf(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1 - alpha);
+            if (test_T < 0.0001f) {
+                done = true;
+                continue;
+            }
+            const float4 fd = s_fd[j];
+            const float w = alpha * T;
+            C0 += fd.x * alpha * T;
+            C1 += fd.y * alpha * T;
+            C2 += fd.z * alpha * T;
+            weight += w;
+            Dd += fd.w * alpha * T;
+            T = test_T;
+            last_contributor = contributor;
+        }
+    }
+    if (inside) {
+        n_contrib[(size_t)view * HW + pix_id] = last_contributor;
+        float* oc = out_color + (size_t)view * 3 * HW;
+        oc[0 * HW + pix_id] = C0 + T * bg_color[0];
+        oc[1 * HW + pix_id] = C1 + T * bg_color[1];
+        oc[2 * HW + pix_id] = C2 + T * bg_color[2];
+        out_alpha[(size_t)view * HW + pix_id] = weight;
+        out_depth[(size_t)view * HW + pix_id] = Dd;
+    }
+}
+
+constexpr int kAcc = 10;  // colour rgb, depth, mean2D xy, conic x/y/w, opacity
+
+__global__ __launch_bounds__(kTilePix) void render_backward_kernel(
+    int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
+    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
+    const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+    const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ acc)
+{
+    __shared__ float2 s_xy[kTilePix];
+    __shared__ float4 s_co[kTilePix];
+    __shared__ float4 s_fd[kTilePix];
+    __shared__ uint32_t s_id[kTilePix];
+    __shared__ float s_acc[kTilePix * kAcc];
+    __shared__ uint32_t s_wmax[4];
+
+    const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
+    const uint32_t tpv = gx * gy;
+    const uint32_t view = tile / tpv;
+    const uint32_t lt = tile - view * tpv;
+    const uint32_t ty = lt / gx, tx = lt - ty * gx;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + (tid >> 4);
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix_id = (size_t)view * HW + (size_t)W * py + px;
+    const float pixf_x = (float)px, pixf_y = (float)py;
+
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+
+    const float T_final = inside ? (1 - alphas[pix_id]) : 0;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0;
+
+    float accum_rec0 = 0, accum_rec1 = 0, accum_rec2 = 0, accum_depth_rec = 0, accum_alpha_rec = 0;
+    float dLp0 = 0, dLp1 = 0, dLp2 = 0, dLpd = 0, dLa = 0;
+    if (inside) {
+        const float* dp = dL_dpixels + (size_t)view * 3 * HW + ((size_t)W * py + px);
+        dLp0 = dp[0]; dLp1 = dp[HW]; dLp2 = dp[2 * HW];
+        dLpd = dL_dpixel_depths[pix_id];
+        dLa = dL_dalphas[pix_id];
+    }
+    float last_alpha = 0, last_c0 = 0, last_c1 = 0, last_c2 = 0, last_depth = 0;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const float bg_dot_dpixel = bg_color[0] * dLp0 + bg_color[1] * dLp1 + bg_color[2] * dLp2;
+
+    // Entries whose ordinal is >= every pixel's last contributor are dead for the whole wave /
+    // workgroup: skip them (the reference walks them and `continue`s per pixel, backward.cu:517-519).
+    const uint32_t wmax = wave_max_u32(last_contributor);
+    if (lane == 0) s_wmax[wave] = wmax;
+    for (int i = tid; i < kTilePix * kAcc; i += kTilePix) s_acc[i] = 0.f;
+    __syncthreads();
+    const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    if (bmax == 0) return;
+    const int first_p_block = total - (int)bmax;  // first reverse position any pixel uses
+    const int first_p_wave = total - (int)wmax;
+    const int rounds = (total + kTilePix - 1) / kTilePix;
+
+    for (int i = first_p_block / kTilePix; i < rounds; i++) {
+        const int round_base = i * kTilePix;
+        const int n = min(kTilePix, total - round_base);
+        __syncthreads();  // previous round's flush is complete
+        if ((int)tid < n) {
+            const uint32_t id = point_list[range.y - (uint32_t)(round_base + (int)tid) - 1];
+            s_id[tid] = id;
+            s_xy[tid] = means2D[id];
+            s_co[tid] = conic_opacity[id];
+            s_fd[tid] = rgbd[id];
+        }
+        __syncthreads();
+        if (wmax != 0) {
+            for (int j = max(0, first_p_wave - round_base); j < n; j++) {
+                const uint32_t ordinal = (uint32_t)(total - 1 - (round_base + j));
+                const float2 xy = s_xy[j];
+                const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
+                const float4 co = s_co[j];
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                const float G = expf(power);
+                const float alpha = fminf(0.99f, co.w * G);
+                const bool valid = (ordinal < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (!__any(valid)) continue;
+                float v[kAcc];
+#pragma unroll
+                for (int k = 0; k < kAcc; k++) v[k] = 0.f;
+                if (valid) {
+                    const float inv = 1.f / (1.f - alpha);
+                    T = T * inv;
+                    const float dchannel_dcolor = alpha * T;
+                    const float4 fd = s_fd[j];
+                    float dL_dopa = 0.0f;
+                    accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0;
+                    accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1;
+                    accum_rec2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2;
+                    last_c0 = fd.x; last_c1 = fd.y; last_c2 = fd.z;
+                    dL_dopa += (fd.x - accum_rec0) * dLp0;
+                    dL_dopa += (fd.y - accum_rec1) * dLp1;
+                    dL_dopa += (fd.z - accum_rec2) * dLp2;
+                    v[0] = dchannel_dcolor * dLp0;
+                    v[1] = dchannel_dcolor * dLp1;
+                    v[2] = dchannel_dcolor * dLp2;
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    last_depth = fd.w;
+                    dL_dopa += (fd.w - accum_depth_rec) * dLpd;
+                    v[3] = dchannel_dcolor * dLpd;
+                    accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
+                    dL_dopa += (1 - accum_alpha_rec) * dLa;
+                    dL_dopa *= T;
+                    last_alpha = alpha;
+                    dL_dopa += (-T_final * inv) * bg_dot_dpixel;
+                    const float dL_dG = co.w * dL_dopa;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                    const float dG_ddely = -gdy * co.z - gdx * co.y;
+                    v[4] = dL_dG * dG_ddelx * ddelx_dx;
+                    v[5] = dL_dG * dG_ddely * ddely_dy;
+                    v[6] = -0.5f * gdx * dx * dL_dG;
+                    v[7] = -0.5f * gdx * dy * dL_dG;
+                    v[8] = -0.5f * gdy * dy * dL_dG;
+                    v[9] = G * dL_dopa;
+                }
+#pragma unroll
+                for (int k = 0; k < kAcc; k++) v[k] = wave_sum_to_lane63(v[k]);
+                if (lane == 63) {
+#pragma unroll
+                    for (int k = 0; k < kAcc; k++) atomicAdd(&s_acc[j * kAcc + k], v[k]);
+                }
+            }
+        }
+        __syncthreads();
+        // flush this round: one global atomic per touched (entry, component)
+        if ((int)tid < n) {
+            float* dst = acc + (size_t)s_id[tid] * kAcc;
+#pragma unroll
+            for (int k = 0; k < kAcc; k++) {
+                const float val = s_acc[tid * kAcc + k];
+                if (val != 0.f) {
+                    atomicAdd(dst + k, val);
+                    s_acc[tid * kAcc + k] = 0.f;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
+                           const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
+                           float* out_depth, float* out_alpha, uint32_t* n_contrib)
+{
+    const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
+    hipLaunchKernelGGL(render_forward_kernel, dim3(tiles_total), dim3(kTilePix), 0, s, W, H, (uint32_t)tiles_x,
+                       (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D, g.conic_opacity, g.rgbd, bg,
+                       out_color, out_depth, out_alpha, n_contrib);
+}
+
+void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
+                            const uint32_t* point_list, const GeomState& g, const float* bg, const float* alphas,
+                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
+                            const float* dL_dalphas, float* acc)
+{
+    const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
+    hipLaunchKernelGGL(render_backward_kernel, dim3(tiles_total), dim3(kTilePix), 0, s, W, H, (uint32_t)tiles_x,
+                       (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D, g.conic_opacity, g.rgbd, bg,
+                       alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc);
+}
+
+}  // namespace gd

@@ -1,0 +1,241 @@
+"""GPU parity: HIP rasterizer (through the C-ABI, via the _C-shaped shim) vs the CPU oracle.
+
+Bar: integers bit-exact (radii, tiles_touched, point_offsets, sorted keys,
+point_list, ranges, num_rendered, n_contrib); pixels abs <= 1e-5 + 1e-4*|x|; gradients
+rtol 1e-3 with an absolute floor scaled to the tensor (atomic-order / fp32-accumulation noise;
+the oracle sums per-pair terms in fp64).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as h
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _run_gpu_forward(inp):
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    args = h.to_torch(inp, DEV)
+    out = _C.rasterize_gaussians(*args)
+    torch.cuda.synchronize()
+    return args, out
+
+
+def _check_forward(inp, st, out, exact_ncontrib=True):
+    R, color, depth, alpha, radii, geom, binning, img = out
+    P, H, W = inp["means3D"].shape[0], inp["image_height"], inp["image_width"]
+    assert R == st.num_rendered
+    np.testing.assert_array_equal(radii.cpu().numpy(), st.radii)
+    sc = h.read_scratch(geom, binning, img, P, 1, W, H, R)
+    np.testing.assert_array_equal(sc["tiles_touched"], st.tiles_touched)
+    np.testing.assert_array_equal(sc["point_offsets"], st.point_offsets)
+    vis = st.radii > 0
+    # per-Gaussian floats of visible Gaussians: bit-exact (same expression order, no contraction)
+    for name in ("means2D", "conic_opacity", "depths", "rgb"):
+        a, b = sc[name][vis], getattr(st, name)[vis]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+    np.testing.assert_array_equal(sc["cov3D"][vis], st.cov3D[vis])
+    np.testing.assert_array_equal(sc["keys"], st.keys)
+    np.testing.assert_array_equal(sc["point_list"], st.point_list)
+    np.testing.assert_array_equal(sc["ranges"], st.ranges)
+    nc = sc["n_contrib"][0]
+    mism = int((nc != st.n_contrib).sum())
+    if exact_ncontrib:
+        assert mism <= max(1, int(1e-4 * nc.size)), f"n_contrib mismatches: {mism}"
+    ok = nc == st.n_contrib
+    for name, g, o in (("color", color, st.color), ("depth", depth, st.depth), ("alpha", alpha, st.alpha)):
+        g = g.cpu().numpy()
+        err = np.abs(g - o)
+        tol = 1e-5 + 1e-4 * np.abs(o)
+        bad = (err > tol) & ok[None]
+        assert not bad.any(), f"{name}: {bad.sum()} pixels beyond tolerance, max err {err.max()}"
+    return sc
+
+
+def _check_grads(name, g, o, rtol=1e-3):
+    g = g.detach().cpu().numpy().reshape(o.shape)
+    scale = np.abs(o).max() + 1e-20
+    err = np.abs(g - o)
+    tol = rtol * np.abs(o) + 2e-5 * scale
+    assert (err <= tol).all(), f"{name}: max err {err.max():.3e} at scale {scale:.3e}, {(err > tol).sum()} bad"
+
+
+@pytest.mark.parametrize("P,HW,deg", [(500, 64, 0), (2000, 96, 3), (10000, 256, 0)])
+def test_forward_parity(P, HW, deg):
+    inp = h.raster_inputs(P=P, H=HW, W=HW, sh_degree=deg, seed=P)
+    st = h.oracle_forward(inp)
+    _, out = _run_gpu_forward(inp)
+    _check_forward(inp, st, out)
+
+
+def test_forward_parity_ragged_image():
+    """W, H not multiples of 16 -> partial tiles on both edges."""
+    inp = h.raster_inputs(P=3000, H=75, W=117, seed=3)
+    st = h.oracle_forward(inp)
+    _, out = _run_gpu_forward(inp)
+    _check_forward(inp, st, out)
+
+
+def test_forward_big_splats_many_tiles():
+    """Large scales: every Gaussian overlaps many tiles, long per-tile lists, saturation."""
+    inp = h.raster_inputs(P=4000, H=128, W=128, seed=5, scale_mul=8.0)
+    st = h.oracle_forward(inp)
+    assert st.num_rendered > 20 * 4000 / 4
+    _, out = _run_gpu_forward(inp)
+    _check_forward(inp, st, out)
+
+
+@pytest.mark.parametrize("P,HW,deg", [(500, 64, 0), (2000, 96, 2), (10000, 256, 0)])
+def test_backward_parity(P, HW, deg):
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    from oracle import gd_oracle
+    inp = h.raster_inputs(P=P, H=HW, W=HW, sh_degree=deg, seed=100 + P)
+    st = h.oracle_forward(inp)
+    gc, gd, ga = h.random_image_grads(HW, HW)
+    ref = gd_oracle.backward(st, gc, gd, ga)
+    args, out = _run_gpu_forward(inp)
+    R, color, depth, alpha, radii, geom, binning, img = out
+    t = lambda a: torch.as_tensor(a, device=DEV)
+    (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, _, _) = args
+    grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
+                                            t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha,
+                                            False)
+    torch.cuda.synchronize()
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations")
+    for n, g in zip(names, grads):
+        _check_grads(n, g, ref[n])
+
+
+def test_colors_precomp_and_cov3d_precomp_paths():
+    """Absent-optional paths: colours instead of SHs, 3D covariance instead of scale/rotation."""
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    from oracle import gd_oracle
+    inp = h.raster_inputs(P=1500, H=64, W=80, seed=11)
+    st0 = h.oracle_forward(inp)
+    rng = np.random.default_rng(0)
+    inp2 = dict(inp)
+    inp2["colors_precomp"] = rng.uniform(size=(1500, 3)).astype(np.float32)
+    inp2["sh"] = None
+    inp2["cov3D_precomp"] = st0.cov3D.copy()
+    inp2["scales"] = None
+    inp2["rotations"] = None
+    st = h.oracle_forward(inp2)
+    args, out = _run_gpu_forward(inp2)
+    _check_forward(inp2, st, out)
+    gc, gd, ga = h.random_image_grads(64, 80)
+    ref = gd_oracle.backward(st, gc, gd, ga)
+    R, color, depth, alpha, radii, geom, binning, img = out
+    t = lambda a: torch.as_tensor(a, device=DEV)
+    (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, _, _) = args
+    grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
+                                            t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha,
+                                            False)
+    for n, g in zip(("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D"), grads[:5]):
+        _check_grads(n, g, ref[n])
+    assert float(grads[6].abs().sum()) == 0.0 and float(grads[7].abs().sum()) == 0.0
+
+
+def test_empty_and_culled_inputs():
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    inp = h.raster_inputs(P=64, H=32, W=32, seed=2)
+    # all Gaussians behind the camera -> nothing rendered, background only
+    inp["means3D"] = (inp["campos"][None] * 3.0 + 0.1 * inp["means3D"]).astype(np.float32)
+    st = h.oracle_forward(inp)
+    _, out = _run_gpu_forward(inp)
+    assert out[0] == st.num_rendered
+    np.testing.assert_array_equal(out[4].cpu().numpy(), st.radii)
+    np.testing.assert_allclose(out[1].cpu().numpy(), st.color, atol=1e-6)
+    # P == 0
+    inp0 = h.raster_inputs(P=1, H=32, W=32)
+    a = list(h.to_torch(inp0, DEV))
+    a[1] = torch.zeros((0, 3), device=DEV)
+    a[3] = torch.zeros((0, 1), device=DEV)
+    a[4] = torch.zeros((0, 3), device=DEV)
+    a[5] = torch.zeros((0, 4), device=DEV)
+    a[14] = torch.zeros((0, 1, 3), device=DEV)
+    R, color, depth, alpha, radii, *_ = _C.rasterize_gaussians(*a)
+    assert R == 0 and float(color.abs().sum()) == 0.0 and radii.numel() == 0
+
+
+def test_mark_visible():
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    from oracle import gd_oracle
+    inp = h.raster_inputs(P=5000, H=64, W=64, seed=4, distance=0.6)
+    ref = gd_oracle.mark_visible(inp["means3D"], inp["viewmatrix"], inp["projmatrix"])
+    t = lambda a: torch.as_tensor(a, device=DEV)
+    got = _C.mark_visible(t(inp["means3D"]), t(inp["viewmatrix"]), t(inp["projmatrix"]))
+    assert 0 < ref.sum() < ref.size
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_autograd_function_matches_oracle_and_reference_surface():
+    """Through GaussianRasterizer / autograd, as gaussian_renderer calls it."""
+    from garmentdreamer_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import gd_oracle
+    HW = 64
+    inp = h.raster_inputs(P=800, H=HW, W=HW, seed=21)
+    st = h.oracle_forward(inp)
+    t = lambda a: torch.as_tensor(a, device=DEV)
+    rs = GaussianRasterizationSettings(HW, HW, inp["tanfovx"], inp["tanfovy"], t(inp["bg"]), 1.0,
+                                       t(inp["viewmatrix"]), t(inp["projmatrix"]), 0, t(inp["campos"]), False, False)
+    leaves = {k: t(inp[k]).requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations", "sh")}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    color, radii, depth, alpha = GaussianRasterizer(rs)(
+        means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=leaves["sh"],
+        scales=leaves["scales"], rotations=leaves["rotations"])
+    assert color.shape == (3, HW, HW) and radii.dtype == torch.int32 and depth.shape == (1, HW, HW)
+    gc, gd, ga = h.random_image_grads(HW, HW)
+    (color * t(gc)).sum().add((depth * t(gd)).sum()).add((alpha * t(ga)).sum()).backward()
+    ref = gd_oracle.backward(st, gc, gd, ga)
+    _check_grads("means3D", leaves["means3D"].grad, ref["dL_dmeans3D"])
+    _check_grads("means2D", means2D.grad, ref["dL_dmeans2D"])
+    _check_grads("opacities", leaves["opacities"].grad, ref["dL_dopacity"])
+    _check_grads("sh", leaves["sh"].grad, ref["dL_dsh"])
+    _check_grads("scales", leaves["scales"].grad, ref["dL_dscales"])
+    _check_grads("rotations", leaves["rotations"].grad, ref["dL_drotations"])
+    with pytest.raises(Exception, match="excatly one of either SHs"):
+        GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                               scales=leaves["scales"], rotations=leaves["rotations"])
+
+
+def test_batched_matches_per_view():
+    """V views through one launch set == V single-view calls (bit-exact images; summed grads)."""
+    from garmentdreamer_amd import cameras as gcam
+    from garmentdreamer_amd.gaussian_renderer import render, render_batch
+    from garmentdreamer_amd.scene import GaussianParams, synthetic_gaussians
+    import math
+    HW, V = 96, 3
+    sc = synthetic_gaussians(3000, seed=9)
+    batch = gcam.orbit_batch(V, height=HW, width=HW)
+    batch["fovy"] = torch.tensor([math.radians(a) for a in (45.0, 55.0, 65.0)])
+    cams = [gcam.Camera(batch["c2w_3dgs"][i], batch["fovy"][i], HW, HW, data_device=DEV) for i in range(V)]
+    bg = torch.ones(3, device=DEV)
+    gi = [torch.randn(3, HW, HW, device=DEV, generator=torch.Generator(DEV).manual_seed(i)) for i in range(V)]
+
+    pc1 = GaussianParams(sc, device=DEV)
+    imgs, vps = [], []
+    for i in range(V):
+        pkg = render(cams[i], pc1, None, bg)
+        imgs.append(pkg["render"])
+        vps.append(pkg["viewspace_points"])
+    loss = sum((im * g).sum() + 0.1 * pk.sum() for im, g, pk in zip(imgs, gi, [x * 0 for x in imgs]))
+    loss.backward()
+
+    pc2 = GaussianParams(sc, device=DEV)
+    pkg = render_batch(cams, pc2, bg)
+    assert pkg["render"].shape == (V, 3, HW, HW)
+    for i in range(V):
+        assert torch.equal(pkg["render"][i], imgs[i])
+    (pkg["render"] * torch.stack(gi)).sum().backward()
+    for (n1, p1), (n2, p2) in zip(pc1.named_parameters(), pc2.named_parameters()):
+        if p1.grad is None:
+            continue
+        scale = float(p1.grad.abs().max()) + 1e-20
+        assert float((p1.grad - p2.grad).abs().max()) <= 2e-4 * scale, n1
+    for i in range(V):
+        s = float(vps[i].grad.abs().max()) + 1e-20
+        assert float((vps[i].grad - pkg["viewspace_points"].grad[i]).abs().max()) <= 2e-4 * s
