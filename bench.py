@@ -1,0 +1,279 @@
+#!/usr/bin/env python
+"""bench.py -- SDS iterations/sec of the GarmentDreamer inner loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full SDS iteration on synthetic data (BASELINE.json metric): rasterize V views
+(fwd) -> bilinear 512^2 -> VAE encode (fwd, with grad) -> UNet on 2V samples (no grad) -> SDS loss
+-> VAE dgrad -> rasterize bwd -> gradient all-reduce (N > 1) -> Adam.  Workload = BASELINE.json
+configs[3]: 100k Gaussians x 8 views @ 512^2, the 8 views sharded V/N per GPU ("strong" scaling:
+total work is fixed).  Random-init SD-2.1 weights (no network for checkpoints), bf16.
+
+Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline      the rasterizer backward render kernel (the kernel north_star names): algorithmic
+                FLOPs per launch (14 per visited pair + 87 per contributing pair, counted on the
+                GPU from n_contrib / pair_counts; derivation in DESIGN.md) / its average launch
+                duration from HIP events recorded around that kernel inside the timed region.
+  roofline_dense  UNet + VAE part: analytic FLOPs (0.804 TF/UNet sample, 1.117 TF/VAE image, dgrad
+                = 1x fwd) / event time of guidance fwd + its backward, vs the 2.5 PF bf16 MFMA roof.
+  cpu_baseline  the CPU oracle (rasterizer fwd+bwd, 1 thread) + fp32 PyTorch-CPU UNet/VAE for ONE of
+                the 8 views, scaled to iterations/s (rank 0, N=1 only; skip with --no-cpu-baseline).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+UNET_TFLOP_PER_SAMPLE = 0.80425746432     # FlopCounterMode on sd21.UNet2DConditionModel @64x64 latents
+VAE_TFLOP_PER_IMAGE = 1.116658466816      # FlopCounterMode on sd21.AutoencoderKLEncoder @512x512
+FLOPS_VISITED_PAIR = 14                   # backward.cu:522-532 per visited (pixel, Gaussian) pair
+FLOPS_CONTRIB_PAIR = 87                   # backward.cu:534-598 per contributing pair (incl. 10 adds)
+PEAK_FP32_TFLOPS = 157.3                  # MI355X fp32 vector = f32-input MFMA rate (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0                 # dense bf16 MFMA
+METRIC = "SDS iters/sec (rasterize+UNet+bwd), 100k Gaussians ×8 views @512², 1/2/4/8 GPU"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--gaussians", type=int, default=100000)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--per-view-raster", action="store_true", help="reference-style Python loop over views")
+    ap.add_argument("--raster-only", action="store_true", help="time only rasterizer fwd+bwd (diagnostic)")
+    return ap.parse_args()
+
+
+def camera_batch(args, step, view_ids):
+    from garmentdreamer_amd import cameras as gcam
+    # SURVEY 8d benchmark default orbit; the ring of azimuths rotates a little every step
+    return gcam.orbit_batch(args.views, elevation_deg=15.0, camera_distance=2.75, fovy_deg=55.0, height=args.res,
+                            width=args.res, azimuth_offset_deg=7.0 * step, view_ids=view_ids)
+
+
+def count_pairs(loop, batch, device):
+    """Visited / contributing pair counts of this rank's views (one extra untimed forward)."""
+    import ctypes as C
+    from garmentdreamer_amd import _native
+    from garmentdreamer_amd.cameras import Camera, CameraBatch
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    g = loop.gaussians
+    cams = [Camera(batch["c2w_3dgs"][i], batch["fovy"][i], batch["height"], batch["width"], data_device="cpu")
+            for i in range(batch["c2w_3dgs"].shape[0])]
+    cb = CameraBatch(cams, device)
+    with torch.no_grad():
+        out = _C.rasterize_gaussians_batched(
+            loop.bg, g.get_xyz, torch.Tensor([]), g.get_opacity, g.get_scaling, g.get_rotation, 1.0,
+            torch.Tensor([]), cb.viewmatrix, cb.projmatrix, cb.tanfovx, cb.tanfovy, cb.image_height, cb.image_width,
+            g.get_features, g.active_sh_degree, cb.campos, False, False)
+    R, _c, _d, _a, radii, geom, binning, img = out
+    V, P = radii.shape
+    lay = _native.Layout()
+    _native.lib().gd_raster_get_layout(geom.data_ptr(), img.data_ptr(), binning.data_ptr(), P, V, cb.image_width,
+                                       cb.image_height, R, C.byref(lay))
+    npix = V * cb.image_height * cb.image_width
+    n_contrib = img[lay.n_contrib:lay.n_contrib + 4 * npix].view(torch.int32)
+    pc = img[lay.pair_counts:lay.pair_counts + 8 * npix].view(torch.int32).view(npix, 2)
+    return dict(num_rendered=int(R), visible=int((radii > 0).sum()), pairs_visited_bwd=int(n_contrib.sum(dtype=torch.int64)),
+                pairs_visited_fwd=int(pc[:, 0].sum(dtype=torch.int64)), pairs_contrib=int(pc[:, 1].sum(dtype=torch.int64)),
+                views=V)
+
+
+def cpu_baseline(args):
+    """CPU oracle rasterizer (1 thread) + fp32 PyTorch-CPU VAE/UNet for ONE view, scaled to the 8-view
+    iteration.  Test infrastructure used as the reported baseline only (never as the product path)."""
+    import numpy as np
+    from garmentdreamer_amd.guidance import sd21
+    from oracle import gd_oracle
+    from tests import helpers as h
+    nthreads = torch.get_num_threads()
+    inp = h.raster_inputs(P=args.gaussians, H=args.res, W=args.res, seed=0, azimuth=-157.5, elevation=15.0,
+                          distance=2.75, fovy_deg=55.0)
+    t0 = time.perf_counter()
+    st = h.oracle_forward(inp)
+    gc, gd, ga = h.random_image_grads(args.res, args.res)
+    gd_oracle.backward(st, gc, gd, ga)
+    t_raster = time.perf_counter() - t0
+    torch.manual_seed(0)
+    vae = sd21.init_random_(sd21.AutoencoderKLEncoder()).float().eval()
+    unet = sd21.init_random_(sd21.UNet2DConditionModel()).float().eval()
+    for p in list(vae.parameters()) + list(unet.parameters()):
+        p.requires_grad_(False)
+    img = torch.rand(1, 3, 512, 512, requires_grad=True)
+    t0 = time.perf_counter()
+    lat = vae.encode(img * 2 - 1).latent_dist.sample() * 0.18215
+    with torch.no_grad():
+        eps = unet(torch.cat([lat.detach()] * 2), torch.tensor([500, 500]), torch.randn(2, 77, 1024))
+    (lat * eps[:1].detach()).sum().backward()
+    t_dense = time.perf_counter() - t0
+    t_view = t_raster + t_dense
+    return {"value": 1.0 / (args.views * t_view), "unit": "iters/s", "cores": nthreads, "kind": "port",
+            "sample": (f"1 of {args.views} views: oracle rasterizer fwd+bwd {args.gaussians} Gaussians @{args.res}^2 "
+                       f"(1 thread, {t_raster:.2f} s) + fp32 torch-CPU VAE fwd/dgrad + UNet x2 fwd ({nthreads} threads, "
+                       f"{t_dense:.2f} s); scaled x{args.views}")}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)))
+        return
+    from garmentdreamer_amd import _native, dist as gdist
+    from garmentdreamer_amd.guidance.stable_diffusion_guidance import PromptEmbeddings, StableDiffusionGuidance
+    from garmentdreamer_amd.scene import GaussianParams, synthetic_gaussians
+    from garmentdreamer_amd.sds_loop import SDSLoop
+
+    rk, lr, ws = gdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP rasterizer has no CPU path")
+    device = torch.device("cuda", lr)
+    torch.cuda.set_device(device)
+    _native.lib()  # fail loudly right here if the HIP library is missing
+    torch.backends.cuda.matmul.allow_tf32 = False
+
+    view_ids = gdist.shard_views(args.views, rk, ws)
+    scene = synthetic_gaussians(args.gaussians, seed=0, sh_degree=0)
+    gaussians = GaussianParams(scene, sh_degree=0, device=device)
+    bg = torch.ones(3, device=device)
+    if args.raster_only:
+        guidance, prompt = None, None
+    else:
+        guidance = StableDiffusionGuidance({"guidance_scale": 100.0, "grad_clip": [0, 1.5, 2.0, 1000]}, device=device)
+        prompt = PromptEmbeddings.random(device)
+    loop = SDSLoop(gaussians, guidance, prompt, bg)
+    if args.per_view_raster:
+        from garmentdreamer_amd.gaussian_renderer import render
+
+        def per_view(cb, pc, bgc):
+            pk = [render(c, pc, None, bgc) for c in _cams_on(cb, device)]
+            return {"render": torch.stack([p["render"] for p in pk]), "viewspace_points": _VS(pk),
+                    "radii": torch.stack([p["radii"] for p in pk]),
+                    "depth_3dgs": torch.stack([p["depth_3dgs"] for p in pk]),
+                    "alpha": torch.stack([p["alpha"] for p in pk]), "visibility_filter": None}
+        loop.render_batch_fn = per_view
+
+    gen = torch.Generator(device=device)
+
+    def one_step(step):
+        batch = camera_batch(args, step, view_ids)
+        V = len(view_ids)
+        gen.manual_seed(1234 + 1000 * step + rk)
+        if args.raster_only:
+            out = loop.render_views(batch)
+            w = torch.randn(out["comp_rgb"].shape, device=device, generator=gen)
+            loss = (out["comp_rgb"] * w).sum() + (out["opacity"] ** 2 + 0.01).sqrt().mean()
+            loop.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            return
+        noise = torch.randn(V, 4, 64, 64, device=device, generator=gen)
+        vae_noise = torch.randn(V, 4, 64, 64, device=device, generator=gen)
+        t = torch.randint(20, 981, (V,), device=device, generator=gen)
+        loop.step(batch, noise=noise, timesteps=t, vae_noise=vae_noise)
+
+    for s in range(args.warmup):
+        one_step(s)
+    torch.cuda.synchronize()
+    _native.profile_reset()
+    _native.profile_enable(True)
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(args.warmup + s)
+    torch.cuda.synchronize()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _native.profile_enable(False)
+    prof = _native.profile_read()
+    if ws > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- work accounting (untimed) ----
+    counts = count_pairs(loop, camera_batch(args, args.warmup, view_ids), device)
+    bwd_ms, bwd_n = prof["render_bwd"]
+    flops_launch = FLOPS_VISITED_PAIR * counts["pairs_visited_bwd"] + FLOPS_CONTRIB_PAIR * counts["pairs_contrib"]
+    roofline = None
+    if bwd_n > 0:
+        avg_s = bwd_ms / bwd_n * 1e-3
+        ach = flops_launch / avg_s / 1e12
+        roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                    "kernel": "render_backward_kernel", "avg_launch_us": avg_s * 1e6, "launches": bwd_n,
+                    "flops_per_launch": flops_launch,
+                    "note": ("fp32 compute roof: 157.3 TF/s vector rate == f32-input MFMA rate on gfx950; the kernel "
+                             "is VALU-bound (no MFMA issued), HBM traffic is ~25 MB/launch")}
+
+    if rk == 0:
+        V = len(view_ids)
+        line = {
+            "metric": METRIC, "value": args.steps / elapsed, "unit": "iters/s", "n_gpus": ws, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": (f"SDS loop: {args.gaussians} Gaussians x {args.views} views @{args.res}^2, "
+                                    f"SD-2.1 UNet+VAE random-init, {V} view(s)/GPU"),
+                       "gaussians": args.gaussians, "views": args.views, "resolution": args.res,
+                       "views_per_gpu": V, "parallelism": f"view-sharded dp{ws}",
+                       "raster": "per-view loop" if args.per_view_raster else "batched",
+                       "raster_only": bool(args.raster_only)},
+            "roofline": roofline,
+            "raster_kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
+            "pair_counts_rank0": counts,
+        }
+        if not args.raster_only:
+            dense_tflop = V * (2 * UNET_TFLOP_PER_SAMPLE + 2 * VAE_TFLOP_PER_IMAGE)
+            raster_ms = sum(v[0] for v in prof.values()) / max(args.steps, 1)
+            dense_s = max(elapsed / args.steps - raster_ms * 1e-3, 1e-9)
+            line["roofline_dense"] = {"bound": "mfma", "achieved": dense_tflop / dense_s, "peak": PEAK_BF16_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": dense_tflop / dense_s / PEAK_BF16_TFLOPS,
+                                      "tflop_per_step_per_gpu": dense_tflop,
+                                      "note": "step time minus rasterizer kernel time; includes Adam, losses, host gaps"}
+        if ws == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:  # the baseline is reporting only; never fail the bench line on it
+                line["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(line), flush=True)
+    if gdist.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+def _cams_on(cb, device):
+    from garmentdreamer_amd.cameras import Camera
+    return [Camera(torch.cat([c.R, c.T[:, None]], 1).new_zeros(4, 4).copy_(
+        torch.cat([torch.cat([c.R, c.T[:, None]], 1), torch.tensor([[0., 0., 0., 1.]])], 0)), c.FoVy, c.image_height,
+        c.image_width, data_device=device) for c in cb.cameras]
+
+
+class _VS:
+    """Adapter: per-view viewspace gradient holders exposed as one object with a stacked ``.grad``."""
+
+    def __init__(self, pk):
+        self.pk = pk
+
+    @property
+    def grad(self):
+        return torch.stack([p["viewspace_points"].grad for p in self.pk])
+
+
+if __name__ == "__main__":
+    main()

@@ -24,7 +24,7 @@ _f = C.c_float
 class Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "depths", "clamped", "radii", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "point_offsets",
-        "block_sums", "ranges", "n_contrib", "point_list", "point_list_alt", "keys", "keys_alt", "sort_hist")]
+        "block_sums", "ranges", "n_contrib", "pair_counts", "point_list", "point_list_alt", "keys", "keys_alt", "sort_hist")]
 
 
 # symbol -> (restype, argtypes); mirrors include/gd_raster.h one to one
@@ -53,6 +53,11 @@ SIGNATURES = {
                                    + [_vp] * 3 + [_vp] * 8 + [_i]),   # 8 outputs (no dL_dconic / dL_ddepth)
     "gd_raster_get_layout": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, C.POINTER(Layout)]),
     "gd_raster_sort_bits": (_i, [_i, _i, _i]),
+    "gd_raster_profile_enable": (_i, [_i]),
+    "gd_raster_profile_collect": (_i, []),
+    "gd_raster_profile_get": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "gd_raster_profile_reset": (_i, []),
+    "gd_raster_profile_kernel_name": (C.c_char_p, [_i]),
     "gd_raster_last_error": (C.c_char_p, []),
     "gd_raster_build_info": (C.c_char_p, []),
 }
@@ -91,3 +96,27 @@ def check(ret: int, what: str) -> int:
         msg = lib().gd_raster_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed ({ret}): {msg}")
     return ret
+
+
+KERNEL_IDS = {"preprocess": 0, "scan": 1, "duplicate": 2, "sort": 3, "ranges": 4, "render_fwd": 5, "render_bwd": 6,
+              "preprocess_bwd": 7}
+
+
+def profile_enable(on: bool) -> None:
+    lib().gd_raster_profile_enable(int(on))
+
+
+def profile_reset() -> None:
+    lib().gd_raster_profile_reset()
+
+
+def profile_read() -> dict:
+    """{kernel: (total_ms, launches)} after waiting for all recorded events."""
+    L = lib()
+    L.gd_raster_profile_collect()
+    out = {}
+    for name, kid in KERNEL_IDS.items():
+        ms, n = C.c_double(0), C.c_int64(0)
+        L.gd_raster_profile_get(kid, C.byref(ms), C.byref(n))
+        out[name] = (ms.value, n.value)
+    return out

@@ -12,6 +12,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "raster_common.h"
 
 namespace gd {
@@ -39,6 +42,43 @@ void obtain(char*& chunk, T*& ptr, size_t count, size_t alignment = 128)
     ptr = reinterpret_cast<T*>(off);
     chunk = reinterpret_cast<char*>(ptr + count);
 }
+
+// ---- optional per-kernel event timing (gd_raster_profile_*) ----
+struct Profiler {
+    std::mutex mu;
+    bool on = false;
+    struct Rec { int kid; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[GD_K_COUNT] = {0};
+    int64_t count[GD_K_COUNT] = {0};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+Profiler g_prof;
+
+struct ProfScope {
+    hipStream_t s; int kid; hipEvent_t a = nullptr, b = nullptr; bool active = false;
+    ProfScope(hipStream_t s_, int kid_) : s(s_), kid(kid_)
+    {
+        if (!g_prof.on) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        a = g_prof.get(); b = g_prof.get();
+        if (a && b) { active = true; (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope()
+    {
+        if (!active) return;
+        (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        g_prof.pending.push_back({kid, a, b});
+    }
+};
 
 int check_debug(hipStream_t s, int debug, const char* where)
 {
@@ -77,6 +117,7 @@ ImageState carve_image(char* chunk, size_t tiles_total, size_t pixels_total, siz
     ImageState im;
     obtain(p, im.ranges, tiles_total);
     obtain(p, im.n_contrib, pixels_total);
+    obtain(p, im.pair_counts, pixels_total);
     if (used) *used = (size_t)(p - chunk);
     return im;
 }
@@ -165,12 +206,13 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     ImageState img = carve_image(img_chunk, dm.tiles_total, dm.pixels_total, nullptr);
     if (radii == nullptr) radii = geom.radii;
 
+    { ProfScope ps(stream, GD_K_PREPROCESS);
     launch_preprocess(stream, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
                       colors_precomp, viewmatrix, projmatrix, cam_pos, W, H, vs, radii, geom, dm.tiles_x, dm.tiles_y,
-                      prefiltered != 0);
+                      prefiltered != 0); }
     if (int e = check_debug(stream, debug, "preprocess")) return e;
     const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
-    launch_scan_block_sums(stream, geom.block_sums, nblk);
+    { ProfScope ps(stream, GD_K_SCAN); launch_scan_block_sums(stream, geom.block_sums, nblk); }
     if (int e = check_debug(stream, debug, "scan")) return e;
 
     // the one host sync of the forward pass (rasterizer_impl.cu:282)
@@ -185,15 +227,17 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
 
     const SortPlan plan = plan_sort(dm.tiles_total);
     const bool start_in_alt = (plan.passes & 1) != 0;
+    { ProfScope ps(stream, GD_K_DUPLICATE);
     launch_duplicate(stream, (int)VP, P, radii, geom, start_in_alt ? bin.keys_alt : bin.keys,
-                     start_in_alt ? bin.point_list_alt : bin.point_list, dm.tiles_x, dm.tiles_y);
+                     start_in_alt ? bin.point_list_alt : bin.point_list, dm.tiles_x, dm.tiles_y); }
     if (int e = check_debug(stream, debug, "duplicate")) return e;
-    launch_radix_sort(stream, bin, num_rendered, plan, start_in_alt);
+    { ProfScope ps(stream, GD_K_SORT); launch_radix_sort(stream, bin, num_rendered, plan, start_in_alt); }
     if (int e = check_debug(stream, debug, "sort")) return e;
-    launch_tile_ranges(stream, bin.keys, num_rendered, img.ranges, dm.tiles_total);
+    { ProfScope ps(stream, GD_K_RANGES); launch_tile_ranges(stream, bin.keys, num_rendered, img.ranges, dm.tiles_total); }
     if (int e = check_debug(stream, debug, "ranges")) return e;
+    { ProfScope ps(stream, GD_K_RENDER_FWD);
     launch_render_forward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
-                          out_color, out_depth, out_alpha, img.n_contrib);
+                          out_color, out_depth, out_alpha, img.n_contrib, img.pair_counts); }
     if (int e = check_debug(stream, debug, "render")) return e;
     GD_HIP(hipGetLastError());
     return (int)num_rendered;
@@ -230,18 +274,21 @@ int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const f
         obtain(p, acc, VP * 10);
     }
     GD_HIP(hipMemsetAsync(acc, 0, sizeof(float) * VP * 10, stream));
-    if (R > 0)
+    if (R > 0) {
+        ProfScope ps(stream, GD_K_RENDER_BWD);
         launch_render_backward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
                                alphas, img.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc);
+    }
     if (int e = check_debug(stream, debug, "render backward")) return e;
 
     const float* cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
     const size_t cov_stride = cov3D_precomp ? 0 : (size_t)P * 6;
+    { ProfScope ps(stream, GD_K_PREPROCESS_BWD);
     launch_preprocess_backward(stream, P, D, M, V, means3D, radii, shs, geom.clamped, scales, rotations,
                                scale_modifier, cov3D, cov_stride, viewmatrix, projmatrix, campos, vs, acc,
                                colors_precomp != nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth,
                                dL_dmean3D, dL_dcov3D, shs ? dL_dsh : nullptr, scales ? dL_dscale : nullptr,
-                               scales ? dL_drot : nullptr, nullptr);
+                               scales ? dL_drot : nullptr, nullptr); }
     if (int e = check_debug(stream, debug, "preprocess backward")) return e;
     GD_HIP(hipGetLastError());
     return GD_OK;
@@ -378,6 +425,7 @@ int gd_raster_get_layout(const char* geom_base, const char* image_base, const ch
     out->block_sums = OFF(geom_base, g.block_sums);
     out->ranges = OFF(image_base, im.ranges);
     out->n_contrib = OFF(image_base, im.n_contrib);
+    out->pair_counts = OFF(image_base, im.pair_counts);
     out->point_list = OFF(binning_base, b.point_list);
     out->point_list_alt = OFF(binning_base, b.point_list_alt);
     out->keys = OFF(binning_base, b.keys);
@@ -391,6 +439,55 @@ int gd_raster_sort_bits(int width, int height, int V)
 {
     const Dims d = make_dims(width, height, V < 1 ? 1 : V);
     return plan_sort(d.tiles_total).total_bits;
+}
+
+int gd_raster_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = on != 0;
+    return GD_OK;
+}
+
+int gd_raster_profile_collect(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (auto& r : g_prof.pending) {
+        if (hipEventSynchronize(r.b) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                g_prof.total_ms[r.kid] += ms;
+                g_prof.count[r.kid] += 1;
+            }
+        }
+        g_prof.pool.push_back(r.a);
+        g_prof.pool.push_back(r.b);
+    }
+    g_prof.pending.clear();
+    return GD_OK;
+}
+
+int gd_raster_profile_get(int kernel_id, double* total_ms, int64_t* launches)
+{
+    if (kernel_id < 0 || kernel_id >= GD_K_COUNT) return GD_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (total_ms) *total_ms = g_prof.total_ms[kernel_id];
+    if (launches) *launches = g_prof.count[kernel_id];
+    return GD_OK;
+}
+
+int gd_raster_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (int i = 0; i < GD_K_COUNT; i++) { g_prof.total_ms[i] = 0; g_prof.count[i] = 0; }
+    return GD_OK;
+}
+
+const char* gd_raster_profile_kernel_name(int kernel_id)
+{
+    static const char* names[GD_K_COUNT] = {"preprocess_kernel", "scan_block_sums_kernel", "duplicate_kernel",
+                                            "radix_sort(all passes)", "tile_ranges_kernel", "render_forward_kernel",
+                                            "render_backward_kernel", "preprocess_backward_kernel"};
+    return (kernel_id >= 0 && kernel_id < GD_K_COUNT) ? names[kernel_id] : "";
 }
 
 const char* gd_raster_last_error(void) { return g_err; }

@@ -37,6 +37,7 @@ struct GeomState {
 struct ImageState {
     uint2* ranges;        // [V*tiles]
     uint32_t* n_contrib;  // [V*H*W]
+    uint2* pair_counts;   // [V*H*W] {visited, blended} per pixel (work accounting for the roofline)
 };
 struct BinningState {
     uint32_t* point_list;      // [R] sorted values (vp indices)
@@ -91,7 +92,7 @@ void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* 
 
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
-                           float* out_depth, float* out_alpha, uint32_t* n_contrib);
+                           float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts);
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const uint32_t* point_list, const GeomState& g, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
     const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-    uint32_t* __restrict__ n_contrib)
+    uint32_t* __restrict__ n_contrib, uint2* __restrict__ pair_counts)
 {
     __shared__ float2 s_xy[kTilePix];
     __shared__ float4 s_co[kTilePix];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     int toDo = (int)(range.y - range.x);
 
     float T = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t contributor = 0, last_contributor = 0, blended = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f;
 
     for (int i = 0; i < rounds; i++, toDo -= kTilePix) {
@@ -133,10 +133,12 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
             Dd += fd.w * alpha * T;
             T = test_T;
             last_contributor = contributor;
+            blended++;
         }
     }
     if (inside) {
         n_contrib[(size_t)view * HW + pix_id] = last_contributor;
+        pair_counts[(size_t)view * HW + pix_id] = make_uint2(contributor, blended);
         float* oc = out_color + (size_t)view * 3 * HW;
         oc[0 * HW + pix_id] = C0 + T * bg_color[0];
         oc[1 * HW + pix_id] = C1 + T * bg_color[1];
@@ -295,12 +297,12 @@ __global__ __launch_bounds__(kTilePix) void render_backward_kernel(
 
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
-                           float* out_depth, float* out_alpha, uint32_t* n_contrib)
+                           float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
     hipLaunchKernelGGL(render_forward_kernel, dim3(tiles_total), dim3(kTilePix), 0, s, W, H, (uint32_t)tiles_x,
                        (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D, g.conic_opacity, g.rgbd, bg,
-                       out_color, out_depth, out_alpha, n_contrib);
+                       out_color, out_depth, out_alpha, n_contrib, pair_counts);
 }
 
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,

@@ -1,0 +1,467 @@
+"""Stable-Diffusion-2.1 UNet, VAE encoder and DDIM noise schedule, restated for PyTorch-ROCm.
+
+The reference obtains these from the un-vendored dependency ``diffusers==0.19.0``
+(Garment_3DGS/requirements.txt:12; call sites Garment_3DGS/threestudio/models/guidance/
+stable_diffusion_guidance.py:66-69,120-131,153-157,165-166) with weights fetched from the HF hub at
+run time.  Neither the package nor the weights exist in this environment, so the public SD-2.1
+architecture is restated here and run with random-init weights; PARITY IS UNPINNED for this part
+(SURVEY 8a row a21, 8c): tests check self-consistency (bf16 path vs fp32 path, analytic scheduler
+constants, shape/param-count facts of the published config) and nothing else can be checked.
+
+Architecture facts (public ``stabilityai/stable-diffusion-2-1-base`` config.json; skeleton visible
+in-tree at Garment_Deformer_NeTF/netf/vsd/lora_unet.py:119-160):
+  UNet: in/out 4, block_out_channels (320,640,1280,1280), layers_per_block 2, down = 3x
+        CrossAttnDownBlock2D + DownBlock2D, mid = UNetMidBlock2DCrossAttn, up = UpBlock2D + 3x
+        CrossAttnUpBlock2D, attention heads (5,10,20,20) of dim 64, cross_attention_dim 1024,
+        use_linear_projection, GroupNorm(32), SiLU, time embedding 320 -> 1280.
+  VAE encoder: block_out_channels (128,256,512,512), layers_per_block 2, one single-head mid
+        attention (d=512), latent_channels 4 (conv_out 8 = mean|logvar), scaling_factor 0.18215.
+  Scheduler: scaled_linear betas in [0.00085, 0.012], 1000 steps.
+Module/parameter names follow diffusers' state-dict keys so real checkpoints load with
+``load_state_dict`` (``load_diffusers_weights``).
+
+Layout choices for MI355X: activations are kept channels_last (NHWC) so the 3x3 convolutions run
+as implicit GEMMs over contiguous K = 9*C_in; attention goes through
+``F.scaled_dot_product_attention`` (flash-style, no N^2 tensor in HBM); weights and activations
+are bf16 (the reference uses fp16), normalisation statistics and softmax accumulate in fp32.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------------
+# building blocks
+# ----------------------------------------------------------------------------------------------
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, in_ch: int, out_ch: int, temb_ch: Optional[int], eps: float = 1e-5, groups: int = 32):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, in_ch, eps=eps)
+        self.conv1 = nn.Conv2d(in_ch, out_ch, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_ch, out_ch) if temb_ch is not None else None
+        self.norm2 = nn.GroupNorm(groups, out_ch, eps=eps)
+        self.conv2 = nn.Conv2d(out_ch, out_ch, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
+
+    def forward(self, x, temb=None):
+        h = self.conv1(F.silu(self.norm1(x)))
+        if self.time_emb_proj is not None:
+            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class Attention(nn.Module):
+    """Multi-head attention with diffusers' parameter names (to_q/to_k/to_v/to_out.0)."""
+
+    def __init__(self, query_dim: int, heads: int, dim_head: int, cross_dim: Optional[int] = None,
+                 qkv_bias: bool = False):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.to_q = nn.Linear(query_dim, inner, bias=qkv_bias)
+        self.to_k = nn.Linear(cross_dim or query_dim, inner, bias=qkv_bias)
+        self.to_v = nn.Linear(cross_dim or query_dim, inner, bias=qkv_bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim)])
+
+    def forward(self, x, context=None):
+        B, N, _ = x.shape
+        ctx = x if context is None else context
+        q = self.to_q(x).view(B, N, self.heads, -1).transpose(1, 2)
+        k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        v = self.to_v(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v)
+        return self.to_out[0](o.transpose(1, 2).reshape(B, N, -1))
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim: int, mult: int = 4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Identity(), nn.Linear(dim * mult, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim: int, heads: int, dim_head: int, cross_dim: int):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, heads, dim_head)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, heads, dim_head, cross_dim=cross_dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, context):
+        x = x + self.attn1(self.norm1(x))
+        x = x + self.attn2(self.norm2(x), context)
+        x = x + self.ff(self.norm3(x))
+        return x
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, channels: int, heads: int, dim_head: int, cross_dim: int, groups: int = 32):
+        super().__init__()
+        self.norm = nn.GroupNorm(groups, channels, eps=1e-6)
+        self.proj_in = nn.Linear(channels, channels)  # use_linear_projection
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(channels, heads, dim_head, cross_dim)])
+        self.proj_out = nn.Linear(channels, channels)
+
+    def forward(self, x, context):
+        B, C, H, W = x.shape
+        h = self.norm(x)
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)  # free for channels_last activations
+        h = self.proj_in(h)
+        for blk in self.transformer_blocks:
+            h = blk(h, context)
+        h = self.proj_out(h)
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        return h + x
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, ch: int, padding: int = 1):
+        super().__init__()
+        self.padding = padding
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=padding)
+
+    def forward(self, x):
+        if self.padding == 0:  # VAE encoder: asymmetric pad (0,1,0,1)
+            x = F.pad(x, (0, 1, 0, 1))
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, ch: int):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class _DownBlock(nn.Module):
+    def __init__(self, in_ch, out_ch, temb_ch, n_layers, heads, cross_dim, attn: bool, down: bool):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(in_ch if i == 0 else out_ch, out_ch, temb_ch) for i in range(n_layers)])
+        self.attentions = nn.ModuleList(
+            [Transformer2DModel(out_ch, heads, out_ch // heads, cross_dim) for _ in range(n_layers)]) if attn else None
+        self.downsamplers = nn.ModuleList([Downsample2D(out_ch)]) if down else None
+
+    def forward(self, x, temb, context, skips):
+        for i, res in enumerate(self.resnets):
+            x = res(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, context)
+            skips.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            skips.append(x)
+        return x
+
+
+class _UpBlock(nn.Module):
+    def __init__(self, in_ch, prev_ch, out_ch, temb_ch, n_layers, heads, cross_dim, attn: bool, up: bool):
+        super().__init__()
+        res = []
+        for i in range(n_layers):
+            skip_ch = in_ch if i == n_layers - 1 else out_ch
+            res_in = prev_ch if i == 0 else out_ch
+            res.append(ResnetBlock2D(res_in + skip_ch, out_ch, temb_ch))
+        self.resnets = nn.ModuleList(res)
+        self.attentions = nn.ModuleList(
+            [Transformer2DModel(out_ch, heads, out_ch // heads, cross_dim) for _ in range(n_layers)]) if attn else None
+        self.upsamplers = nn.ModuleList([Upsample2D(out_ch)]) if up else None
+
+    def forward(self, x, temb, context, skips):
+        for i, res in enumerate(self.resnets):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = res(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, context)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class _MidBlockCrossAttn(nn.Module):
+    def __init__(self, ch, temb_ch, heads, cross_dim):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb_ch), ResnetBlock2D(ch, ch, temb_ch)])
+        self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, ch // heads, cross_dim)])
+
+    def forward(self, x, temb, context):
+        x = self.resnets[0](x, temb)
+        x = self.attentions[0](x, context)
+        return self.resnets[1](x, temb)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_ch, out_ch)
+        self.linear_2 = nn.Linear(out_ch, out_ch)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+def sinusoidal_timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusers ``Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)`` -> [B, dim] fp32."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
+    emb = t.float()[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+class UNet2DConditionModel(nn.Module):
+    """SD-2.1 denoiser.  ``forward(sample[B,4,h,w], timestep[B], encoder_hidden_states[B,77,1024])``
+    returns the predicted noise ``[B,4,h,w]`` (the reference reads ``.sample`` of diffusers' output
+    object: stable_diffusion_guidance.py:153-157)."""
+
+    def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                 cross_attention_dim=1024, attention_head_dim=(5, 10, 20, 20)):
+        super().__init__()
+        ch = block_out_channels
+        temb_ch = ch[0] * 4
+        self.block_out_channels = tuple(ch)
+        self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch[0], temb_ch)
+        self.down_blocks = nn.ModuleList()
+        out = ch[0]
+        for i, c in enumerate(ch):
+            inp, out = out, c
+            last = i == len(ch) - 1
+            self.down_blocks.append(_DownBlock(inp, out, temb_ch, layers_per_block, attention_head_dim[i],
+                                               cross_attention_dim, attn=not last, down=not last))
+        self.mid_block = _MidBlockCrossAttn(ch[-1], temb_ch, attention_head_dim[-1], cross_attention_dim)
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(ch))
+        rev_heads = list(reversed(attention_head_dim))
+        out = rev[0]
+        for i, c in enumerate(rev):
+            prev, out = out, c
+            inp = rev[min(i + 1, len(ch) - 1)]
+            last = i == len(ch) - 1
+            self.up_blocks.append(_UpBlock(inp, prev, out, temb_ch, layers_per_block + 1, rev_heads[i],
+                                           cross_attention_dim, attn=i != 0, up=not last))
+        self.conv_norm_out = nn.GroupNorm(32, ch[0], eps=1e-5)
+        self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
+
+    def forward(self, sample, timestep, encoder_hidden_states):
+        dtype = self.conv_in.weight.dtype
+        if timestep.dim() == 0:
+            timestep = timestep[None].expand(sample.shape[0])
+        temb = self.time_embedding(sinusoidal_timestep_embedding(timestep, self.block_out_channels[0]).to(dtype))
+        x = self.conv_in(sample.to(dtype).contiguous(memory_format=torch.channels_last))
+        ctx = encoder_hidden_states.to(dtype)
+        skips = [x]
+        for blk in self.down_blocks:
+            x = blk(x, temb, ctx, skips)
+        x = self.mid_block(x, temb, ctx)
+        for blk in self.up_blocks:
+            x = blk(x, temb, ctx, skips)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+# ----------------------------------------------------------------------------------------------
+# VAE encoder
+# ----------------------------------------------------------------------------------------------
+
+
+class _VAEAttention(nn.Module):
+    """Single-head spatial self-attention of the VAE mid block (N = h*w tokens, d = channels)."""
+
+    def __init__(self, ch: int):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.to_q = nn.Linear(ch, ch)
+        self.to_k = nn.Linear(ch, ch)
+        self.to_v = nn.Linear(ch, ch)
+        self.to_out = nn.ModuleList([nn.Linear(ch, ch)])
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        h = self.group_norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        q, k, v = self.to_q(h)[:, None], self.to_k(h)[:, None], self.to_v(h)[:, None]
+        o = F.scaled_dot_product_attention(q, k, v)[:, 0]
+        o = self.to_out[0](o).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        return x + o
+
+
+class _VAEDownBlock(nn.Module):
+    def __init__(self, in_ch, out_ch, n_layers, down: bool):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(in_ch if i == 0 else out_ch, out_ch, None, eps=1e-6) for i in range(n_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_ch, padding=0)]) if down else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+        return x
+
+
+class _VAEMidBlock(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, None, eps=1e-6), ResnetBlock2D(ch, ch, None, eps=1e-6)])
+        self.attentions = nn.ModuleList([_VAEAttention(ch)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4):
+        super().__init__()
+        ch = block_out_channels
+        self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        out = ch[0]
+        for i, c in enumerate(ch):
+            inp, out = out, c
+            self.down_blocks.append(_VAEDownBlock(inp, out, layers_per_block, down=i != len(ch) - 1))
+        self.mid_block = _VAEMidBlock(ch[-1])
+        self.conv_norm_out = nn.GroupNorm(32, ch[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(ch[-1], 2 * latent_channels, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x.contiguous(memory_format=torch.channels_last))
+        for b in self.down_blocks:
+            x = b(x)
+        x = self.mid_block(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class DiagonalGaussianDistribution:
+    def __init__(self, parameters: torch.Tensor):
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, noise: Optional[torch.Tensor] = None, generator=None) -> torch.Tensor:
+        if noise is None:
+            noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * noise
+
+    def mode(self):
+        return self.mean
+
+
+class _EncodeOutput:
+    def __init__(self, dist):
+        self.latent_dist = dist
+
+
+class _VAEConfig:
+    scaling_factor = 0.18215
+
+
+class AutoencoderKLEncoder(nn.Module):
+    """Encoder half of AutoencoderKL: ``encode(x).latent_dist.sample()`` as the reference calls it
+    (stable_diffusion_guidance.py:165-166).  The decoder is only used by ``guidance_eval`` previews
+    (disabled in the pipeline: GaussianDreamer.py:244) and is out of scope."""
+
+    config = _VAEConfig()
+
+    def __init__(self, block_out_channels=(128, 256, 512, 512)):
+        super().__init__()
+        self.encoder = Encoder(block_out_channels=block_out_channels)
+        self.quant_conv = nn.Conv2d(8, 8, 1)
+
+    def encode(self, x):
+        return _EncodeOutput(DiagonalGaussianDistribution(self.quant_conv(self.encoder(x.to(self.quant_conv.weight.dtype)))))
+
+
+# ----------------------------------------------------------------------------------------------
+# scheduler
+# ----------------------------------------------------------------------------------------------
+
+
+class _SchedulerConfig:
+    num_train_timesteps = 1000
+    prediction_type = "epsilon"
+
+
+class DDIMScheduler:
+    """The subset the guidance uses: ``alphas_cumprod``, ``config.num_train_timesteps``, ``add_noise``
+    (stable_diffusion_guidance.py:129-131,238).  scaled_linear betas, 1000 steps."""
+
+    def __init__(self, beta_start=0.00085, beta_end=0.012, num_train_timesteps=1000, prediction_type="epsilon"):
+        self.config = _SchedulerConfig()
+        self.config.num_train_timesteps = num_train_timesteps
+        self.config.prediction_type = prediction_type
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        sqrt_a = ac[timesteps] ** 0.5
+        sqrt_1ma = (1 - ac[timesteps]) ** 0.5
+        while sqrt_a.dim() < original_samples.dim():
+            sqrt_a = sqrt_a.unsqueeze(-1)
+            sqrt_1ma = sqrt_1ma.unsqueeze(-1)
+        return sqrt_a * original_samples + sqrt_1ma * noise
+
+
+# ----------------------------------------------------------------------------------------------
+# weights
+# ----------------------------------------------------------------------------------------------
+
+
+def init_random_(module: nn.Module, seed: int = 0) -> nn.Module:
+    """Deterministic random init ON THE MODULE'S DEVICE (fast for the 866 M-parameter UNet) at a
+    scale that keeps activations O(1) through ~60 residual blocks: N(0, 1/fan_in) weights,
+    residual-branch output layers scaled down, zero biases, unit norm gains."""
+    gens = {}
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            g = gens.get(p.device)
+            if g is None:
+                g = gens[p.device] = torch.Generator(device=p.device).manual_seed(seed)
+            if p.dim() > 1:
+                fan_in = p[0].numel()
+                p.normal_(0.0, 1.0 / math.sqrt(fan_in), generator=g)
+                if name.endswith(("conv2.weight", "to_out.0.weight", "net.2.weight", "proj_out.weight")):
+                    p.mul_(0.2)
+            elif name.endswith(".bias"):
+                p.zero_()
+            else:
+                p.fill_(1.0)
+    return module
+
+
+def load_diffusers_weights(module: nn.Module, path: str, prefix: str = "") -> None:
+    """Load a diffusers ``*.safetensors`` shard (UNet or VAE) by key; names already match."""
+    from safetensors.torch import load_file
+    sd = load_file(path)
+    if prefix:
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    own = module.state_dict()
+    missing = [k for k in own if k not in sd]
+    if missing:
+        raise KeyError(f"{len(missing)} parameters missing in {path}, e.g. {missing[:3]}")
+    module.load_state_dict({k: sd[k] for k in own})

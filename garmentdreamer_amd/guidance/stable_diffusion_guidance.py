@@ -1,0 +1,233 @@
+"""Score-Distillation guidance with the threestudio plugin surface.
+
+Mirrors ``StableDiffusionGuidance`` (Garment_3DGS/threestudio/models/guidance/
+stable_diffusion_guidance.py): same ``Config`` fields (:21-48), ``__call__`` signature and output
+dict (:374-448), ``set_min_max_steps`` (:141-143), ``update_step`` (:581-591), ``encode_images``
+(:160-167), ``forward_unet`` (:146-157), ``compute_grad_sds`` (:185-276) -- including the
+reference's CFG form ``eps_text + s (eps_text - eps_uncond)`` (:249-251) with cond-first text
+embeddings (prompt_processors/base.py:77-78), ``w = 1 - alphas_cumprod[t]``, nan_to_num, the
+``grad_clip`` schedule and the reparameterised MSE loss whose gradient w.r.t. the latents is
+exactly ``grad`` (:418-427).
+
+What differs, on purpose:
+  * the UNet / VAE / scheduler come from ``sd21.py`` (own restatement, random-init unless a local
+    checkpoint path is given) instead of ``diffusers.StableDiffusionPipeline.from_pretrained``;
+  * half precision is bf16 on MI355X (reference: fp16 + Lightning GradScaler);
+  * randomness is injectable: ``__call__(..., noise=, timesteps=, vae_noise=)`` so tests and
+    multi-GPU runs are reproducible (the reference draws VAE noise -> t -> eps from the global
+    generator, in that order: :166,401-407,237).  Without them the same order is used.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import sd21
+
+
+def C(value: Any, epoch: int, global_step: int) -> float:
+    """threestudio's schedule literal ``[start_step, v0, v1, end_step]``
+    (Garment_3DGS/threestudio/utils/misc.py:65-86)."""
+    if isinstance(value, (int, float)):
+        return value
+    value = list(value)
+    if len(value) == 3:
+        value = [0] + value
+    assert len(value) == 4
+    start_step, start_value, end_value, end_step = value
+    current = global_step if isinstance(end_step, int) else epoch
+    return start_value + (end_value - start_value) * max(min(1.0, (current - start_step) / (end_step - start_step)), 0.0)
+
+
+class StableDiffusionGuidance(nn.Module):
+    @dataclass
+    class Config:
+        pretrained_model_name_or_path: str = "stabilityai/stable-diffusion-2-1-base"
+        enable_memory_efficient_attention: bool = False
+        enable_sequential_cpu_offload: bool = False
+        enable_attention_slicing: bool = False
+        enable_channels_last_format: bool = True
+        guidance_scale: float = 100.0
+        grad_clip: Optional[Any] = None
+        half_precision_weights: bool = True
+        min_step_percent: float = 0.02
+        max_step_percent: float = 0.98
+        max_step_percent_annealed: float = 0.5
+        anneal_start_step: Optional[int] = None
+        use_sjc: bool = False
+        var_red: bool = True
+        weighting_strategy: str = "sds"
+        token_merging: bool = False
+        token_merging_params: Optional[dict] = field(default_factory=dict)
+        view_dependent_prompting: bool = True
+        max_items_eval: int = 4
+        # additions
+        unet_weights: Optional[str] = None   # local diffusers safetensors; None -> random init
+        vae_weights: Optional[str] = None
+        init_seed: int = 0
+
+    def __init__(self, cfg: Optional[dict] = None, device="cuda", unet: Optional[nn.Module] = None,
+                 vae: Optional[nn.Module] = None):
+        super().__init__()
+        cfg = cfg or {}
+        self.cfg = cfg if isinstance(cfg, self.Config) else self.Config(**cfg)
+        if self.cfg.use_sjc:
+            raise NotImplementedError("score-jacobian-chaining is not on GarmentDreamer's path (use_sjc=False)")
+        self.device = torch.device(device)
+        self.configure(unet, vae)
+
+    def configure(self, unet=None, vae=None) -> None:
+        self.weights_dtype = torch.bfloat16 if self.cfg.half_precision_weights else torch.float32
+        if unet is None:
+            with torch.device(self.device):
+                unet = sd21.UNet2DConditionModel()
+            if self.cfg.unet_weights:
+                sd21.load_diffusers_weights(unet, self.cfg.unet_weights)
+            else:
+                sd21.init_random_(unet, self.cfg.init_seed)
+        if vae is None:
+            with torch.device(self.device):
+                vae = sd21.AutoencoderKLEncoder()
+            if self.cfg.vae_weights:
+                sd21.load_diffusers_weights(vae, self.cfg.vae_weights)
+            else:
+                sd21.init_random_(vae, self.cfg.init_seed + 1)
+        fmt = torch.channels_last if self.cfg.enable_channels_last_format else torch.contiguous_format
+        self.unet = unet.to(device=self.device, dtype=self.weights_dtype).to(memory_format=fmt).eval()
+        self.vae = vae.to(device=self.device, dtype=self.weights_dtype).to(memory_format=fmt).eval()
+        for p in self.vae.parameters():
+            p.requires_grad_(False)
+        for p in self.unet.parameters():
+            p.requires_grad_(False)
+        self.scheduler = sd21.DDIMScheduler()
+        self.num_train_timesteps = self.scheduler.config.num_train_timesteps
+        self.set_min_max_steps()
+        self.alphas = self.scheduler.alphas_cumprod.to(self.device)
+        self.grad_clip_val: Optional[float] = None
+
+    def set_min_max_steps(self, min_step_percent=0.02, max_step_percent=0.98):
+        self.min_step = int(self.num_train_timesteps * min_step_percent)
+        self.max_step = int(self.num_train_timesteps * max_step_percent)
+
+    def forward_unet(self, latents, t, encoder_hidden_states):
+        input_dtype = latents.dtype
+        return self.unet(latents.to(self.weights_dtype), t.to(self.weights_dtype),
+                         encoder_hidden_states=encoder_hidden_states.to(self.weights_dtype)).to(input_dtype)
+
+    def encode_images(self, imgs, vae_noise: Optional[torch.Tensor] = None):
+        input_dtype = imgs.dtype
+        imgs = imgs * 2.0 - 1.0
+        posterior = self.vae.encode(imgs.to(self.weights_dtype)).latent_dist
+        noise = None if vae_noise is None else vae_noise.to(self.weights_dtype)
+        latents = posterior.sample(noise) * self.vae.config.scaling_factor
+        return latents.to(input_dtype)
+
+    def compute_grad_sds(self, latents, t, prompt_utils, elevation, azimuth, camera_distances,
+                         noise: Optional[torch.Tensor] = None):
+        if getattr(prompt_utils, "use_perp_neg", False):
+            raise NotImplementedError("perp-neg prompting is off in GarmentDreamer's config (use_perp_neg=False)")
+        text_embeddings = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances,
+                                                           self.cfg.view_dependent_prompting)
+        with torch.no_grad():
+            if noise is None:
+                noise = torch.randn_like(latents)
+            latents_noisy = self.scheduler.add_noise(latents, noise, t)
+            latent_model_input = torch.cat([latents_noisy] * 2, dim=0)
+            noise_pred = self.forward_unet(latent_model_input, torch.cat([t] * 2),
+                                           encoder_hidden_states=text_embeddings)
+        noise_pred_text, noise_pred_uncond = noise_pred.chunk(2)
+        noise_pred = noise_pred_text + self.cfg.guidance_scale * (noise_pred_text - noise_pred_uncond)
+
+        if self.cfg.weighting_strategy == "sds":
+            w = (1 - self.alphas[t]).view(-1, 1, 1, 1)
+        elif self.cfg.weighting_strategy == "uniform":
+            w = 1
+        elif self.cfg.weighting_strategy == "fantasia3d":
+            w = (self.alphas[t] ** 0.5 * (1 - self.alphas[t])).view(-1, 1, 1, 1)
+        else:
+            raise ValueError(f"Unknown weighting strategy: {self.cfg.weighting_strategy}")
+        grad = w * (noise_pred - noise)
+        guidance_eval_utils = {"use_perp_neg": False, "neg_guidance_weights": None,
+                               "text_embeddings": text_embeddings, "t_orig": t, "latents_noisy": latents_noisy,
+                               "noise_pred": noise_pred}
+        return grad, guidance_eval_utils
+
+    def __call__(self, rgb, prompt_utils, elevation, azimuth, camera_distances, rgb_as_latents=False,
+                 guidance_eval=False, noise: Optional[torch.Tensor] = None, timesteps: Optional[torch.Tensor] = None,
+                 vae_noise: Optional[torch.Tensor] = None, **kwargs):
+        batch_size = rgb.shape[0]
+        rgb_BCHW = rgb.permute(0, 3, 1, 2)
+        if rgb_as_latents:
+            latents = F.interpolate(rgb_BCHW, (64, 64), mode="bilinear", align_corners=False)
+        else:
+            rgb_BCHW_512 = F.interpolate(rgb_BCHW, (512, 512), mode="bilinear", align_corners=False)
+            latents = self.encode_images(rgb_BCHW_512, vae_noise)
+
+        if timesteps is None:
+            t = torch.randint(self.min_step, self.max_step + 1, [batch_size], dtype=torch.long, device=self.device)
+        else:
+            t = timesteps.to(device=self.device, dtype=torch.long)
+
+        grad, guidance_eval_utils = self.compute_grad_sds(latents, t, prompt_utils, elevation, azimuth,
+                                                          camera_distances, noise)
+        grad = torch.nan_to_num(grad)
+        if self.grad_clip_val is not None:
+            grad = grad.clamp(-self.grad_clip_val, self.grad_clip_val)
+        target = (latents - grad).detach()
+        loss_sds = 0.5 * F.mse_loss(latents, target, reduction="sum") / batch_size
+        guidance_out = {"loss_sds": loss_sds, "grad_norm": grad.norm(), "min_step": self.min_step,
+                        "max_step": self.max_step}
+        if guidance_eval:
+            raise NotImplementedError("guidance_eval previews need the VAE decoder, which is off GarmentDreamer's "
+                                      "path (GaussianDreamer.py:244 passes guidance_eval=False)")
+        return guidance_out
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        if self.cfg.grad_clip is not None:
+            self.grad_clip_val = C(self.cfg.grad_clip, epoch, global_step)
+        self.set_min_max_steps(min_step_percent=C(self.cfg.min_step_percent, epoch, global_step),
+                               max_step_percent=C(self.cfg.max_step_percent, epoch, global_step))
+
+
+class PromptEmbeddings:
+    """Stand-in for ``PromptProcessorOutput`` (prompt_processors/base.py:36-78): holds the four
+    view-dependent (side/front/back/overhead) cond + uncond embeddings and returns
+    ``[cond; uncond]`` ``[2B,77,1024]``.  The CLIP text encoder that fills it runs once at start-up
+    in the reference and is out of scope; benchmarks use N(0,1) embeddings."""
+
+    use_perp_neg = False
+
+    def __init__(self, text_embeddings_vd, uncond_text_embeddings_vd, front_threshold=45.0, back_threshold=45.0,
+                 overhead_threshold=60.0):
+        self.text_embeddings_vd = text_embeddings_vd          # [4,77,1024]
+        self.uncond_text_embeddings_vd = uncond_text_embeddings_vd
+        self.text_embeddings = text_embeddings_vd[:1]
+        self.uncond_text_embeddings = uncond_text_embeddings_vd[:1]
+        self.front_threshold, self.back_threshold, self.overhead_threshold = front_threshold, back_threshold, \
+            overhead_threshold
+
+    @classmethod
+    def random(cls, device, dtype=torch.float32, seed: int = 0):
+        g = torch.Generator().manual_seed(seed)
+        e = torch.randn(2, 4, 77, 1024, generator=g).to(device=device, dtype=dtype)
+        return cls(e[0], e[1])
+
+    def get_text_embeddings(self, elevation, azimuth, camera_distances, view_dependent_prompting=True):
+        batch_size = elevation.shape[0]
+        if view_dependent_prompting:
+            # side=0 (default), front=1, back=2, overhead=3; later rules override earlier ones
+            azi = (azimuth + 180) % 360 - 180  # shift_azimuth_deg
+            idx = torch.zeros_like(elevation, dtype=torch.long)
+            idx[(azi > -self.front_threshold) & (azi < self.front_threshold)] = 1
+            idx[(azi > 180 - self.back_threshold) | (azi < -180 + self.back_threshold)] = 2
+            idx[elevation > self.overhead_threshold] = 3
+            idx = idx.to(self.text_embeddings_vd.device)
+            text, uncond = self.text_embeddings_vd[idx], self.uncond_text_embeddings_vd[idx]
+        else:
+            text = self.text_embeddings.expand(batch_size, -1, -1)
+            uncond = self.uncond_text_embeddings.expand(batch_size, -1, -1)
+        return torch.cat([text, uncond], dim=0)

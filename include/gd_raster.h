@@ -126,8 +126,8 @@ int gd_raster_backward_batched(void* stream, int V, int P, int D, int M, int R, 
 typedef struct gd_raster_layout {
     /* geometry chunk (per (view, Gaussian) index vp = v*P + g) */
     size_t depths, clamped, radii, means2D, cov3D, conic_opacity, rgb, tiles_touched, point_offsets, block_sums;
-    /* image chunk */
-    size_t ranges, n_contrib;
+    /* image chunk; pair_counts[pixel] = {list entries visited by the forward pass, entries blended} */
+    size_t ranges, n_contrib, pair_counts;
     /* binning chunk */
     size_t point_list, point_list_alt, keys, keys_alt, sort_hist;
 } gd_raster_layout;
@@ -137,6 +137,25 @@ int gd_raster_get_layout(const char* geom_base, const char* image_base, const ch
 /* Number of radix passes / sorted key bits used for a tile grid (getHigherMsb,
  * rasterizer_impl.cu:35-50,301). */
 int gd_raster_sort_bits(int width, int height, int V);
+
+/* ---- Per-kernel timing for bench.py's roofline line.  When enabled, every launch of the
+ * listed kernels is bracketed by hipEvents on the launch stream; gd_raster_profile_collect()
+ * waits for the recorded events and folds them into per-kernel totals.  Disabled by default
+ * (zero overhead).  Kernel ids: */
+#define GD_K_PREPROCESS 0
+#define GD_K_SCAN 1
+#define GD_K_DUPLICATE 2
+#define GD_K_SORT 3
+#define GD_K_RANGES 4
+#define GD_K_RENDER_FWD 5
+#define GD_K_RENDER_BWD 6
+#define GD_K_PREPROCESS_BWD 7
+#define GD_K_COUNT 8
+int gd_raster_profile_enable(int on);
+int gd_raster_profile_collect(void);
+int gd_raster_profile_get(int kernel_id, double* total_ms, int64_t* launches);
+int gd_raster_profile_reset(void);
+const char* gd_raster_profile_kernel_name(int kernel_id);
 
 const char* gd_raster_last_error(void);
 const char* gd_raster_build_info(void);

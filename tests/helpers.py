@@ -71,6 +71,7 @@ def read_scratch(geom, binning, img, P, V, W, H, R):
         point_offsets=view(g, lay.point_offsets, VP, np.uint32),
         ranges=view(im, lay.ranges, tiles * 2, np.uint32).reshape(tiles, 2),
         n_contrib=view(im, lay.n_contrib, V * H * W, np.uint32).reshape(V, H, W),
+        pair_counts=view(im, lay.pair_counts, V * H * W * 2, np.uint32).reshape(V, H, W, 2),
         point_list=view(b, lay.point_list, R, np.uint32),
         keys=view(b, lay.keys, R, np.uint64),
     )

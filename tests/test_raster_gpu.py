@@ -45,6 +45,10 @@ def _check_forward(inp, st, out, exact_ncontrib=True):
     np.testing.assert_array_equal(sc["point_list"], st.point_list)
     np.testing.assert_array_equal(sc["ranges"], st.ranges)
     nc = sc["n_contrib"][0]
+    # work counters used by bench.py's roofline: visited / blended pairs of the forward pass, and
+    # sum(n_contrib) == pairs the backward pass visits
+    assert abs(int(sc["pair_counts"][0, :, :, 0].sum()) - st.pairs_visited_fwd) <= 1e-4 * st.pairs_visited_fwd + 64
+    assert abs(int(sc["pair_counts"][0, :, :, 1].sum()) - st.pairs_blended_fwd) <= 1e-4 * st.pairs_blended_fwd + 8
     mism = int((nc != st.n_contrib).sum())
     if exact_ncontrib:
         assert mism <= max(1, int(1e-4 * nc.size)), f"n_contrib mismatches: {mism}"
