@@ -79,6 +79,11 @@ def lib():
             raise NativeLibraryError(
                 f"{_LIB_PATH} not found: build it with `python -m garmentdreamer_amd._build` "
                 "(hipcc --offload-arch=gfx950). The HIP rasterizer has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; load it FIRST so
+        # our library's DT_NEEDED libamdhip64.so.7 binds to the same instance (streams and device
+        # pointers are shared with torch).  Loading ours first puts a second runtime in the
+        # process and every call then fails with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         try:
             L = C.CDLL(_LIB_PATH)
         except OSError as e:  # e.g. libamdhip64 missing
