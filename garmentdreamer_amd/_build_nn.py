@@ -1,0 +1,11 @@
+"""Second in-tree HIP library: kernels of the guidance step (include/gd_nn.h)."""
+from __future__ import annotations
+
+NN_SOURCES = [
+    ("nn_groupnorm.hip", ["-munsafe-fp-atomics"]),
+]
+
+
+def build(force: bool = False, verbose: bool = False):
+    from . import _build
+    return [_build.build_library("libgd_nn.so", NN_SOURCES, force, verbose)]

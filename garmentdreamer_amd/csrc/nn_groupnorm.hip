@@ -1,0 +1,304 @@
+// nn_groupnorm.hip -- GroupNorm(32) (+ SiLU) on NHWC bf16 activations, forward and input-gradient.
+//
+// Why hand-written: PyTorch-ROCm's native GroupNorm kernels are NCHW-only, so with channels_last
+// convolutions every GroupNorm costs two full-tensor layout copies plus separate moments / affine /
+// SiLU kernels (9+ tensor passes).  Here: one statistics pass + one fused normalise*gamma+beta ->
+// SiLU pass (3 tensor passes), directly on NHWC.  Pure HBM streams: 16-byte (8 x bf16) vector
+// accesses, thread <-> fixed channel vector so gamma/beta/mean/rstd live in registers, fp32 math,
+// fp64 global accumulation of the (few) per-workgroup partial sums.
+//
+// Layout: x[n][p][c], p = pixel (H*W), c fastest.  Workgroup = rows x vpp threads where
+// vpp = C/8 vectors per pixel and rows = max(1, 256 / vpp); blockIdx.x walks pixel chunks,
+// blockIdx.y = n.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gd_nn.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+struct alignas(16) bf16x8 {
+    uint16_t v[8];
+};
+
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                              // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+constexpr int kMaxThreads = 320;  // C = 2560 -> 320 vectors per pixel
+
+// Sum over the workgroup of per-thread per-channel partials, folded to per-group totals and added
+// to ws[n][g][0..1] in fp64.  `a`, `b`: the thread's 8-channel partial sums of two quantities.
+__device__ __forceinline__ void reduce_to_groups(const float (&a)[8], const float (&b)[8], int vpp, int rows, int tv,
+                                                 int tr, int C, int G, double* __restrict__ ws_n, float* lds)
+{
+    // lds: [2][rows][C]
+    float* la = lds;
+    float* lb = lds + (size_t)rows * C;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        la[tr * C + tv * 8 + k] = a[k];
+        lb[tr * C + tv * 8 + k] = b[k];
+    }
+    __syncthreads();
+    // column sums over the workgroup's rows (parallel over channels), then channels -> groups
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sa = 0.f, sb = 0.f;
+        for (int r = 0; r < rows; r++) {
+            sa += la[r * C + c];
+            sb += lb[r * C + c];
+        }
+        la[c] = sa;   // row 0 is only read by this same thread for column c
+        lb[c] = sb;
+    }
+    __syncthreads();
+    const int cg = C / G;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float sa = 0.f, sb = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; c++) {
+            sa += la[c];
+            sb += lb[c];
+        }
+        atomicAdd(&ws_n[2 * g], (double)sa);
+        atomicAdd(&ws_n[2 * g + 1], (double)sb);
+    }
+}
+
+__global__ void gn_stats_kernel(const bf16x8* __restrict__ x, int HW, int C, int G, int vpp, int rows, int ppb,
+                                double* __restrict__ ws)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n = blockIdx.y;
+    const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    float s[8], ss[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = ss[k] = 0.f;
+    const bf16x8* xn = x + (size_t)n * HW * vpp;
+    for (int p = p0 + tr; p < p1; p += rows) {
+        const bf16x8 v = xn[(size_t)p * vpp + tv];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float f = bf2f(v.v[k]);
+            s[k] += f;
+            ss[k] += f * f;
+        }
+    }
+    reduce_to_groups(s, ss, vpp, rows, tv, tr, C, G, ws + (size_t)n * G * 2, lds);
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+
+__global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y,
+                                const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta, int HW, int C,
+                                int G, int vpp, int rows, int ppb, float eps, int apply_silu,
+                                const double* __restrict__ ws, float* __restrict__ mean_rstd)
+{
+    const int n = blockIdx.y;
+    const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    const int cg = C / G;
+    const double M = (double)HW * cg;
+    float a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = tv * 8 + k, g = c / cg;
+        const double mean = ws[((size_t)n * G + g) * 2] / M;
+        double var = ws[((size_t)n * G + g) * 2 + 1] / M - mean * mean;
+        var = var < 0 ? 0 : var;
+        const float rstd = rsqrtf((float)var + eps);
+        a[k] = rstd * bf2f(gamma[c]);
+        b[k] = bf2f(beta[c]) - (float)mean * a[k];
+        if (blockIdx.x == 0 && tr == 0 && (c % cg) == 0) {
+            mean_rstd[((size_t)n * G + g) * 2] = (float)mean;
+            mean_rstd[((size_t)n * G + g) * 2 + 1] = rstd;
+        }
+    }
+    const bf16x8* xn = x + (size_t)n * HW * vpp;
+    bf16x8* yn = y + (size_t)n * HW * vpp;
+    for (int p = p0 + tr; p < p1; p += rows) {
+        const bf16x8 v = xn[(size_t)p * vpp + tv];
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float z = bf2f(v.v[k]) * a[k] + b[k];
+            if (apply_silu) z = silu_f(z);
+            o.v[k] = f2bf(z);
+        }
+        yn[(size_t)p * vpp + tv] = o;
+    }
+}
+
+// dz = dy * silu'(z) (or dy); per group: s1 = sum gamma*dz, s2 = sum gamma*dz*xhat
+__global__ void gn_bwd_stats_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy,
+                                    const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+                                    const float* __restrict__ mean_rstd, int HW, int C, int G, int vpp, int rows,
+                                    int ppb, int apply_silu, double* __restrict__ ws)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n = blockIdx.y;
+    const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    const int cg = C / G;
+    float mean[8], rstd[8], gm[8], bt[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = tv * 8 + k, g = c / cg;
+        mean[k] = mean_rstd[((size_t)n * G + g) * 2];
+        rstd[k] = mean_rstd[((size_t)n * G + g) * 2 + 1];
+        gm[k] = bf2f(gamma[c]);
+        bt[k] = bf2f(beta[c]);
+        s1[k] = s2[k] = 0.f;
+    }
+    const bf16x8* xn = x + (size_t)n * HW * vpp;
+    const bf16x8* dn = dy + (size_t)n * HW * vpp;
+    for (int p = p0 + tr; p < p1; p += rows) {
+        const bf16x8 v = xn[(size_t)p * vpp + tv];
+        const bf16x8 d = dn[(size_t)p * vpp + tv];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float xh = (bf2f(v.v[k]) - mean[k]) * rstd[k];
+            float dz = bf2f(d.v[k]);
+            if (apply_silu) {
+                const float z = xh * gm[k] + bt[k];
+                const float sg = 1.f / (1.f + __expf(-z));
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            const float t = dz * gm[k];
+            s1[k] += t;
+            s2[k] += t * xh;
+        }
+    }
+    reduce_to_groups(s1, s2, vpp, rows, tv, tr, C, G, ws + (size_t)n * G * 2, lds);
+}
+
+__global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy,
+                                    const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+                                    const float* __restrict__ mean_rstd, bf16x8* __restrict__ dx, int HW, int C,
+                                    int G, int vpp, int rows, int ppb, int apply_silu, const double* __restrict__ ws)
+{
+    const int n = blockIdx.y;
+    const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    const int cg = C / G;
+    const float invM = 1.f / ((float)HW * cg);
+    float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = tv * 8 + k, g = c / cg;
+        mean[k] = mean_rstd[((size_t)n * G + g) * 2];
+        rstd[k] = mean_rstd[((size_t)n * G + g) * 2 + 1];
+        gm[k] = bf2f(gamma[c]);
+        bt[k] = bf2f(beta[c]);
+        m1[k] = (float)ws[((size_t)n * G + g) * 2] * invM;
+        m2[k] = (float)ws[((size_t)n * G + g) * 2 + 1] * invM;
+    }
+    const bf16x8* xn = x + (size_t)n * HW * vpp;
+    const bf16x8* dn = dy + (size_t)n * HW * vpp;
+    bf16x8* on = dx + (size_t)n * HW * vpp;
+    for (int p = p0 + tr; p < p1; p += rows) {
+        const bf16x8 v = xn[(size_t)p * vpp + tv];
+        const bf16x8 d = dn[(size_t)p * vpp + tv];
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float xh = (bf2f(v.v[k]) - mean[k]) * rstd[k];
+            float dz = bf2f(d.v[k]);
+            if (apply_silu) {
+                const float z = xh * gm[k] + bt[k];
+                const float sg = 1.f / (1.f + __expf(-z));
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            o.v[k] = f2bf(rstd[k] * (dz * gm[k] - m1[k] - xh * m2[k]));
+        }
+        on[(size_t)p * vpp + tv] = o;
+    }
+}
+
+struct Geo {
+    int vpp, rows, threads, ppb, nchunks;
+    size_t lds;
+};
+
+bool make_geo(int HW, int C, int G, int N, Geo* g)
+{
+    if (C <= 0 || G <= 0 || C % 8 || C % G || HW <= 0 || N <= 0) return false;
+    g->vpp = C / 8;
+    if (g->vpp > kMaxThreads) return false;
+    g->rows = g->vpp >= 256 ? 1 : 256 / g->vpp;
+    g->threads = g->rows * g->vpp;
+    // enough workgroups to fill 256 CUs a few times over, but >= rows pixels each
+    int ppb = 1024;
+    while (ppb > g->rows && (long)((HW + ppb - 1) / ppb) * N < 2048) ppb >>= 1;
+    if (ppb < g->rows) ppb = g->rows;
+    g->ppb = ppb;
+    g->nchunks = (HW + ppb - 1) / ppb;
+    g->lds = (size_t)2 * g->rows * C * sizeof(float);
+    return true;
+}
+
+int fail(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gd_nn_groupnorm_ws_bytes(int N, int G) { return (size_t)N * G * 2 * sizeof(double); }
+
+int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
+                                 int HW, int C, int G, float eps, int apply_silu, double* stats_ws, float* mean_rstd)
+{
+    Geo g;
+    if (!x || !y || !gamma || !beta || !stats_ws || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats_ws, 0, gd_nn_groupnorm_ws_bytes(N, G), s) != hipSuccess)
+        return fail(GD_NN_ERR_HIP, "hipMemsetAsync failed");
+    dim3 grid(g.nchunks, N), block(g.threads);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows, g.ppb,
+                       stats_ws);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (bf16x8*)y, (const uint16_t*)gamma,
+                       (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, eps, apply_silu, stats_ws, mean_rstd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_groupnorm_silu_backward(void* stream, const void* x, const void* dy, const void* gamma, const void* beta,
+                                  const float* mean_rstd, void* dx, int N, int HW, int C, int G, int apply_silu,
+                                  double* stats_ws)
+{
+    Geo g;
+    if (!x || !dy || !gamma || !beta || !stats_ws || !mean_rstd || !dx)
+        return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats_ws, 0, gd_nn_groupnorm_ws_bytes(N, G), s) != hipSuccess)
+        return fail(GD_NN_ERR_HIP, "hipMemsetAsync failed");
+    dim3 grid(g.nchunks, N), block(g.threads);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, block, g.lds, s, (const bf16x8*)x, (const bf16x8*)dy,
+                       (const uint16_t*)gamma, (const uint16_t*)beta, mean_rstd, HW, C, G, g.vpp, g.rows, g.ppb,
+                       apply_silu, stats_ws);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (const bf16x8*)dy,
+                       (const uint16_t*)gamma, (const uint16_t*)beta, mean_rstd, (bf16x8*)dx, HW, C, G, g.vpp, g.rows,
+                       g.ppb, apply_silu, stats_ws);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+const char* gd_nn_last_error(void) { return g_err; }
+
+}  // extern "C"

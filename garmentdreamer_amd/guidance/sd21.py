@@ -34,6 +34,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..nn_ops import group_norm_silu
+
+
+def _gn(norm: nn.GroupNorm, x, silu: bool):
+    """GroupNorm (+SiLU): fused NHWC HIP kernel on the GPU (nn_ops), torch ops on CPU."""
+    return group_norm_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu)
+
+
 # ----------------------------------------------------------------------------------------------
 # building blocks
 # ----------------------------------------------------------------------------------------------
@@ -50,10 +58,10 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
     def forward(self, x, temb=None):
-        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv1(_gn(self.norm1, x, True))
         if self.time_emb_proj is not None:
             h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self.conv2(_gn(self.norm2, h, True))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return x + h
@@ -128,7 +136,7 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, context):
         B, C, H, W = x.shape
-        h = self.norm(x)
+        h = _gn(self.norm, x, False)
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)  # free for channels_last activations
         h = self.proj_in(h)
         for blk in self.transformer_blocks:
@@ -281,7 +289,7 @@ class UNet2DConditionModel(nn.Module):
         x = self.mid_block(x, temb, ctx)
         for blk in self.up_blocks:
             x = blk(x, temb, ctx, skips)
-        return self.conv_out(F.silu(self.conv_norm_out(x)))
+        return self.conv_out(_gn(self.conv_norm_out, x, True))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -302,7 +310,7 @@ class _VAEAttention(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        h = self.group_norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        h = _gn(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
         q, k, v = self.to_q(h)[:, None], self.to_k(h)[:, None], self.to_v(h)[:, None]
         o = F.scaled_dot_product_attention(q, k, v)[:, 0]
         o = self.to_out[0](o).reshape(B, H, W, C).permute(0, 3, 1, 2)
@@ -353,7 +361,7 @@ class Encoder(nn.Module):
         for b in self.down_blocks:
             x = b(x)
         x = self.mid_block(x)
-        return self.conv_out(F.silu(self.conv_norm_out(x)))
+        return self.conv_out(_gn(self.conv_norm_out, x, True))
 
 
 class DiagonalGaussianDistribution:
