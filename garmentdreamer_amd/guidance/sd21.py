@@ -34,12 +34,27 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..nn_ops import group_norm_silu
+from ..nn_ops import conv3x3, conv3x3_supported, group_norm_silu
 
 
 def _gn(norm: nn.GroupNorm, x, silu: bool):
     """GroupNorm (+SiLU): fused NHWC HIP kernel on the GPU (nn_ops), torch ops on CPU."""
     return group_norm_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu)
+
+
+def _conv3(conv: nn.Conv2d, x, image_bias=None, residual=None):
+    """3x3/s1/p1 convolution with the bias (or a per-image bias [N,Cout]) and an optional residual
+    fused into the MFMA kernel's epilogue (nn_ops.conv3x3); falls back to torch's conv for layers the
+    kernel does not cover (Cin % 64 != 0, fp32, CPU, or too few 128x128 tiles to fill the chip)."""
+    bias = conv.bias if image_bias is None else image_bias
+    if conv3x3_supported(x, conv.weight) and conv.stride == (1, 1) and conv.padding == (1, 1):
+        tiles = -(-x.shape[0] * x.shape[2] * x.shape[3] // 128) * -(-conv.out_channels // 128)
+        if tiles >= 128:
+            return conv3x3(x, conv.weight, bias, residual)
+    y = F.conv2d(x, conv.weight, None if image_bias is not None else conv.bias, conv.stride, conv.padding)
+    if image_bias is not None:
+        y = y + image_bias[:, :, None, None]
+    return y if residual is None else y + residual
 
 
 # ----------------------------------------------------------------------------------------------
@@ -58,13 +73,13 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
     def forward(self, x, temb=None):
-        h = self.conv1(_gn(self.norm1, x, True))
-        if self.time_emb_proj is not None:
-            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(_gn(self.norm2, h, True))
+        image_bias = None
+        if self.time_emb_proj is not None:  # conv bias + time-embedding projection = one per-image bias
+            image_bias = self.time_emb_proj(F.silu(temb)) + self.conv1.bias
+        h = _conv3(self.conv1, _gn(self.norm1, x, True), image_bias=image_bias)
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
-        return x + h
+        return _conv3(self.conv2, _gn(self.norm2, h, True), residual=x)
 
 
 class Attention(nn.Module):
@@ -164,7 +179,7 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return _conv3(self.conv, F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
 class _DownBlock(nn.Module):
@@ -289,7 +304,7 @@ class UNet2DConditionModel(nn.Module):
         x = self.mid_block(x, temb, ctx)
         for blk in self.up_blocks:
             x = blk(x, temb, ctx, skips)
-        return self.conv_out(_gn(self.conv_norm_out, x, True))
+        return _conv3(self.conv_out, _gn(self.conv_norm_out, x, True))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -361,7 +376,7 @@ class Encoder(nn.Module):
         for b in self.down_blocks:
             x = b(x)
         x = self.mid_block(x)
-        return self.conv_out(_gn(self.conv_norm_out, x, True))
+        return _conv3(self.conv_out, _gn(self.conv_norm_out, x, True))
 
 
 class DiagonalGaussianDistribution:

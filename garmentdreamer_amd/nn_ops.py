@@ -19,6 +19,9 @@ SIGNATURES = {
     "gd_nn_groupnorm_silu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "gd_nn_groupnorm_silu_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
+    "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
+    "gd_nn_conv_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
 }
 
@@ -94,3 +97,89 @@ def group_norm_silu(x, weight, bias, groups: int, eps: float, silu: bool = True)
         # fp32 GPU runs (parity checks of the bf16 path) use torch's ops
     y = F.group_norm(x, groups, weight, bias, eps)
     return F.silu(y) if silu else y
+
+
+# ---------------------------------------------------------------------------------------------
+# 3x3 convolution (implicit GEMM on MFMA), fused bias / per-image bias / residual
+# ---------------------------------------------------------------------------------------------
+
+def _conv_launch(x, w_khwc, bias, residual, out_channels):
+    N, Cin, H, W = x.shape
+    L = lib()
+    y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device,
+                    memory_format=torch.channels_last)
+    stride = 0
+    if bias is not None:
+        bias = bias.contiguous()
+        stride = out_channels if bias.dim() == 2 else 0
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        ret = L.gd_nn_conv3x3_forward(stream, x.data_ptr(), w_khwc.data_ptr(), None if bias is None else bias.data_ptr(),
+                                      stride, None if residual is None else residual.data_ptr(), y.data_ptr(), N, H,
+                                      W, Cin, out_channels)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_conv3x3_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+    return y
+
+
+def _flipped(weight):
+    """Cached dgrad weights [Cin][3][3][Cout] for a frozen conv weight (stored channels_last)."""
+    f = getattr(weight, "_gd_flipped", None)
+    if f is None or f.device != weight.device:
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        f = torch.empty((Cin, Cout, 3, 3), dtype=torch.bfloat16, device=weight.device,
+                        memory_format=torch.channels_last)
+        L = lib()
+        with torch.cuda.device(weight.device):
+            ret = L.gd_nn_conv3x3_flip_weights(torch.cuda.current_stream(weight.device).cuda_stream,
+                                               weight.data_ptr(), f.data_ptr(), Cout, Cin)
+        if ret < 0:
+            raise RuntimeError("gd_nn_conv3x3_flip_weights failed")
+        weight._gd_flipped = f
+    return f
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        ctx.weight = weight
+        ctx.has_res = residual is not None
+        return _conv_launch(x, weight, bias, residual, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        w = ctx.weight
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if w.shape[0] % 64 == 0:
+                dx = _conv_launch(dy, _flipped(w), None, None, w.shape[1])
+            else:  # tiny-Cout layers (e.g. 512 -> 8) : K of the dgrad GEMM is not a multiple of 64
+                dx = torch.nn.grad.conv2d_input(dy.shape[:1] + (w.shape[1],) + dy.shape[2:], w, dy, padding=1)
+        return dx, None, None, (dy if ctx.has_res else None)
+
+
+def conv3x3_supported(x, weight) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] % 64 == 0 and weight.shape[0] % 4 == 0
+            and weight.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv3x3(x, weight, bias=None, residual=None):
+    """3x3 / stride 1 / pad 1 convolution (+ bias [Cout] or per-image bias [N,Cout]) (+ residual).
+    MFMA implicit-GEMM HIP kernel for bf16 NHWC GPU tensors; torch ops otherwise (CPU / fp32)."""
+    if conv3x3_supported(x, weight):
+        if weight.requires_grad or (bias is not None and bias.requires_grad):
+            raise RuntimeError("conv3x3 HIP kernel computes input gradients only (frozen weights)")
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+            residual = residual.contiguous(memory_format=torch.channels_last)
+        return _Conv3x3.apply(x, weight, bias, residual)
+    if bias is not None and bias.dim() == 2:
+        y = F.conv2d(x, weight, None, padding=1) + bias[:, :, None, None]
+    else:
+        y = F.conv2d(x, weight, bias, padding=1)
+    return y if residual is None else y + residual

@@ -61,3 +61,35 @@ def test_unet_and_vae_bf16_hip_path_tracks_fp32_torch_path():
     l16.square().sum().backward()
     assert F.cosine_similarity(l32.flatten(), l16.flatten(), dim=0).item() > 0.995
     assert F.cosine_similarity(i32.grad.flatten(), i16.grad.flatten(), dim=0).item() > 0.98
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,per_image_bias,res", [
+    (2, 64, 128, 16, 16, False, False), (1, 128, 128, 32, 40, False, True), (3, 320, 320, 16, 16, True, True),
+    (2, 192, 64, 9, 13, True, False), (1, 64, 8, 16, 16, False, False), (2, 640, 320, 8, 8, False, True)])
+def test_conv3x3_mfma_matches_fp32_reference(N, Cin, Cout, H, W, per_image_bias, res):
+    """Asymmetric random data (catches operand / C-layout transposes), halo zero padding, ragged
+    pixel and channel tiles, fused per-image bias and residual; plus the input gradient."""
+    from garmentdreamer_amd.nn_ops import conv3x3, conv3x3_supported
+    g = torch.Generator(DEV).manual_seed(Cin * 7 + Cout)
+    x = torch.randn(N, Cin, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (3 * Cin ** 0.5)).to(torch.bfloat16) \
+        .contiguous(memory_format=torch.channels_last)
+    b = torch.randn((N, Cout) if per_image_bias else (Cout,), device=DEV, generator=g).to(torch.bfloat16)
+    r = torch.randn(N, Cout, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    assert conv3x3_supported(x, w)
+    xg = x.clone().requires_grad_(True)
+    y = conv3x3(xg, w, b, r)
+    xr = x.float().requires_grad_(True)
+    yr = F.conv2d(xr, w.float(), None, padding=1) + (b.float()[:, :, None, None] if per_image_bias else b.float()[None, :, None, None])
+    if res:
+        yr = yr + r.float()
+    assert y.shape == yr.shape and y.dtype == torch.bfloat16
+    err = (y.float() - yr).abs().max().item()
+    assert err <= 1.5e-2 * yr.abs().max().item() + 1e-2, err
+    assert F.cosine_similarity(y.float().flatten(), yr.flatten(), dim=0).item() > 0.9999
+    gy = torch.randn(y.shape, device=DEV, generator=g).to(torch.bfloat16)
+    y.backward(gy)
+    yr.backward(gy.float())
+    gerr = (xg.grad.float() - xr.grad).abs().max().item()
+    assert gerr <= 2e-2 * xr.grad.abs().max().item() + 1e-2, gerr
+    assert F.cosine_similarity(xg.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.9995

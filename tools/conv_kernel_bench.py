@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""Own MFMA conv3x3 vs MIOpen on the dominant shapes.  python tools/conv_kernel_bench.py"""
+import sys
+import time
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, ".")
+from garmentdreamer_amd.nn_ops import conv3x3
+
+SHAPES = [(8, 128, 128, 512), (8, 256, 256, 256), (8, 512, 512, 128), (8, 512, 512, 64), (8, 128, 256, 256),
+          (16, 320, 320, 64), (16, 640, 640, 32), (16, 1280, 1280, 16), (16, 1280, 1280, 8), (16, 640, 320, 64),
+          (16, 960, 320, 64), (16, 2560, 1280, 16), (16, 1920, 640, 32)]
+
+
+def timeit(fn, n=10):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+for (N, ci, co, hw) in SHAPES:
+    x = torch.randn(N, ci, hw, hw, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(co, ci, 3, 3, device="cuda") / (3 * ci ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, device="cuda").to(torch.bfloat16)
+    fl = 2.0 * N * hw * hw * co * ci * 9
+    with torch.no_grad():
+        t_own = timeit(lambda: conv3x3(x, w, b))
+        t_mio = timeit(lambda: F.conv2d(x, w, b, padding=1))
+        err = (conv3x3(x, w, b).float() - F.conv2d(x, w, b, padding=1).float()).abs().max().item()
+    print(f"N{N} {ci:4d}->{co:4d} @{hw:3d}: own {t_own*1e6:8.1f} us {fl/t_own/1e12:7.1f} TF/s | miopen {t_mio*1e6:8.1f} us "
+          f"{fl/t_mio/1e12:7.1f} TF/s | speedup {t_mio/t_own:5.2f} | maxdiff {err:.3f}")
