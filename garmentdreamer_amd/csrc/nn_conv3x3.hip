@@ -29,6 +29,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <vector>
+
 #include "../../include/gd_nn.h"
 
 namespace {
@@ -212,6 +215,23 @@ __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint
 
 uint16_t* g_zeros[16] = {nullptr};
 
+// optional event timing of the conv kernel (bench.py's roofline line)
+struct ConvProf {
+    std::mutex mu;
+    bool on = false;
+    struct Rec { hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms = 0, total_flops = 0;
+    int64_t launches = 0;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
+} g_cprof;
+
 thread_local char g_err[256] = "";
 int fail(int code, const char* msg)
 {
@@ -247,11 +267,59 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
                                   2 * kStageBytes);
         attr_set[dev] = true;
     }
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (g_cprof.on) {
+        std::lock_guard<std::mutex> lk(g_cprof.mu);
+        ea = g_cprof.get(); eb = g_cprof.get();
+        if (ea && eb) (void)hipEventRecord(ea, s);
+    }
     hipLaunchKernelGGL(conv3x3_nhwc_bf16_kernel, dim3(nwg), dim3(256), 2 * kStageBytes, s, (const uint16_t*)x,
                        (const uint16_t*)weight, (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual,
                        (uint16_t*)y, N, H, W, Cin, Cout, g_zeros[dev], tiles_n, nwg);
+    if (ea && eb) {
+        (void)hipEventRecord(eb, s);
+        std::lock_guard<std::mutex> lk(g_cprof.mu);
+        g_cprof.pending.push_back({ea, eb});
+        g_cprof.total_flops += 2.0 * (double)M * Cout * 9.0 * Cin;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_conv_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_cprof.mu);
+    g_cprof.on = on != 0;
+    return GD_NN_OK;
+}
+
+int gd_nn_conv_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_cprof.mu);
+    g_cprof.total_ms = g_cprof.total_flops = 0;
+    g_cprof.launches = 0;
+    return GD_NN_OK;
+}
+
+/* Waits for the recorded events; returns summed kernel time, launches and algorithmic FLOPs
+ * (2 * N*H*W * Cout * 9*Cin per launch) since the last reset. */
+int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_flops)
+{
+    std::lock_guard<std::mutex> lk(g_cprof.mu);
+    for (auto& r : g_cprof.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            g_cprof.total_ms += ms;
+            g_cprof.launches += 1;
+        }
+        g_cprof.pool.push_back(r.a);
+        g_cprof.pool.push_back(r.b);
+    }
+    g_cprof.pending.clear();
+    if (total_ms) *total_ms = g_cprof.total_ms;
+    if (launches) *launches = g_cprof.launches;
+    if (total_flops) *total_flops = g_cprof.total_flops;
     return GD_NN_OK;
 }
 

@@ -21,6 +21,9 @@ SIGNATURES = {
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
+    "gd_nn_conv_profile_enable": (_i, [_i]),
+    "gd_nn_conv_profile_reset": (_i, []),
+    "gd_nn_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gd_nn_conv_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
 }
@@ -183,3 +186,15 @@ def conv3x3(x, weight, bias=None, residual=None):
     else:
         y = F.conv2d(x, weight, bias, padding=1)
     return y if residual is None else y + residual
+
+
+def conv_profile(enable=None, reset=False):
+    """Toggle / reset / read the conv kernel's event timing: returns (total_ms, launches, total_flops)."""
+    L = lib()
+    if reset:
+        L.gd_nn_conv_profile_reset()
+    if enable is not None:
+        L.gd_nn_conv_profile_enable(int(enable))
+    ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+    L.gd_nn_conv_profile_read(C.byref(ms), C.byref(n), C.byref(fl))
+    return ms.value, n.value, fl.value

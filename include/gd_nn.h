@@ -53,6 +53,11 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
  * input gradient dx = conv3x3(dy, flipped) (weights are frozen in the guidance; no wgrad). */
 int gd_nn_conv3x3_flip_weights(void* stream, const void* weight, void* flipped, int Cout, int Cin);
 
+/* Event timing of the conv kernel for bench.py's roofline object (off by default). */
+int gd_nn_conv_profile_enable(int on);
+int gd_nn_conv_profile_reset(void);
+int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_flops);
+
 const char* gd_nn_conv_last_error(void);
 const char* gd_nn_last_error(void);
 
