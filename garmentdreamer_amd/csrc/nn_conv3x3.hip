@@ -40,10 +40,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int BM = 128;   // pixels per tile
-constexpr int BN = 128;   // output channels per tile
 constexpr int BK = 64;    // channels of one tap per K-step (128-byte rows)
-constexpr int kStageBytes = (BM + BN) * BK * 2;  // 32 KiB
 
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 __device__ __forceinline__ uint16_t f2bf(float f)
@@ -59,12 +56,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// bias_img_stride: 0 -> bias[co]; Cout -> bias[n][co] (time-embedding projection folded in).
-__global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
+// byte offset of logical (row, 16-B chunk j) inside a swizzled [rows][64] bf16 tile image
+__device__ __forceinline__ int swz(int row, int j)
+{
+    return (row >> 1) * 256 + (((((row & 1) << 3) | j) ^ ((row >> 1) & 15)) << 4);
+}
+
+// Tile = BN output channels x BM pixels, WN x WM waves, each wave (BN/WN) x (BM/WM) built from
+// 32x32x16 MFMAs.  bias_img_stride: 0 -> bias[co]; Cout -> bias[n][co].
+template <int BN, int BM, int WN, int WM>
+__global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
     int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, int H, int W,
     int Cin, int Cout, const uint16_t* __restrict__ zeros, int tiles_n, int nwg)
 {
+    constexpr int THREADS = 64 * WN * WM;
+    constexpr int NA = BM * 8 / THREADS;      // 16-B chunks of the pixel tile per thread per K-step
+    constexpr int NB = BN * 8 / THREADS;      // ... of the weight tile
+    constexpr int FA = BN / WN / 32;          // MFMA tiles per wave along channels
+    constexpr int FB = BM / WM / 32;          // ... along pixels
+    constexpr int kStage = (BM + BN) * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order: consecutive logical tiles (same pixel tile, different Cout tile, then
@@ -76,18 +87,22 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
     const int HW = H * W;
     const int64_t M = (int64_t)Nimg * HW;
 
-    // ---- per-thread load descriptors: 4 pixel rows + 4 weight rows, one 16-B chunk each ----
-    const int sp = tid & 7;          // stored chunk position inside the 128-B row
-    const int r_lo = tid >> 3;       // row 0..31 (+32*i)
-    const uint16_t* a_src[4];        // pixel row base (tap 0,0; channel 0), or nullptr if m >= M
-    int a_y[4], a_x[4], a_j[4];
-    const uint16_t* b_src[4];
-    int b_j[4];
+    // LDS image: 256-byte lines = two consecutive 128-byte tile rows = 16 slots of 16 B; logical
+    // slot c = (row&1)*8 + chunk is stored at slot c ^ (line & 15): a 64-lane fragment read then
+    // touches 16 distinct slots per 16-lane service group (conflict free).  The image is written
+    // lane-linearly by global_load_lds, so the permutation is applied to WHICH (row, chunk) a lane
+    // fetches.
+    const uint16_t* a_src[NA];
+    int a_y[NA], a_x[NA], a_j[NA];
+    const uint16_t* b_src[NB];
+    int b_j[NB];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int r = r_lo + 32 * i;
+    for (int i = 0; i < NA; i++) {
+        const int q = tid + THREADS * i;
+        const int line = q >> 4, c = (q & 15) ^ (line & 15);
+        const int r = 2 * line + (c >> 3);
         const int64_t m = (int64_t)m0 + r;
-        a_j[i] = (sp ^ (r & 7)) * 8;
+        a_j[i] = (c & 7) * 8;
         if (m < M) {
             const int nimg = (int)(m / HW);
             const int rem = (int)(m - (int64_t)nimg * HW);
@@ -97,8 +112,14 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
         } else {
             a_y[i] = -100000; a_x[i] = 0; a_src[i] = zeros;
         }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const int q = tid + THREADS * i;
+        const int line = q >> 4, c = (q & 15) ^ (line & 15);
+        const int r = 2 * line + (c >> 3);
         const int co = n0 + r;
-        b_j[i] = a_j[i];
+        b_j[i] = (c & 7) * 8;
         b_src[i] = co < Cout ? wt + (size_t)co * 9 * Cin : nullptr;
     }
     const int kc = Cin / BK;         // K-steps per tap
@@ -107,32 +128,32 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
     auto issue = [&](int s, int buf) {
         const int tap = s / kc, c0 = (s - tap * kc) * BK;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        char* sA = smem + buf * kStageBytes;                 // pixel tile  [128][64] bf16
-        char* sB = sA + BM * BK * 2;                         // weight tile [128][64] bf16
+        char* sA = smem + buf * kStage;                      // pixel tile  [BM][64] bf16
+        char* sB = sA + BM * BK * 2;                         // weight tile [BN][64] bf16
         const int tap_off = (dy * W + dx) * Cin + c0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NA; i++) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
             const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
             const uint16_t* src = ok ? a_src[i] + tap_off + a_j[i] : zeros;
-            glds16(src, sA + (wave * 64 + 256 * i) * 16);
+            glds16(src, sA + (wave * 64 + THREADS * i) * 16);
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NB; i++) {
             const uint16_t* src = b_src[i] ? b_src[i] + tap * Cin + c0 + b_j[i] : zeros;
-            glds16(src, sB + (wave * 64 + 256 * i) * 16);
+            glds16(src, sB + (wave * 64 + THREADS * i) * 16);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[FA][FB];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < FA; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < FB; b++)
 #pragma unroll
             for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
 
-    const int wc = wave & 1, wp = wave >> 1;   // wave's 64-channel / 64-pixel quadrant
+    const int wc = wave % WN, wp = wave / WN;   // wave's channel / pixel block
     const int frow = lane & 31, fk = lane >> 5;
 
     issue(0, 0);
@@ -141,42 +162,36 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // stage `buf` landed for everyone; stage buf^1 free
         if (s + 1 < nsteps) issue(s + 1, buf ^ 1);
-        const char* sA = smem + buf * kStageBytes;
+        const char* sA = smem + buf * kStage;
         const char* sB = sA + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-            bf16x8_t wf[2], pf[2];
+            bf16x8_t wf[FA], pf[FB];
             const int j = kk * 2 + fk;
 #pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const int row = wc * 64 + a * 32 + frow;
-                wf[a] = *(const bf16x8_t*)(sB + (row * 8 + (j ^ (row & 7))) * 16);
-            }
+            for (int a = 0; a < FA; a++) wf[a] = *(const bf16x8_t*)(sB + swz(wc * (BN / WN) + a * 32 + frow, j));
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const int row = wp * 64 + b * 32 + frow;
-                pf[b] = *(const bf16x8_t*)(sA + (row * 8 + (j ^ (row & 7))) * 16);
-            }
+            for (int b = 0; b < FB; b++) pf[b] = *(const bf16x8_t*)(sA + swz(wp * (BM / WM) + b * 32 + frow, j));
 #pragma unroll
-            for (int a = 0; a < 2; a++)
+            for (int a = 0; a < FA; a++)
 #pragma unroll
-                for (int b = 0; b < 2; b++)
+                for (int b = 0; b < FB; b++)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
         }
     }
 
     // ---- epilogue: D[i = channel][j = pixel]; lane: pixel column lane&31, rows (reg&3)+8*(reg>>2)+4*(lane>>5)
 #pragma unroll
-    for (int b = 0; b < 2; b++) {
-        const int64_t m = (int64_t)m0 + wp * 64 + b * 32 + (lane & 31);
+    for (int b = 0; b < FB; b++) {
+        const int64_t m = (int64_t)m0 + wp * (BM / WM) + b * 32 + (lane & 31);
         if (m >= M) continue;
         const int nimg = (int)(m / HW);
         const uint16_t* bias_n = bias ? bias + (size_t)nimg * bias_img_stride : nullptr;
 #pragma unroll
-        for (int a = 0; a < 2; a++) {
+        for (int a = 0; a < FA; a++) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int co = n0 + wc * 64 + a * 32 + 8 * q + 4 * fk;
+                const int co = n0 + wc * (BN / WN) + a * 32 + 8 * q + 4 * fk;
                 if (co >= Cout) continue;
                 float v[4];
 #pragma unroll
@@ -214,6 +229,7 @@ __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint
 }
 
 uint16_t* g_zeros[16] = {nullptr};
+int g_force_variant = -1;  // tuning hook: 0 = 128x128, 1 = 128x256, 2 = 256x256, -1 = heuristic
 
 // optional event timing of the conv kernel (bench.py's roofline line)
 struct ConvProf {
@@ -259,13 +275,21 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
         if (hipMemset(g_zeros[dev], 0, 256) != hipSuccess) return fail(GD_NN_ERR_HIP, "hipMemset failed");
     }
     const int64_t M = (int64_t)N * H * W;
-    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (Cout + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    static bool attr_set[16] = {false};
-    if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_nhwc_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * kStageBytes);
-        attr_set[dev] = true;
+    // tile choice: the 256x256 / 8-wave tile has twice the MFMA work per byte staged through LDS;
+    // use it when Cout fills it and there are enough tiles for 256 CUs, else 128 channels x 256
+    // pixels, else the 128x128 / 4-wave tile.
+    int variant = g_force_variant;
+    if (variant < 0) {
+        // cost model: (waves of workgroups over the resident slots) x (tile area / per-slot rate); rates are the
+        // measured whole-chip TFLOP/s of each variant on large shapes (tools/conv_kernel_bench.py)
+        const int bn[3] = {128, 128, 256}, bm[3] = {128, 256, 256}, slots[3] = {512, 256, 256};
+        const double eff[3] = {650.0, 760.0, 1000.0};
+        double best = 1e300;
+        for (int v = 0; v < 3; v++) {
+            const int64_t T = ((M + bm[v] - 1) / bm[v]) * ((Cout + bn[v] - 1) / bn[v]);
+            const double t = (double)((T + slots[v] - 1) / slots[v]) * bn[v] * bm[v] * slots[v] / eff[v];
+            if (t < best) { best = t; variant = v; }
+        }
     }
     hipEvent_t ea = nullptr, eb = nullptr;
     if (g_cprof.on) {
@@ -273,9 +297,26 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
         ea = g_cprof.get(); eb = g_cprof.get();
         if (ea && eb) (void)hipEventRecord(ea, s);
     }
-    hipLaunchKernelGGL(conv3x3_nhwc_bf16_kernel, dim3(nwg), dim3(256), 2 * kStageBytes, s, (const uint16_t*)x,
-                       (const uint16_t*)weight, (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual,
-                       (uint16_t*)y, N, H, W, Cin, Cout, g_zeros[dev], tiles_n, nwg);
+#define GD_LAUNCH(BN_, BM_, WN_, WM_)                                                                              \
+    do {                                                                                                           \
+        auto kern = conv3x3_nhwc_bf16_kernel<BN_, BM_, WN_, WM_>;                                                  \
+        constexpr int lds = 2 * (BN_ + BM_) * BK * 2;                                                              \
+        static bool attr_set[16] = {false};                                                                        \
+        if (!attr_set[dev]) {                                                                                      \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);         \
+            attr_set[dev] = true;                                                                                  \
+        }                                                                                                          \
+        const int tiles_m = (int)((M + BM_ - 1) / BM_), tiles_n = (Cout + BN_ - 1) / BN_;                          \
+        const int nwg = tiles_m * tiles_n;                                                                         \
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WN_ * WM_), lds, s, (const uint16_t*)x,                      \
+                           (const uint16_t*)weight, (const uint16_t*)bias, bias_img_stride,                        \
+                           (const uint16_t*)residual, (uint16_t*)y, N, H, W, Cin, Cout, g_zeros[dev], tiles_n,     \
+                           nwg);                                                                                   \
+    } while (0)
+    if (variant == 2) GD_LAUNCH(256, 256, 2, 4);
+    else if (variant == 1) GD_LAUNCH(128, 256, 2, 4);
+    else GD_LAUNCH(128, 128, 2, 2);
+#undef GD_LAUNCH
     if (ea && eb) {
         (void)hipEventRecord(eb, s);
         std::lock_guard<std::mutex> lk(g_cprof.mu);
@@ -284,6 +325,12 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_conv_force_variant(int v)
+{
+    g_force_variant = v;
     return GD_NN_OK;
 }
 

@@ -21,6 +21,7 @@ SIGNATURES = {
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
+    "gd_nn_conv_force_variant": (_i, [_i]),
     "gd_nn_conv_profile_enable": (_i, [_i]),
     "gd_nn_conv_profile_reset": (_i, []),
     "gd_nn_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -53,6 +53,10 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
  * input gradient dx = conv3x3(dy, flipped) (weights are frozen in the guidance; no wgrad). */
 int gd_nn_conv3x3_flip_weights(void* stream, const void* weight, void* flipped, int Cout, int Cin);
 
+/* Tuning hook: force the tile variant (0 = 128x128/4 waves, 1 = 128 ch x 256 px/8 waves,
+ * 2 = 256x256/8 waves, -1 = built-in heuristic). */
+int gd_nn_conv_force_variant(int v);
+
 /* Event timing of the conv kernel for bench.py's roofline object (off by default). */
 int gd_nn_conv_profile_enable(int on);
 int gd_nn_conv_profile_reset(void);

@@ -27,9 +27,16 @@ for (N, ci, co, hw) in SHAPES:
     w = (torch.randn(co, ci, 3, 3, device="cuda") / (3 * ci ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     b = torch.randn(co, device="cuda").to(torch.bfloat16)
     fl = 2.0 * N * hw * hw * co * ci * 9
+    from garmentdreamer_amd import nn_ops
+    L = nn_ops.lib()
     with torch.no_grad():
-        t_own = timeit(lambda: conv3x3(x, w, b))
+        ref = F.conv2d(x, w, b, padding=1).float()
+        res = []
+        for v in (0, 1, 2, -1):
+            L.gd_nn_conv_force_variant(v)
+            t = timeit(lambda: conv3x3(x, w, b))
+            err = (conv3x3(x, w, b).float() - ref).abs().max().item()
+            res.append(f"v{v}: {t*1e6:7.1f}us {fl/t/1e12:6.1f}TF e{err:.2f}")
+        L.gd_nn_conv_force_variant(-1)
         t_mio = timeit(lambda: F.conv2d(x, w, b, padding=1))
-        err = (conv3x3(x, w, b).float() - F.conv2d(x, w, b, padding=1).float()).abs().max().item()
-    print(f"N{N} {ci:4d}->{co:4d} @{hw:3d}: own {t_own*1e6:8.1f} us {fl/t_own/1e12:7.1f} TF/s | miopen {t_mio*1e6:8.1f} us "
-          f"{fl/t_mio/1e12:7.1f} TF/s | speedup {t_mio/t_own:5.2f} | maxdiff {err:.3f}")
+    print(f"N{N} {ci:4d}->{co:4d} @{hw:3d}: " + " | ".join(res) + f" | miopen {t_mio*1e6:7.1f}us {fl/t_mio/1e12:6.1f}TF")
