@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgd_raster.so")
+# GD_RASTER_LIB: optional override for A/B timing of experimental builds (tools/, never set in tests)
+_LIB_PATH = os.environ.get("GD_RASTER_LIB") or os.path.join(_HERE, "libgd_raster.so")
 _lib = None
 
 GD_MAX_VIEWS = 16

@@ -25,7 +25,13 @@
 // Numerics: same operation order as the reference per pixel; FMA contraction is allowed here
 // (pixel / gradient parity is a tolerance), expf is the accurate libm form so that
 // the 1/255 and 1e-4 thresholds (and therefore n_contrib) agree with the oracle.
+#include <stdlib.h>
+
 #include "raster_common.h"
+
+#ifndef GD_ABLATE
+#define GD_ABLATE 0   // 1: skip the cross-lane reduction + LDS atomics (timing ablation only; wrong results)
+#endif
 
 namespace gd {
 
@@ -150,18 +156,37 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
 
 constexpr int kAcc = 10;  // colour rgb, depth, mean2D xy, conic x/y/w, opacity
 
-__global__ __launch_bounds__(kTilePix) void render_backward_kernel(
+// Per-pixel state of the reverse walk (backward.cu:461-487).
+struct PixState {
+    float T, T_final, last_alpha, last_c0, last_c1, last_c2, last_depth;
+    float accum_rec0, accum_rec1, accum_rec2, accum_depth_rec, accum_alpha_rec;
+    float dLp0, dLp1, dLp2, dLpd, dLa, bg_dot;
+    float pixf_y;
+    uint32_t last_contributor;
+};
+
+// PPL = pixels per lane.  A 16x16 tile is handled by 256/PPL threads (4/PPL wave64s); lane l owns
+// column l&15 and rows (l>>4) + 4*k' ... so that the per-entry cross-lane reduction (the dominant
+// cost at PPL = 1: ablating it halves the kernel time) is paid once per PPL pixels: the lane first
+// sums its own pixels' partials in registers.  PPL = 4 -> one wave per tile, no cross-wave
+// combine; used when the launch has enough tiles to fill the chip (batched multi-view).
+template <int PPL>
+__global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
     int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
     const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
     const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ acc)
 {
-    __shared__ float2 s_xy[kTilePix];
-    __shared__ float4 s_co[kTilePix];
-    __shared__ float4 s_fd[kTilePix];
-    __shared__ uint32_t s_id[kTilePix];
-    __shared__ float s_acc[kTilePix * kAcc];
+    constexpr int THREADS = kTilePix / PPL;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int ROWS_PER_PASS = THREADS / 16;   // tile rows covered by one pixel slot of all threads
+    constexpr int ROUND = THREADS;                // list entries staged per round (keeps LDS per wave constant)
+    __shared__ float2 s_xy[ROUND];
+    __shared__ float4 s_co[ROUND];
+    __shared__ float4 s_fd[ROUND];
+    __shared__ uint32_t s_id[ROUND];
+    __shared__ float s_acc[ROUND * kAcc];
     __shared__ uint32_t s_wmax[4];
 
     const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
@@ -170,123 +195,153 @@ __global__ __launch_bounds__(kTilePix) void render_backward_kernel(
     const uint32_t lt = tile - view * tpv;
     const uint32_t ty = lt / gx, tx = lt - ty * gx;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + (tid >> 4);
-    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const uint32_t px = tx * kTile + (tid & 15u);
+    const float pixf_x = (float)px;
     const size_t HW = (size_t)H * W;
-    const size_t pix_id = (size_t)view * HW + (size_t)W * py + px;
-    const float pixf_x = (float)px, pixf_y = (float)py;
 
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
-
-    const float T_final = inside ? (1 - alphas[pix_id]) : 0;
-    float T = T_final;
-    const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0;
-
-    float accum_rec0 = 0, accum_rec1 = 0, accum_rec2 = 0, accum_depth_rec = 0, accum_alpha_rec = 0;
-    float dLp0 = 0, dLp1 = 0, dLp2 = 0, dLpd = 0, dLa = 0;
-    if (inside) {
-        const float* dp = dL_dpixels + (size_t)view * 3 * HW + ((size_t)W * py + px);
-        dLp0 = dp[0]; dLp1 = dp[HW]; dLp2 = dp[2 * HW];
-        dLpd = dL_dpixel_depths[pix_id];
-        dLa = dL_dalphas[pix_id];
-    }
-    float last_alpha = 0, last_c0 = 0, last_c1 = 0, last_c2 = 0, last_depth = 0;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-    const float bg_dot_dpixel = bg_color[0] * dLp0 + bg_color[1] * dLp1 + bg_color[2] * dLp2;
+    const float bg0 = bg_color[0], bg1 = bg_color[1], bg2 = bg_color[2];
+
+    PixState ps[PPL];
+    uint32_t lane_max = 0;
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        const uint32_t py = ty * kTile + (tid >> 4) + q * ROWS_PER_PASS;
+        const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+        const size_t pix_id = (size_t)view * HW + (size_t)W * py + px;
+        PixState& p = ps[q];
+        p.pixf_y = (float)py;
+        p.T_final = inside ? (1 - alphas[pix_id]) : 0;
+        p.T = p.T_final;
+        p.last_contributor = inside ? n_contrib[pix_id] : 0;
+        p.dLp0 = p.dLp1 = p.dLp2 = p.dLpd = p.dLa = 0;
+        if (inside) {
+            const float* dp = dL_dpixels + (size_t)view * 3 * HW + ((size_t)W * py + px);
+            p.dLp0 = dp[0]; p.dLp1 = dp[HW]; p.dLp2 = dp[2 * HW];
+            p.dLpd = dL_dpixel_depths[pix_id];
+            p.dLa = dL_dalphas[pix_id];
+        }
+        p.bg_dot = bg0 * p.dLp0 + bg1 * p.dLp1 + bg2 * p.dLp2;
+        p.last_alpha = p.last_c0 = p.last_c1 = p.last_c2 = p.last_depth = 0;
+        p.accum_rec0 = p.accum_rec1 = p.accum_rec2 = p.accum_depth_rec = p.accum_alpha_rec = 0;
+        lane_max = max(lane_max, p.last_contributor);
+    }
 
     // Entries whose ordinal is >= every pixel's last contributor are dead for the whole wave /
     // workgroup: skip them (the reference walks them and `continue`s per pixel, backward.cu:517-519).
-    const uint32_t wmax = wave_max_u32(last_contributor);
+    const uint32_t wmax = wave_max_u32(lane_max);
     if (lane == 0) s_wmax[wave] = wmax;
-    for (int i = tid; i < kTilePix * kAcc; i += kTilePix) s_acc[i] = 0.f;
+    for (int i = tid; i < ROUND * kAcc; i += THREADS) s_acc[i] = 0.f;
     __syncthreads();
-    const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    uint32_t bmax = s_wmax[0];
+#pragma unroll
+    for (int w = 1; w < WAVES; w++) bmax = max(bmax, s_wmax[w]);
     if (bmax == 0) return;
     const int first_p_block = total - (int)bmax;  // first reverse position any pixel uses
     const int first_p_wave = total - (int)wmax;
-    const int rounds = (total + kTilePix - 1) / kTilePix;
+    const int rounds = (total + ROUND - 1) / ROUND;
 
-    for (int i = first_p_block / kTilePix; i < rounds; i++) {
-        const int round_base = i * kTilePix;
-        const int n = min(kTilePix, total - round_base);
+    for (int i = first_p_block / ROUND; i < rounds; i++) {
+        const int round_base = i * ROUND;
+        const int n = min(ROUND, total - round_base);
         __syncthreads();  // previous round's flush is complete
-        if ((int)tid < n) {
-            const uint32_t id = point_list[range.y - (uint32_t)(round_base + (int)tid) - 1];
-            s_id[tid] = id;
-            s_xy[tid] = means2D[id];
-            s_co[tid] = conic_opacity[id];
-            s_fd[tid] = rgbd[id];
+        for (int e = tid; e < n; e += THREADS) {
+            const uint32_t id = point_list[range.y - (uint32_t)(round_base + e) - 1];
+            s_id[e] = id;
+            s_xy[e] = means2D[id];
+            s_co[e] = conic_opacity[id];
+            s_fd[e] = rgbd[id];
         }
         __syncthreads();
         if (wmax != 0) {
             for (int j = max(0, first_p_wave - round_base); j < n; j++) {
                 const uint32_t ordinal = (uint32_t)(total - 1 - (round_base + j));
                 const float2 xy = s_xy[j];
-                const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
                 const float4 co = s_co[j];
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                const float G = expf(power);
-                const float alpha = fminf(0.99f, co.w * G);
-                const bool valid = (ordinal < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (!__any(valid)) continue;
+                const float dx = xy.x - pixf_x;
                 float v[kAcc];
 #pragma unroll
                 for (int k = 0; k < kAcc; k++) v[k] = 0.f;
-                if (valid) {
-                    const float inv = 1.f / (1.f - alpha);
-                    T = T * inv;
-                    const float dchannel_dcolor = alpha * T;
-                    const float4 fd = s_fd[j];
-                    float dL_dopa = 0.0f;
-                    accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0;
-                    accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1;
-                    accum_rec2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2;
-                    last_c0 = fd.x; last_c1 = fd.y; last_c2 = fd.z;
-                    dL_dopa += (fd.x - accum_rec0) * dLp0;
-                    dL_dopa += (fd.y - accum_rec1) * dLp1;
-                    dL_dopa += (fd.z - accum_rec2) * dLp2;
-                    v[0] = dchannel_dcolor * dLp0;
-                    v[1] = dchannel_dcolor * dLp1;
-                    v[2] = dchannel_dcolor * dLp2;
-                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                    last_depth = fd.w;
-                    dL_dopa += (fd.w - accum_depth_rec) * dLpd;
-                    v[3] = dchannel_dcolor * dLpd;
-                    accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
-                    dL_dopa += (1 - accum_alpha_rec) * dLa;
-                    dL_dopa *= T;
-                    last_alpha = alpha;
-                    dL_dopa += (-T_final * inv) * bg_dot_dpixel;
-                    const float dL_dG = co.w * dL_dopa;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                    const float dG_ddely = -gdy * co.z - gdx * co.y;
-                    v[4] = dL_dG * dG_ddelx * ddelx_dx;
-                    v[5] = dL_dG * dG_ddely * ddely_dy;
-                    v[6] = -0.5f * gdx * dx * dL_dG;
-                    v[7] = -0.5f * gdx * dy * dL_dG;
-                    v[8] = -0.5f * gdy * dy * dL_dG;
-                    v[9] = G * dL_dopa;
+                bool any_valid = false;
+#pragma unroll
+                for (int q = 0; q < PPL; q++) {
+                    PixState& p = ps[q];
+                    const float dy = xy.y - p.pixf_y;
+                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                    // v_exp_f32 path: |power| <= 5.6 wherever the pair can contribute, relative error ~3e-7 --
+                    // far inside the gradient tolerance; the forward pass (which fixes n_contrib) keeps libm expf
+                    const float G = __expf(power);
+                    const float alpha = fminf(0.99f, co.w * G);
+                    const bool valid = (ordinal < p.last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                    if (valid) {
+                        any_valid = true;
+                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // shared by T/(1-a), T_final/(1-a)
+                        p.T = p.T * inv;
+                        const float dchannel_dcolor = alpha * p.T;
+                        const float4 fd = s_fd[j];
+                        float dL_dopa = 0.0f;
+                        p.accum_rec0 = p.last_alpha * p.last_c0 + (1.f - p.last_alpha) * p.accum_rec0;
+                        p.accum_rec1 = p.last_alpha * p.last_c1 + (1.f - p.last_alpha) * p.accum_rec1;
+                        p.accum_rec2 = p.last_alpha * p.last_c2 + (1.f - p.last_alpha) * p.accum_rec2;
+                        p.last_c0 = fd.x; p.last_c1 = fd.y; p.last_c2 = fd.z;
+                        dL_dopa += (fd.x - p.accum_rec0) * p.dLp0;
+                        dL_dopa += (fd.y - p.accum_rec1) * p.dLp1;
+                        dL_dopa += (fd.z - p.accum_rec2) * p.dLp2;
+                        v[0] += dchannel_dcolor * p.dLp0;
+                        v[1] += dchannel_dcolor * p.dLp1;
+                        v[2] += dchannel_dcolor * p.dLp2;
+                        p.accum_depth_rec = p.last_alpha * p.last_depth + (1.f - p.last_alpha) * p.accum_depth_rec;
+                        p.last_depth = fd.w;
+                        dL_dopa += (fd.w - p.accum_depth_rec) * p.dLpd;
+                        v[3] += dchannel_dcolor * p.dLpd;
+                        p.accum_alpha_rec = p.last_alpha + (1.f - p.last_alpha) * p.accum_alpha_rec;
+                        dL_dopa += (1 - p.accum_alpha_rec) * p.dLa;
+                        dL_dopa *= p.T;
+                        p.last_alpha = alpha;
+                        dL_dopa += (-p.T_final * inv) * p.bg_dot;
+                        const float dL_dG = co.w * dL_dopa;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                        const float dG_ddely = -gdy * co.z - gdx * co.y;
+                        v[4] += dL_dG * dG_ddelx * ddelx_dx;
+                        v[5] += dL_dG * dG_ddely * ddely_dy;
+                        v[6] += -0.5f * gdx * dx * dL_dG;
+                        v[7] += -0.5f * gdx * dy * dL_dG;
+                        v[8] += -0.5f * gdy * dy * dL_dG;
+                        v[9] += G * dL_dopa;
+                    }
                 }
+                if (!__any(any_valid)) continue;
+#if GD_ABLATE == 1
+#pragma unroll
+                for (int k = 0; k < kAcc; k++) asm volatile("" ::"v"(v[k]));
+#else
 #pragma unroll
                 for (int k = 0; k < kAcc; k++) v[k] = wave_sum_to_lane63(v[k]);
                 if (lane == 63) {
+                    if (WAVES == 1) {
 #pragma unroll
-                    for (int k = 0; k < kAcc; k++) atomicAdd(&s_acc[j * kAcc + k], v[k]);
+                        for (int k = 0; k < kAcc; k++) s_acc[j * kAcc + k] = v[k];   // single writer per tile
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < kAcc; k++) atomicAdd(&s_acc[j * kAcc + k], v[k]);
+                    }
                 }
+#endif
             }
         }
         __syncthreads();
         // flush this round: one global atomic per touched (entry, component)
-        if ((int)tid < n) {
-            float* dst = acc + (size_t)s_id[tid] * kAcc;
+        for (int e = tid; e < n; e += THREADS) {
+            float* dst = acc + (size_t)s_id[e] * kAcc;
 #pragma unroll
             for (int k = 0; k < kAcc; k++) {
-                const float val = s_acc[tid * kAcc + k];
+                const float val = s_acc[e * kAcc + k];
                 if (val != 0.f) {
                     atomicAdd(dst + k, val);
-                    s_acc[tid * kAcc + k] = 0.f;
+                    s_acc[e * kAcc + k] = 0.f;
                 }
             }
         }
@@ -311,9 +366,18 @@ void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int
                             const float* dL_dalphas, float* acc)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
-    hipLaunchKernelGGL(render_backward_kernel, dim3(tiles_total), dim3(kTilePix), 0, s, W, H, (uint32_t)tiles_x,
-                       (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D, g.conic_opacity, g.rgbd, bg,
-                       alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc);
+    // pixels per lane: fewer, fatter lanes amortise the per-entry wave reduction; needs enough tiles to
+    // fill 256 CUs x 4 SIMDs (GD_RASTER_BWD_PPL overrides, for tuning)
+    int ppl = tiles_total >= 4096 ? 4 : (tiles_total >= 2048 ? 2 : 1);
+    if (const char* e = getenv("GD_RASTER_BWD_PPL")) ppl = atoi(e);
+#define GD_BWD(PPL_)                                                                                               \
+    hipLaunchKernelGGL(render_backward_kernel<PPL_>, dim3(tiles_total), dim3(kTilePix / PPL_), 0, s, W, H,         \
+                       (uint32_t)tiles_x, (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D,           \
+                       g.conic_opacity, g.rgbd, bg, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc)
+    if (ppl == 4) GD_BWD(4);
+    else if (ppl == 2) GD_BWD(2);
+    else GD_BWD(1);
+#undef GD_BWD
 }
 
 }  // namespace gd
