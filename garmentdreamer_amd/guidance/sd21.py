@@ -34,7 +34,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..nn_ops import conv3x3, conv3x3_supported, group_norm_silu
+from ..nn_ops import conv1x1, conv3x3, conv3x3_small_cin, conv3x3_supported, group_norm_silu
 
 
 def _gn(norm: nn.GroupNorm, x, silu: bool):
@@ -78,7 +78,7 @@ class ResnetBlock2D(nn.Module):
             image_bias = self.time_emb_proj(F.silu(temb)) + self.conv1.bias
         h = _conv3(self.conv1, _gn(self.norm1, x, True), image_bias=image_bias)
         if self.conv_shortcut is not None:
-            x = self.conv_shortcut(x)
+            x = conv1x1(x, self.conv_shortcut.weight, self.conv_shortcut.bias)
         return _conv3(self.conv2, _gn(self.norm2, h, True), residual=x)
 
 
@@ -326,8 +326,15 @@ class _VAEAttention(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         h = _gn(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
-        q, k, v = self.to_q(h)[:, None], self.to_k(h)[:, None], self.to_v(h)[:, None]
-        o = F.scaled_dot_product_attention(q, k, v)[:, 0]
+        q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
+        if x.is_cuda:
+            # one head of dim 512: three plain GEMMs + a softmax (hipBLASLt) beat the fused kernel, whose
+            # backward for head_dim 512 runs at ~180 TFLOP/s; the [B,N,N] bf16 score matrix (34 MB per
+            # image at N = 4096) is cheap on a 288 GB part
+            p = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * (C ** -0.5), dim=-1)
+            o = torch.bmm(p, v)
+        else:
+            o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
         o = self.to_out[0](o).reshape(B, H, W, C).permute(0, 3, 1, 2)
         return x + o
 
@@ -372,7 +379,7 @@ class Encoder(nn.Module):
         self.conv_out = nn.Conv2d(ch[-1], 2 * latent_channels, 3, padding=1)
 
     def forward(self, x):
-        x = self.conv_in(x.contiguous(memory_format=torch.channels_last))
+        x = conv3x3_small_cin(x.contiguous(memory_format=torch.channels_last), self.conv_in.weight, self.conv_in.bias)
         for b in self.down_blocks:
             x = b(x)
         x = self.mid_block(x)

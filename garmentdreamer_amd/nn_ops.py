@@ -165,6 +165,57 @@ class _Conv3x3(torch.autograd.Function):
         return dx, None, None, (dy if ctx.has_res else None)
 
 
+class _ConvSmallCin(torch.autograd.Function):
+    """First VAE convolution (Cin = 3): forward through torch's conv, input gradient through the MFMA
+    kernel with the flipped weights zero-padded to 4 output channels (the library dgrad for this shape
+    costs 2.7 ms per step on MI355X; this path ~1 ms)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.weight = weight
+        ctx.x_shape = x.shape
+        with torch.no_grad():
+            return F.conv2d(x, weight, bias, padding=1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        w = ctx.weight
+        Cout, Cin = w.shape[0], w.shape[1]
+        f = getattr(w, "_gd_flipped4", None)
+        if f is None or f.device != w.device:
+            f = torch.zeros((4, Cout, 3, 3), dtype=torch.bfloat16, device=w.device).contiguous(
+                memory_format=torch.channels_last)
+            wc = w.contiguous(memory_format=torch.channels_last)
+            with torch.cuda.device(w.device):
+                ret = lib().gd_nn_conv3x3_flip_weights(torch.cuda.current_stream(w.device).cuda_stream, wc.data_ptr(),
+                                                       f.data_ptr(), Cout, Cin)
+            if ret < 0:
+                raise RuntimeError("gd_nn_conv3x3_flip_weights failed")
+            w._gd_flipped4 = f
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx4 = _conv_launch(dy, f, None, None, 4)
+        return dx4[:, :Cin], None, None
+
+
+def conv3x3_small_cin(x, weight, bias):
+    """3x3/s1/p1 convolution with Cin <= 4 (image -> features)."""
+    if (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.shape[1] <= 4
+            and weight.shape[0] % 64 == 0 and not weight.requires_grad):
+        return _ConvSmallCin.apply(x, weight, bias)
+    return F.conv2d(x, weight, bias, padding=1)
+
+
+def conv1x1(x, weight, bias):
+    """1x1 convolution on an NHWC tensor = a plain GEMM over the channel axis (hipBLASLt), no copies:
+    the [N,H,W,C] view of a channels_last tensor is contiguous."""
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        y = F.linear(x.permute(0, 2, 3, 1), weight.flatten(1), bias)
+        return y.permute(0, 3, 1, 2)
+    return F.conv2d(x, weight, bias)
+
+
 def conv3x3_supported(x, weight) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4
             and tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] % 64 == 0 and weight.shape[0] % 4 == 0

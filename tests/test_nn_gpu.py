@@ -93,3 +93,29 @@ def test_conv3x3_mfma_matches_fp32_reference(N, Cin, Cout, H, W, per_image_bias,
     gerr = (xg.grad.float() - xr.grad).abs().max().item()
     assert gerr <= 2e-2 * xr.grad.abs().max().item() + 1e-2, gerr
     assert F.cosine_similarity(xg.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.9995
+
+
+def test_first_conv_small_cin_and_conv1x1_match_torch():
+    from garmentdreamer_amd.nn_ops import conv1x1, conv3x3_small_cin
+    g = torch.Generator(DEV).manual_seed(5)
+    x = torch.rand(2, 3, 40, 56, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 3, 3, 3, device=DEV, generator=g) / 5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(128, device=DEV, generator=g).to(torch.bfloat16)
+    xg = x.clone().requires_grad_(True)
+    y = conv3x3_small_cin(xg, w, b)
+    xr = x.float().requires_grad_(True)
+    yr = F.conv2d(xr, w.float(), b.float(), padding=1)
+    assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item()
+    gy = torch.randn(y.shape, device=DEV, generator=g).to(torch.bfloat16)
+    y.backward(gy)
+    yr.backward(gy.float())
+    assert xg.grad.shape == x.shape
+    assert F.cosine_similarity(xg.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.9995
+    assert (xg.grad.float() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item() + 1e-2
+    x1 = torch.randn(2, 256, 12, 20, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn(128, 256, 1, 1, device=DEV, generator=g) / 16).to(torch.bfloat16)
+    b1 = torch.randn(128, device=DEV, generator=g).to(torch.bfloat16)
+    y1 = conv1x1(x1, w1, b1)
+    r1 = F.conv2d(x1.float(), w1.float(), b1.float())
+    assert y1.shape == r1.shape and y1.is_contiguous(memory_format=torch.channels_last)
+    assert (y1.float() - r1).abs().max().item() <= 2e-2 * r1.abs().max().item()
