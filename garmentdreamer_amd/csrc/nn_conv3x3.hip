@@ -50,6 +50,15 @@ __device__ __forceinline__ uint16_t f2bf(float f)
     return (uint16_t)(u >> 16);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> packed bf16 (round to nearest even) in ONE instruction: v_cvt_pk_bf16_f32 (gfx950)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
+{
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -61,6 +70,18 @@ __device__ __forceinline__ int swz(int row, int j)
 {
     return (row >> 1) * 256 + (((((row & 1) << 3) | j) ^ ((row >> 1) & 15)) << 4);
 }
+
+__device__ __forceinline__ void bload_lds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff,
+                                            char* lds_wave_base)
+{
+    // buffer_load_dwordx4 ... offen lds: 16 B per lane straight into LDS (wave-uniform base +
+    // lane*16); a lane whose voffset is beyond num_records gets ZEROS -- that is the halo padding
+    // and the ragged-tile masking, with no branch and no zero page.
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff,
+                                             soff, 0, 0);
+}
+
+constexpr uint32_t kOOB = 0x80000000u;   // voffset that fails the buffer range check (tensors are < 2 GiB)
 
 // Tile = BN output channels x BM pixels, WN x WM waves, each wave (BN/WN) x (BM/WM) built from
 // 32x32x16 MFMAs.  bias_img_stride: 0 -> bias[co]; Cout -> bias[n][co].
@@ -77,7 +98,9 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     constexpr int FB = BM / WM / 32;          // ... along pixels
     constexpr int kStage = (BM + BN) * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    (void)zeros;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware tile order: consecutive logical tiles (same pixel tile, different Cout tile, then
     // the next pixel tile) stay on one XCD's L2.
     int bid = blockIdx.x;
@@ -87,30 +110,38 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     const int HW = H * W;
     const int64_t M = (int64_t)Nimg * HW;
 
+    // Buffer descriptors.  The activation descriptor's base is moved back by one image row + one
+    // pixel so that per-lane voffsets (pixel m, chunk) and the wave-uniform soffset (tap, channel
+    // step) are both non-negative; valid lanes never address bytes before `in`.
+    const uint32_t row_bytes = (uint32_t)Cin * 2u;
+    const uint32_t back = ((uint32_t)W + 1u) * row_bytes;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)in - back), 0, (int)((uint32_t)(M * row_bytes) + back), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)wt, 0, (int)((uint32_t)Cout * 9u * row_bytes), 0x00020000);
+
     // LDS image: 256-byte lines = two consecutive 128-byte tile rows = 16 slots of 16 B; logical
     // slot c = (row&1)*8 + chunk is stored at slot c ^ (line & 15): a 64-lane fragment read then
     // touches 16 distinct slots per 16-lane service group (conflict free).  The image is written
-    // lane-linearly by global_load_lds, so the permutation is applied to WHICH (row, chunk) a lane
-    // fetches.
-    const uint16_t* a_src[NA];
-    int a_y[NA], a_x[NA], a_j[NA];
-    const uint16_t* b_src[NB];
-    int b_j[NB];
+    // lane-linearly by the LDS-DMA loads, so the permutation is applied to WHICH (row, chunk) a
+    // lane fetches.
+    uint32_t a_off[NA];              // byte offset of (pixel row, chunk) relative to rs_in, or kOOB
+    int a_y[NA], a_x[NA];
+    uint32_t b_off[NB];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int q = tid + THREADS * i;
         const int line = q >> 4, c = (q & 15) ^ (line & 15);
         const int r = 2 * line + (c >> 3);
         const int64_t m = (int64_t)m0 + r;
-        a_j[i] = (c & 7) * 8;
         if (m < M) {
             const int nimg = (int)(m / HW);
             const int rem = (int)(m - (int64_t)nimg * HW);
             a_y[i] = rem / W;
             a_x[i] = rem - a_y[i] * W;
-            a_src[i] = in + (size_t)m * Cin;
+            a_off[i] = (uint32_t)m * row_bytes + (uint32_t)(c & 7) * 16u;
         } else {
-            a_y[i] = -100000; a_x[i] = 0; a_src[i] = zeros;
+            a_y[i] = -100000; a_x[i] = 0; a_off[i] = kOOB;
         }
     }
 #pragma unroll
@@ -119,29 +150,38 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
         const int line = q >> 4, c = (q & 15) ^ (line & 15);
         const int r = 2 * line + (c >> 3);
         const int co = n0 + r;
-        b_j[i] = (c & 7) * 8;
-        b_src[i] = co < Cout ? wt + (size_t)co * 9 * Cin : nullptr;
+        b_off[i] = co < Cout ? (uint32_t)co * 9u * row_bytes + (uint32_t)(c & 7) * 16u : kOOB;
     }
     const int kc = Cin / BK;         // K-steps per tap
     const int nsteps = 9 * kc;
 
-    auto issue = [&](int s, int buf) {
-        const int tap = s / kc, c0 = (s - tap * kc) * BK;
+    // loader state: (tap, channel step) of the NEXT stage to fetch; halo validity is re-evaluated
+    // once per tap, the per-K-step cost is one scalar add
+    int ld_tap = 0, ld_c = 0;
+    uint32_t a_voff[NA];
+    auto set_tap = [&](int tap) {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        char* sA = smem + buf * kStage;                      // pixel tile  [BM][64] bf16
-        char* sB = sA + BM * BK * 2;                         // weight tile [BN][64] bf16
-        const int tap_off = (dy * W + dx) * Cin + c0;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
             const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const uint16_t* src = ok ? a_src[i] + tap_off + a_j[i] : zeros;
-            glds16(src, sA + (wave * 64 + THREADS * i) * 16);
+            a_voff[i] = ok ? a_off[i] : kOOB;
         }
+    };
+    set_tap(0);
+    auto issue = [&](int buf) {
+        char* sA = smem + buf * kStage;                      // pixel tile  [BM][64] bf16
+        char* sB = sA + BM * BK * 2;                         // weight tile [BN][64] bf16
+        const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
+        const uint32_t soff_a = (uint32_t)(ky * W + kx) * row_bytes + (uint32_t)ld_c * (BK * 2);
+        const uint32_t soff_b = (uint32_t)ld_tap * row_bytes + (uint32_t)ld_c * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-            const uint16_t* src = b_src[i] ? b_src[i] + tap * Cin + c0 + b_j[i] : zeros;
-            glds16(src, sB + (wave * 64 + THREADS * i) * 16);
+        for (int i = 0; i < NA; i++) bload_lds16(rs_in, a_voff[i], soff_a, sA + (wave * 64 + THREADS * i) * 16);
+#pragma unroll
+        for (int i = 0; i < NB; i++) bload_lds16(rs_w, b_off[i], soff_b, sB + (wave * 64 + THREADS * i) * 16);
+        if (++ld_c == kc) {
+            ld_c = 0;
+            if (++ld_tap < 9) set_tap(ld_tap);
         }
     };
 
@@ -155,23 +195,27 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
 
     const int wc = wave % WN, wp = wave / WN;   // wave's channel / pixel block
     const int frow = lane & 31, fk = lane >> 5;
+    // fragment read offsets for kk = 0; for kk > 0 the slot index is XORed with 2*kk (<< 4 bytes)
+    uint32_t w_rd[FA], p_rd[FB];
+#pragma unroll
+    for (int a = 0; a < FA; a++) w_rd[a] = (uint32_t)(BM * BK * 2 + swz(wc * (BN / WN) + a * 32 + frow, fk));
+#pragma unroll
+    for (int b = 0; b < FB; b++) p_rd[b] = (uint32_t)swz(wp * (BM / WM) + b * 32 + frow, fk);
 
-    issue(0, 0);
+    issue(0);
     for (int s = 0; s < nsteps; s++) {
         const int buf = s & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // stage `buf` landed for everyone; stage buf^1 free
-        if (s + 1 < nsteps) issue(s + 1, buf ^ 1);
-        const char* sA = smem + buf * kStage;
-        const char* sB = sA + BM * BK * 2;
+        if (s + 1 < nsteps) issue(buf ^ 1);
+        const char* st = smem + buf * kStage;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             bf16x8_t wf[FA], pf[FB];
-            const int j = kk * 2 + fk;
 #pragma unroll
-            for (int a = 0; a < FA; a++) wf[a] = *(const bf16x8_t*)(sB + swz(wc * (BN / WN) + a * 32 + frow, j));
+            for (int a = 0; a < FA; a++) wf[a] = *(const bf16x8_t*)(st + (w_rd[a] ^ (uint32_t)(kk << 5)));
 #pragma unroll
-            for (int b = 0; b < FB; b++) pf[b] = *(const bf16x8_t*)(sA + swz(wp * (BM / WM) + b * 32 + frow, j));
+            for (int b = 0; b < FB; b++) pf[b] = *(const bf16x8_t*)(st + (p_rd[b] ^ (uint32_t)(kk << 5)));
 #pragma unroll
             for (int a = 0; a < FA; a++)
 #pragma unroll
@@ -207,8 +251,8 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
                     v[2] += bf2f((uint16_t)(rr.y & 0xffff)); v[3] += bf2f((uint16_t)(rr.y >> 16));
                 }
                 uint2 o;
-                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                o.x = pack_bf16(v[0], v[1]);
+                o.y = pack_bf16(v[2], v[3]);
                 *(uint2*)(out + (size_t)m * Cout + co) = o;
             }
         }
@@ -267,6 +311,9 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
     if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || Cin % BK || Cout % 4 || Cin <= 0 || Cout <= 0)
         return fail(GD_NN_ERR_INVALID_ARG, "conv3x3: need Cin % 64 == 0 and Cout % 4 == 0");
+    if ((double)N * H * W * Cin * 2.0 + ((double)W + 1.0) * Cin * 2.0 >= 2147483648.0 ||
+        (double)Cout * 9.0 * Cin * 2.0 >= 2147483648.0)
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3: activation / weight tensor must be < 2 GiB (32-bit buffer offsets)");
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
     hipStream_t s = (hipStream_t)stream;
@@ -280,16 +327,14 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
     // pixels, else the 128x128 / 4-wave tile.
     int variant = g_force_variant;
     if (variant < 0) {
-        // cost model: (waves of workgroups over the resident slots) x (tile area / per-slot rate); rates are the
-        // measured whole-chip TFLOP/s of each variant on large shapes (tools/conv_kernel_bench.py)
-        const int bn[3] = {128, 128, 256}, bm[3] = {128, 256, 256}, slots[3] = {512, 256, 256};
-        const double eff[3] = {650.0, 760.0, 1000.0};
-        double best = 1e300;
-        for (int v = 0; v < 3; v++) {
-            const int64_t T = ((M + bm[v] - 1) / bm[v]) * ((Cout + bn[v] - 1) / bn[v]);
-            const double t = (double)((T + slots[v] - 1) / slots[v]) * bn[v] * bm[v] * slots[v] / eff[v];
-            if (t < best) { best = t; variant = v; }
-        }
+        // rules distilled from tools/conv_kernel_bench.py on MI355X: the 256x256 tile wins whenever Cout fills it
+        // and there is most of a wave of tiles; 128 ch x 256 px wins for long pixel dimensions with deep K or huge M;
+        // otherwise the 128x128 tile (2 workgroups per CU) hides latency best.
+        const int64_t t256 = ((M + 255) / 256) * ((Cout + 255) / 256);
+        const int64_t t128x256 = ((M + 255) / 256) * ((Cout + 127) / 128);
+        if (Cout % 256 == 0 && t256 >= 192) variant = 2;
+        else if (t128x256 >= 512 && (Cin >= 512 || M >= (1 << 20))) variant = 1;
+        else variant = 0;
     }
     hipEvent_t ea = nullptr, eb = nullptr;
     if (g_cprof.on) {
