@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--per-view-raster", action="store_true", help="reference-style Python loop over views")
     ap.add_argument("--raster-only", action="store_true", help="time only rasterizer fwd+bwd (diagnostic)")
+    ap.add_argument("--vsd", action="store_true",
+                    help="BASELINE configs[4] diagnostic: NeTF VSD iteration (VAE + 2 frozen UNet + LoRA UNet fwd, "
+                         "LoRA UNet fwd+bwd) on a synthetic 512^2 render, one view per GPU")
     return ap.parse_args()
 
 
@@ -133,11 +136,76 @@ def cpu_baseline(args):
                        f"{t_dense:.2f} s); scaled x{args.views}")}
 
 
+def vsd_main(args):
+    """NeTF texture-stage iteration (Garment_Deformer_NeTF/netf/trainer.py:158-256) with the mesh render
+    replaced by a synthetic 512^2 image leaf (nvdiffrast + tiny-cuda-nn are out of scope)."""
+    from garmentdreamer_amd import dist as gdist
+    from garmentdreamer_amd.guidance import sd21
+    from garmentdreamer_amd.guidance.sd_vsd import LoraUnet, StableDiffusionVSD
+    rk, lr, ws = gdist.init_from_env()
+    device = torch.device("cuda", lr)
+    torch.cuda.set_device(device)
+    gd = StableDiffusionVSD(device, fp16=True)
+    with torch.device(device):
+        lora = sd21.init_random_(sd21.LoraUNet2DConditionModel(), 2)
+    lora = lora.to(torch.bfloat16).to(memory_format=torch.channels_last)
+    train = lora.freeze_base()
+    q = LoraUnet(lora)
+    opt = torch.optim.AdamW(train, lr=1e-4)
+    g = torch.Generator(device=device).manual_seed(7 + rk)
+    gd.set_text_embeds(torch.randn(1, 77, 1024, device=device, generator=g),
+                       torch.randn(1, 77, 1024, device=device, generator=g))
+    img = torch.rand(1, 3, 512, 512, device=device, generator=g, requires_grad=True)
+    bucket = None
+
+    def step():
+        nonlocal bucket
+        pose = torch.randn(1, 16, device=device, generator=g)
+        loss, _, latents = gd.train_step(img, guidance_scale=7.5, q_unet=q, pose=pose, shading="albedo")
+        img.grad = None
+        loss.backward()
+        lu = gd.lora_train_loss(q, latents, pose, shading="albedo", unet_bs=1)
+        opt.zero_grad(set_to_none=True)
+        lu.backward()
+        if ws > 1:
+            grads = [p.grad for p in train if p.grad is not None]
+            if bucket is None:
+                bucket = gdist.GradBucket(grads)
+            bucket.all_reduce_mean_(grads)
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if rk == 0:
+        tfl = 3 * UNET_TFLOP_PER_SAMPLE + 2 * VAE_TFLOP_PER_IMAGE + 3 * UNET_TFLOP_PER_SAMPLE
+        print(json.dumps({"metric": "NeTF VSD iters/sec (VAE + 3 UNet fwd + LoRA-UNet fwd/bwd), 512^2, 1 view/GPU",
+                          "value": ws * args.steps / el, "unit": "view-iters/s", "n_gpus": ws, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "VSD step, SD-2.1 UNet + LoRA UNet (rank 4) random-init, batch 1"},
+                          "roofline_dense": {"bound": "mfma", "achieved": tfl / (el / args.steps),
+                                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": tfl / (el / args.steps) / PEAK_BF16_TFLOPS}}), flush=True)
+    if gdist.is_dist():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
         return
+    if args.vsd:
+        return vsd_main(args)
     from garmentdreamer_amd import _native, dist as gdist
     from garmentdreamer_amd.guidance.stable_diffusion_guidance import PromptEmbeddings, StableDiffusionGuidance
     from garmentdreamer_amd.scene import GaussianParams, synthetic_gaussians

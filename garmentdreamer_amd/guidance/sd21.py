@@ -82,8 +82,24 @@ class ResnetBlock2D(nn.Module):
         return _conv3(self.conv2, _gn(self.norm2, h, True), residual=x)
 
 
+class LoRALinearLayer(nn.Module):
+    """diffusers 0.19 ``LoRALinearLayer``: down (in -> rank, N(0, 1/rank)) then up (rank -> out, zeros)."""
+
+    def __init__(self, in_features: int, out_features: int, rank: int = 4):
+        super().__init__()
+        self.down = nn.Linear(in_features, rank, bias=False)
+        self.up = nn.Linear(rank, out_features, bias=False)
+        nn.init.normal_(self.down.weight, std=1 / rank)
+        nn.init.zeros_(self.up.weight)
+
+    def forward(self, x):
+        return self.up(self.down(x.to(self.down.weight.dtype))).to(x.dtype)
+
+
 class Attention(nn.Module):
-    """Multi-head attention with diffusers' parameter names (to_q/to_k/to_v/to_out.0)."""
+    """Multi-head attention with diffusers' parameter names (to_q/to_k/to_v/to_out.0).  ``add_lora``
+    attaches the four low-rank adapters of diffusers' ``LoRAAttnProcessor`` (used by the NeTF stage's
+    trainable "q" UNet: Garment_Deformer_NeTF/netf/trainer.py:79-101)."""
 
     def __init__(self, query_dim: int, heads: int, dim_head: int, cross_dim: Optional[int] = None,
                  qkv_bias: bool = False):
@@ -94,15 +110,33 @@ class Attention(nn.Module):
         self.to_k = nn.Linear(cross_dim or query_dim, inner, bias=qkv_bias)
         self.to_v = nn.Linear(cross_dim or query_dim, inner, bias=qkv_bias)
         self.to_out = nn.ModuleList([nn.Linear(inner, query_dim)])
+        self.lora = None
+        self.lora_scale = 1.0
+
+    def add_lora(self, rank: int = 4):
+        q_in, kv_in, inner = self.to_q.in_features, self.to_k.in_features, self.to_q.out_features
+        self.lora = nn.ModuleDict({
+            "to_q_lora": LoRALinearLayer(q_in, inner, rank), "to_k_lora": LoRALinearLayer(kv_in, inner, rank),
+            "to_v_lora": LoRALinearLayer(kv_in, inner, rank),
+            "to_out_lora": LoRALinearLayer(inner, self.to_out[0].out_features, rank)})
+        return self.lora
 
     def forward(self, x, context=None):
         B, N, _ = x.shape
         ctx = x if context is None else context
-        q = self.to_q(x).view(B, N, self.heads, -1).transpose(1, 2)
-        k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
-        v = self.to_v(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v)
-        return self.to_out[0](o.transpose(1, 2).reshape(B, N, -1))
+        q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
+        if self.lora is not None:
+            q = q + self.lora_scale * self.lora["to_q_lora"](x)
+            k = k + self.lora_scale * self.lora["to_k_lora"](ctx)
+            v = v + self.lora_scale * self.lora["to_v_lora"](ctx)
+        q = q.view(B, N, self.heads, -1).transpose(1, 2)
+        k = k.view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        v = v.view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, -1)
+        y = self.to_out[0](o)
+        if self.lora is not None:
+            y = y + self.lora_scale * self.lora["to_out_lora"](o)
+        return y
 
 
 class GEGLU(nn.Module):
@@ -291,11 +325,18 @@ class UNet2DConditionModel(nn.Module):
         self.conv_norm_out = nn.GroupNorm(32, ch[0], eps=1e-5)
         self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
 
-    def forward(self, sample, timestep, encoder_hidden_states):
+    def extra_embedding(self, batch: int, **kwargs):
+        """Hook for subclasses: an additive term for the time embedding (None here)."""
+        return None
+
+    def forward(self, sample, timestep, encoder_hidden_states, **kwargs):
         dtype = self.conv_in.weight.dtype
         if timestep.dim() == 0:
             timestep = timestep[None].expand(sample.shape[0])
         temb = self.time_embedding(sinusoidal_timestep_embedding(timestep, self.block_out_channels[0]).to(dtype))
+        extra = self.extra_embedding(sample.shape[0], **kwargs)
+        if extra is not None:
+            temb = temb + extra.to(dtype)
         x = self.conv_in(sample.to(dtype).contiguous(memory_format=torch.channels_last))
         ctx = encoder_hidden_states.to(dtype)
         skips = [x]
@@ -305,6 +346,50 @@ class UNet2DConditionModel(nn.Module):
         for blk in self.up_blocks:
             x = blk(x, temb, ctx, skips)
         return _conv3(self.conv_out, _gn(self.conv_norm_out, x, True))
+
+
+class LoraUNet2DConditionModel(UNet2DConditionModel):
+    """The NeTF stage's trainable "q" network: an SD-2.1 UNet with LoRA adapters on every attention
+    (rank 4) plus a camera-pose MLP and per-shading embeddings added to the time embedding
+    (Garment_Deformer_NeTF/netf/vsd/lora_unet.py:415-422,632-645; adapters installed at
+    Garment_Deformer_NeTF/netf/trainer.py:88-101).  ``forward(x, t, text, c=pose[B,16], shading=...)``.
+    Base weights are frozen; only the adapters, ``camera_emb`` and the shading embeddings train."""
+
+    def __init__(self, rank: int = 4, **kw):
+        super().__init__(**kw)
+        temb_ch = self.block_out_channels[0] * 4
+        self.camera_emb = nn.Sequential(nn.Linear(16, temb_ch), nn.SiLU(), nn.Linear(temb_ch, temb_ch))
+        self.lambertian_emb = nn.Parameter(torch.randn(1, temb_ch))
+        self.textureless_emb = nn.Parameter(torch.randn(1, temb_ch))
+        self.normal_emb = nn.Parameter(torch.randn(1, temb_ch))
+        self.lora_layers = nn.ModuleList()
+        for m in self.modules():
+            if isinstance(m, Attention):
+                self.lora_layers.append(m.add_lora(rank))
+
+    def freeze_base(self):
+        for p in self.parameters():
+            p.requires_grad_(False)
+        train = list(self.lora_layers.parameters()) + list(self.camera_emb.parameters()) + \
+            [self.lambertian_emb, self.textureless_emb, self.normal_emb]
+        for p in train:
+            p.requires_grad_(True)
+        return train
+
+    def extra_embedding(self, batch: int, c=None, shading: str = "albedo"):
+        dev, dt = self.camera_emb[0].weight.device, self.camera_emb[0].weight.dtype
+        if c is None:
+            c = torch.zeros(batch, 16, device=dev)
+        emb = self.camera_emb(c.to(device=dev, dtype=dt))
+        if shading == "textureless":
+            emb = emb + self.textureless_emb
+        elif shading == "lambertian":
+            emb = emb + self.lambertian_emb
+        elif shading == "normal":
+            emb = emb + self.normal_emb
+        else:
+            assert shading == "albedo"
+        return emb
 
 
 # ----------------------------------------------------------------------------------------------
@@ -456,6 +541,16 @@ class DDIMScheduler:
             sqrt_1ma = sqrt_1ma.unsqueeze(-1)
         return sqrt_a * original_samples + sqrt_1ma * noise
 
+    def get_velocity(self, sample, noise, timesteps):
+        """v-prediction target: sqrt(abar) * eps - sqrt(1 - abar) * x0."""
+        ac = self.alphas_cumprod.to(device=sample.device, dtype=sample.dtype)
+        sqrt_a = ac[timesteps] ** 0.5
+        sqrt_1ma = (1 - ac[timesteps]) ** 0.5
+        while sqrt_a.dim() < sample.dim():
+            sqrt_a = sqrt_a.unsqueeze(-1)
+            sqrt_1ma = sqrt_1ma.unsqueeze(-1)
+        return sqrt_a * noise - sqrt_1ma * sample
+
 
 # ----------------------------------------------------------------------------------------------
 # weights
@@ -469,6 +564,8 @@ def init_random_(module: nn.Module, seed: int = 0) -> nn.Module:
     gens = {}
     with torch.no_grad():
         for name, p in module.named_parameters():
+            if "lora" in name:   # adapters keep their constructor init (down ~ N(0, 1/rank), up = 0)
+                continue
             g = gens.get(p.device)
             if g is None:
                 g = gens[p.device] = torch.Generator(device=p.device).manual_seed(seed)

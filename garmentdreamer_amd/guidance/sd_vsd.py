@@ -1,0 +1,154 @@
+"""Variational-Score-Distillation guidance of the NeTF texture stage (BASELINE.json configs[4]).
+
+Mirrors ``StableDiffusion.train_step`` / ``SpecifyGradient`` / ``encode_imgs``
+(Garment_Deformer_NeTF/netf/guidance/sd_vsd_utils.py:15-28,131-218,274-282) and the LoRA training
+step the trainer runs after each guidance step (Garment_Deformer_NeTF/netf/trainer.py:228-256):
+
+    latents = VAE_enc(2x-1).sample() * 0.18215                    (with grad)
+    t ~ U[20, 500]                    (t_range [0.02, 0.5], :39,162)
+    eps_cfg = eps_uncond + s (eps_cond - eps_uncond)              (frozen UNet on [x_t; x_t], s = 7.5; :182-190)
+    v_q = q_unet(x_t, t, text, c=pose, shading)                   (LoRA UNet, v-prediction)
+    eps_q = sqrt(abar) v_q + sqrt(1-abar) x_t                     (:199-207)
+    grad = (1 - abar) (eps_cfg - eps_q); loss = SpecifyGradient(latents, grad)      (:210-214)
+
+As in the reference the batch size is 1 and the image is 512^2 (:144,146); embeddings are ordered
+[cond; uncond] and CFG uses the usual ``uncond + s (cond - uncond)`` form (unlike the threestudio
+guidance).  The UNets / VAE are the restatements in ``sd21.py`` (diffusers + hub weights are absent:
+parity unpinned, see that module); bf16 on MI355X where the reference runs fp32 (``fp16=False``, :35).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import sd21
+
+
+class SpecifyGradient(torch.autograd.Function):
+    """sd_vsd_utils.py:15-28: forward returns sum(grad) as a dummy loss value, backward hands
+    ``gt_grad / batch_size`` to the latents."""
+
+    @staticmethod
+    def forward(ctx, input_tensor, gt_grad):
+        ctx.save_for_backward(gt_grad)
+        return gt_grad.detach().sum().to(input_tensor.dtype)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (gt_grad,) = ctx.saved_tensors
+        return gt_grad / len(gt_grad), None
+
+
+class StableDiffusionVSD(nn.Module):
+    def __init__(self, device, fp16: bool = True, t_range=(0.02, 0.5), unet: Optional[nn.Module] = None,
+                 vae: Optional[nn.Module] = None, init_seed: int = 0):
+        super().__init__()
+        self.device = torch.device(device)
+        self.dtype = torch.bfloat16 if fp16 else torch.float32
+        if unet is None:
+            with torch.device(self.device):
+                unet = sd21.init_random_(sd21.UNet2DConditionModel(), init_seed)
+        if vae is None:
+            with torch.device(self.device):
+                vae = sd21.init_random_(sd21.AutoencoderKLEncoder(), init_seed + 1)
+        self.unet = unet.to(device=self.device, dtype=self.dtype).to(memory_format=torch.channels_last).eval()
+        self.vae = vae.to(device=self.device, dtype=self.dtype).to(memory_format=torch.channels_last).eval()
+        for p in list(self.unet.parameters()) + list(self.vae.parameters()):
+            p.requires_grad_(False)
+        self.scheduler = sd21.DDIMScheduler()
+        self.num_train_timesteps = self.scheduler.config.num_train_timesteps
+        self.min_step = int(self.num_train_timesteps * t_range[0])
+        self.max_step = int(self.num_train_timesteps * t_range[1])
+        self.alphas = self.scheduler.alphas_cumprod.to(self.device)
+        self.embeddings = {}
+
+    def set_text_embeds(self, pos, neg, front=None, side=None, back=None):
+        """The reference fills these with the CLIP text encoder (get_text_embeds, :81-91); out of
+        scope here, so callers provide [1,77,1024] tensors (random for benchmarks)."""
+        self.embeddings = {"pos": pos, "neg": neg, "front": front if front is not None else pos,
+                           "side": side if side is not None else pos, "back": back if back is not None else pos}
+
+    def encode_imgs(self, imgs, vae_noise=None):
+        imgs = 2 * imgs - 1
+        posterior = self.vae.encode(imgs.to(self.dtype)).latent_dist
+        return posterior.sample(vae_noise) * self.vae.config.scaling_factor
+
+    def train_step(self, pred_rgb, guidance_scale=7.5, q_unet=None, pose=None, shading=None, as_latent=False,
+                   t5=False, hors=None, noise=None, timesteps=None, vae_noise=None):
+        batch_size = pred_rgb.shape[0]
+        assert batch_size == 1
+        assert pred_rgb.shape[2] == pred_rgb.shape[3] == 512
+        assert not as_latent
+        latents = self.encode_imgs(pred_rgb, vae_noise).float()
+        if timesteps is not None:
+            t = timesteps.to(self.device).long()
+        elif t5:
+            t = torch.randint(self.min_step, 500 + 1, [1], dtype=torch.long, device=self.device)
+        else:
+            t = torch.randint(self.min_step, self.max_step + 1, (batch_size,), dtype=torch.long, device=self.device)
+        with torch.no_grad():
+            if noise is None:
+                noise = torch.randn_like(latents)
+            latents_noisy = self.scheduler.add_noise(latents, noise, t)
+            latent_model_input = torch.cat([latents_noisy] * 2)
+            tt = torch.cat([t] * 2)
+            if hors is None:
+                embeddings = torch.cat([self.embeddings["pos"].expand(batch_size, -1, -1),
+                                        self.embeddings["neg"].expand(batch_size, -1, -1)])
+            else:
+                def _dir(h):
+                    return "front" if abs(h) < 60 else ("side" if abs(h) < 120 else "back")
+                embeddings = torch.cat([self.embeddings[_dir(h)] for h in hors] +
+                                       [self.embeddings["neg"].expand(batch_size, -1, -1)])
+            noise_pred = self.unet(latent_model_input, tt, encoder_hidden_states=embeddings).float()
+            noise_pred_cond, noise_pred_uncond = noise_pred.chunk(2)
+            noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_cond - noise_pred_uncond)
+            if q_unet is None or pose is None:
+                raise NotImplementedError("VSD needs the LoRA UNet and a pose (sd_vsd_utils.py:192-197)")
+            v_q = q_unet(latents_noisy, t, self.embeddings["pos"].expand(batch_size, -1, -1), c=pose,
+                         shading=shading or "albedo").float()
+            a = self.alphas[t].view(-1, 1, 1, 1)
+            noise_pred_q = a.sqrt() * v_q + (1 - a).sqrt() * latents_noisy   # v -> eps
+        w = (1 - self.alphas[t]).view(batch_size, 1, 1, 1)
+        grad = torch.nan_to_num(w * (noise_pred - noise_pred_q))
+        loss = SpecifyGradient.apply(latents, grad)
+        pseudo_loss = torch.mul((w * noise_pred).detach(), latents.detach()).detach().sum()
+        return loss, pseudo_loss, latents
+
+    def lora_train_loss(self, q_unet, latents, pose, shading="albedo", unet_bs=1, v_pred=True, uncond_p=0.1,
+                        timesteps=None, noise=None, drop_pose: Optional[bool] = None):
+        """One denoising-loss evaluation for the LoRA UNet (trainer.py:228-256): MSE to the velocity
+        (or noise) target on the current latents; the caller backprops and steps its optimizer."""
+        with torch.no_grad():
+            latents_clean = latents.detach().expand(unet_bs, *latents.shape[1:]).contiguous()
+            pose_b = pose.expand(unet_bs, 16).contiguous()
+            if drop_pose is None:
+                drop_pose = bool(torch.rand(()) < uncond_p)
+            if drop_pose:
+                pose_b = torch.zeros_like(pose_b)
+            if timesteps is None:
+                timesteps = torch.randint(0, 1000, (unet_bs,), device=self.device).long()
+            if noise is None:
+                noise = torch.randn(latents_clean.shape, device=self.device)
+            latents_noisy = self.scheduler.add_noise(latents_clean, noise, timesteps)
+            target = self.scheduler.get_velocity(latents_clean, noise, timesteps) if v_pred else noise
+        out = q_unet(latents_noisy, timesteps, self.embeddings["pos"].expand(unet_bs, -1, -1), c=pose_b,
+                     shading=shading).float()
+        return F.mse_loss(out, target)
+
+
+class LoraUnet(nn.Module):
+    """trainer.py:107-116: wraps the adapter UNet and repeats the single text embedding over the batch."""
+
+    def __init__(self, unet: sd21.LoraUNet2DConditionModel):
+        super().__init__()
+        self.unet = unet
+        self.sample_size = 64
+        self.in_channels = 4
+
+    def forward(self, x, t, text_embeddings, c=None, shading="albedo"):
+        textemb = text_embeddings.expand(x.shape[0], -1, -1) if text_embeddings.shape[0] == 1 else text_embeddings
+        return self.unet(x, t, encoder_hidden_states=textemb, c=c, shading=shading)
