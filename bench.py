@@ -214,7 +214,7 @@ def main():
     rk, lr, ws = gdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP rasterizer has no CPU path")
-    device = torch.device("cuda", lr)
+    device = torch.device("cuda", lr % torch.cuda.device_count())   # (ranks may share a GPU only under GD_DIST_BACKEND=gloo)
     torch.cuda.set_device(device)
     _native.lib()  # fail loudly right here if the HIP library is missing
     torch.backends.cuda.matmul.allow_tf32 = False

@@ -47,7 +47,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+            # GD_DIST_BACKEND=gloo lets several ranks share ONE GPU (functional check of the sharded
+            # path on a single-GPU box); production is "nccl" (= RCCL on ROCm), one rank per GPU.
+            backend = os.environ.get("GD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(lr)
             dist.init_process_group(backend, rank=rk, world_size=ws, device_id=torch.device("cuda", lr))
