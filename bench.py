@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--per-view-raster", action="store_true", help="reference-style Python loop over views")
     ap.add_argument("--raster-only", action="store_true", help="time only rasterizer fwd+bwd (diagnostic)")
+    ap.add_argument("--no-graphs", action="store_true", help="eager launches instead of hipGraph replay of UNet/VAE")
     ap.add_argument("--vsd", action="store_true",
                     help="BASELINE configs[4] diagnostic: NeTF VSD iteration (VAE + 2 frozen UNet + LoRA UNet fwd, "
                          "LoRA UNet fwd+bwd) on a synthetic 512^2 render, one view per GPU")
@@ -226,7 +227,8 @@ def main():
     if args.raster_only:
         guidance, prompt = None, None
     else:
-        guidance = StableDiffusionGuidance({"guidance_scale": 100.0, "grad_clip": [0, 1.5, 2.0, 1000]}, device=device)
+        guidance = StableDiffusionGuidance({"guidance_scale": 100.0, "grad_clip": [0, 1.5, 2.0, 1000],
+                                            "use_hip_graphs": not args.no_graphs}, device=device)
         prompt = PromptEmbeddings.random(device)
     loop = SDSLoop(gaussians, guidance, prompt, bg)
     if args.per_view_raster:
