@@ -66,6 +66,61 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+typedef __attribute__((ext_vector_type(2))) unsigned gd_u2;
+// v_permlane32_swap: a <- [a.lo | b.lo], b <- [a.hi | b.hi]   (lo/hi = lanes 0-31 / 32-63)
+__device__ __forceinline__ void swap32(float& a, float& b)
+{
+    gd_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+// v_permlane16_swap: a <- [a.r0, b.r0, a.r2, b.r2], b <- [a.r1, b.r1, a.r3, b.r3]   (r = rows of 16 lanes)
+__device__ __forceinline__ void swap16(float& a, float& b)
+{
+    gd_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// Sum TEN values over the 64 lanes of a wave with a halving tree: each step adds lane partners AND
+// halves the number of live registers (the two halves of the wave / row / octet / quad carry different
+// values afterwards), so the whole reduction is ~38 VALU instead of 10 x 6 DPP adds.  On return the
+// 4 lanes of quad (lane >> 2) all hold the total of value  4*(lane>>4) + ((lane&4) ? 2 + ((lane>>3)&1)
+// : ((lane>>3)&1))  (values >= 10 are junk).
+__device__ __forceinline__ float wave_reduce10(float (&v)[10], uint32_t lane)
+{
+    float s[8];
+    // distance 32: (v[i], v[i+8]) -> lower half: value i, upper half: value i+8
+    swap32(v[0], v[8]); s[0] = v[0] + v[8];
+    swap32(v[1], v[9]); s[1] = v[1] + v[9];
+#pragma unroll
+    for (int i = 2; i < 8; i++) {   // partner value is identically zero: only the lower half is meaningful
+        float c = v[i];
+        swap32(v[i], c);
+        s[i] = v[i] + c;
+    }
+    // distance 16: rows become values i, i+4, i+8, i+12
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        swap16(s[i], s[i + 4]);
+        s[i] = s[i] + s[i + 4];
+    }
+    // distance 8 (row_ror:8), keep t0|t1 and t2|t3 in the two octets of a row
+    const bool oct1 = (lane & 8u) != 0, quad1 = (lane & 4u) != 0;
+    const float a0 = s[0] + dpp_term<0x128, 0xf, 0xf>(s[0]);
+    const float a1 = s[1] + dpp_term<0x128, 0xf, 0xf>(s[1]);
+    const float a2 = s[2] + dpp_term<0x128, 0xf, 0xf>(s[2]);
+    const float a3 = s[3] + dpp_term<0x128, 0xf, 0xf>(s[3]);
+    const float u0 = oct1 ? a1 : a0, u1 = oct1 ? a3 : a2;
+    // distance 4: row_shl:4 serves lanes with (lane&4)==0, row_shr:4 the others
+    const float p = u0 + dpp_term<0x104, 0xf, 0xf>(u0);
+    const float q = u1 + dpp_term<0x114, 0xf, 0xf>(u1);
+    float z = quad1 ? q : p;
+    z += dpp_term<0x4E, 0xf, 0xf>(z);   // quad_perm [2,3,0,1]
+    z += dpp_term<0xB1, 0xf, 0xf>(z);   // quad_perm [1,0,3,2]
+    return z;
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
 #pragma unroll
@@ -83,6 +138,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     __shared__ float2 s_xy[kTilePix];
     __shared__ float4 s_co[kTilePix];
     __shared__ float4 s_fd[kTilePix];
+    __shared__ float s_thr[kTilePix];   // ln(1/(255 opacity)) - margin: below it alpha < 1/255 for certain
 
     const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
     const uint32_t tpv = gx * gy;
@@ -111,7 +167,9 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
         if (range.x + progress < range.y) {
             const uint32_t id = point_list[range.x + progress];
             s_xy[tid] = means2D[id];
-            s_co[tid] = conic_opacity[id];
+            const float4 c4 = conic_opacity[id];
+            s_co[tid] = c4;
+            s_thr[tid] = -__logf(255.0f * c4.w) - 1e-3f;
             s_fd[tid] = rgbd[id];
         }
         __syncthreads();
@@ -123,6 +181,9 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
             const float4 co = s_co[j];
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
             if (power > 0.0f) continue;
+            // cheap certain reject: o*exp(power) < 1/255 whenever power < ln(1/(255 o)) - 1e-3 (the margin
+            // covers the rounding of the fast log); everything else takes the reference's exact test below
+            if (power < s_thr[j]) continue;
             const float alpha = fminf(0.99f, co.w * expf(power));
             if (alpha < 1.0f / 255.0f) continue;
             const float test_T = T * (1 - alpha);
@@ -186,6 +247,7 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
     __shared__ float4 s_co[ROUND];
     __shared__ float4 s_fd[ROUND];
     __shared__ uint32_t s_id[ROUND];
+    __shared__ float s_thr[ROUND];                // ln(1 / (255 opacity)): alpha >= 1/255  <=>  power >= s_thr
     __shared__ float s_acc[ROUND * kAcc];
     __shared__ uint32_t s_wmax[4];
 
@@ -251,7 +313,9 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
             const uint32_t id = point_list[range.y - (uint32_t)(round_base + e) - 1];
             s_id[e] = id;
             s_xy[e] = means2D[id];
-            s_co[e] = conic_opacity[id];
+            const float4 c4 = conic_opacity[id];
+            s_co[e] = c4;
+            s_thr[e] = -__logf(255.0f * c4.w);
             s_fd[e] = rgbd[id];
         }
         __syncthreads();
@@ -260,7 +324,10 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
                 const uint32_t ordinal = (uint32_t)(total - 1 - (round_base + j));
                 const float2 xy = s_xy[j];
                 const float4 co = s_co[j];
+                const float thr = s_thr[j];
                 const float dx = xy.x - pixf_x;
+                // power(dy) = pa + dy * (pb + pc * dy): two FMAs per pixel, no exp on the visited-only path
+                const float pa = -0.5f * co.x * dx * dx, pb = -co.y * dx, pc = -0.5f * co.z;
                 float v[kAcc];
 #pragma unroll
                 for (int k = 0; k < kAcc; k++) v[k] = 0.f;
@@ -269,14 +336,16 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
                 for (int q = 0; q < PPL; q++) {
                     PixState& p = ps[q];
                     const float dy = xy.y - p.pixf_y;
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    // v_exp_f32 path: |power| <= 5.6 wherever the pair can contribute, relative error ~3e-7 --
-                    // far inside the gradient tolerance; the forward pass (which fixes n_contrib) keeps libm expf
-                    const float G = __expf(power);
-                    const float alpha = fminf(0.99f, co.w * G);
-                    const bool valid = (ordinal < p.last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                    const float power = fmaf(fmaf(pc, dy, pb), dy, pa);
+                    // alpha >= 1/255 decided on the exponent (power >= ln(1/(255 o))): the exp is only paid by
+                    // contributing pairs.  Pairs within rounding of the threshold may be classified differently
+                    // from the forward pass; their alpha is ~1/255 and the effect is far inside the tolerance.
+                    const bool valid = (ordinal < p.last_contributor) && !(power > 0.0f) && (power >= thr);
                     if (valid) {
                         any_valid = true;
+                        // v_exp_f32 path (relative error ~3e-7); the forward pass keeps libm expf for n_contrib
+                        const float G = __expf(power);
+                        const float alpha = fminf(0.99f, co.w * G);
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // shared by T/(1-a), T_final/(1-a)
                         p.T = p.T * inv;
                         const float dchannel_dcolor = alpha * p.T;
@@ -318,16 +387,11 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
 #pragma unroll
                 for (int k = 0; k < kAcc; k++) asm volatile("" ::"v"(v[k]));
 #else
-#pragma unroll
-                for (int k = 0; k < kAcc; k++) v[k] = wave_sum_to_lane63(v[k]);
-                if (lane == 63) {
-                    if (WAVES == 1) {
-#pragma unroll
-                        for (int k = 0; k < kAcc; k++) s_acc[j * kAcc + k] = v[k];   // single writer per tile
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < kAcc; k++) atomicAdd(&s_acc[j * kAcc + k], v[k]);
-                    }
+                const float z = wave_reduce10(v, lane);
+                const uint32_t vid = 4u * (lane >> 4) + ((lane & 4u) ? 2u + ((lane >> 3) & 1u) : ((lane >> 3) & 1u));
+                if ((lane & 3u) == 0 && vid < (uint32_t)kAcc) {
+                    if (WAVES == 1) s_acc[j * kAcc + vid] = z;   // single writer per tile
+                    else atomicAdd(&s_acc[j * kAcc + vid], z);
                 }
 #endif
             }
@@ -368,7 +432,7 @@ void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
     // pixels per lane: fewer, fatter lanes amortise the per-entry wave reduction; needs enough tiles to
     // fill 256 CUs x 4 SIMDs (GD_RASTER_BWD_PPL overrides, for tuning)
-    int ppl = tiles_total >= 4096 ? 4 : (tiles_total >= 2048 ? 2 : 1);
+    int ppl = tiles_total >= 2048 ? 2 : 1;   // measured: 893 us (2) vs 931 (1) vs 959 (4) at 8192 tiles
     if (const char* e = getenv("GD_RASTER_BWD_PPL")) ppl = atoi(e);
 #define GD_BWD(PPL_)                                                                                               \
     hipLaunchKernelGGL(render_backward_kernel<PPL_>, dim3(tiles_total), dim3(kTilePix / PPL_), 0, s, W, H,         \
