@@ -34,6 +34,10 @@
 
 #include "../../include/gd_nn.h"
 
+#ifndef GD_CONV_ABLATE
+#define GD_CONV_ABLATE 0
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
@@ -175,10 +179,14 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
         const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
         const uint32_t soff_a = (uint32_t)(ky * W + kx) * row_bytes + (uint32_t)ld_c * (BK * 2);
         const uint32_t soff_b = (uint32_t)ld_tap * row_bytes + (uint32_t)ld_c * (BK * 2);
+#if GD_CONV_ABLATE != 1 && GD_CONV_ABLATE != 2 && GD_CONV_ABLATE < 6
 #pragma unroll
         for (int i = 0; i < NA; i++) bload_lds16(rs_in, a_voff[i], soff_a, sA + (wave * 64 + THREADS * i) * 16);
+#endif
+#if GD_CONV_ABLATE != 2 && GD_CONV_ABLATE < 6
 #pragma unroll
         for (int i = 0; i < NB; i++) bload_lds16(rs_w, b_off[i], soff_b, sB + (wave * 64 + THREADS * i) * 16);
+#endif
         if (++ld_c == kc) {
             ld_c = 0;
             if (++ld_tap < 9) set_tap(ld_tap);
@@ -202,16 +210,35 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
 #pragma unroll
     for (int b = 0; b < FB; b++) p_rd[b] = (uint32_t)swz(wp * (BM / WM) + b * 32 + frow, fk);
 
+#if GD_CONV_ABLATE == 4 || GD_CONV_ABLATE >= 6
+    bf16x8_t wf0[FA], pf0[FB];
+#pragma unroll
+    for (int a = 0; a < FA; a++) wf0[a] = *(const bf16x8_t*)(smem + w_rd[a]);
+#pragma unroll
+    for (int b = 0; b < FB; b++) pf0[b] = *(const bf16x8_t*)(smem + p_rd[b]);
+#endif
     issue(0);
     for (int s = 0; s < nsteps; s++) {
         const int buf = s & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if GD_CONV_ABLATE != 5 && GD_CONV_ABLATE != 6
         __syncthreads();                       // stage `buf` landed for everyone; stage buf^1 free
+#endif
         if (s + 1 < nsteps) issue(buf ^ 1);
         const char* st = smem + buf * kStage;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             bf16x8_t wf[FA], pf[FB];
+#if GD_CONV_ABLATE == 4 || GD_CONV_ABLATE >= 6
+            if (s > 0) {
+#pragma unroll
+                for (int a = 0; a < FA; a++)
+#pragma unroll
+                    for (int b = 0; b < FB; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[a], pf0[b], acc[a][b], 0, 0, 0);
+                continue;
+            }
+#endif
 #pragma unroll
             for (int a = 0; a < FA; a++) wf[a] = *(const bf16x8_t*)(st + (w_rd[a] ^ (uint32_t)(kk << 5)));
 #pragma unroll
@@ -220,7 +247,12 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
             for (int a = 0; a < FA; a++)
 #pragma unroll
                 for (int b = 0; b < FB; b++)
+#if GD_CONV_ABLATE == 3
+                    if (a == 0 && b == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+                    else { acc[a][b][0] += __builtin_bit_cast(float, (int)wf[a][0] ^ (int)pf[b][1]); }
+#else
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+#endif
         }
     }
 

@@ -11,7 +11,8 @@ import torch
 import torch.nn.functional as F
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgd_nn.so")
+# GD_NN_LIB: optional override for A/B timing of experimental builds (tools/, never set in tests)
+_LIB_PATH = os.environ.get("GD_NN_LIB") or os.path.join(_HERE, "libgd_nn.so")
 _lib = None
 
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
