@@ -128,6 +128,46 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
+// Which of the tile's four 16x4 pixel strips can an entry reach?  Bit s is CLEAR only if the minimum of the
+// conic's quadratic form  f(d) = 0.5 (a dx^2 + c dy^2) + b dx dy,  d = centre - pixel,  over the strip's
+// rectangle exceeds tau (= ln(255 opacity) + margin): then every pixel of the strip has power < ln(1/(255 o))
+// and fails the alpha >= 1/255 test, so skipping the entry for that strip's wave changes no result.
+// f is convex, so unless the centre lies inside the rectangle the minimum sits on one of the four edges,
+// where it is a clamped 1-D parabola minimum.  (The reference walks every entry of the tile for every
+// pixel, forward.cu:330-358 / backward.cu:505-533; ~56 % of (strip, entry) pairs are dead on the
+// benchmark scene.)  One evaluation per staged entry, by the staging thread.
+__device__ __forceinline__ uint32_t strip_alive_mask(const float2 xy, const float4 co, const float tau,
+                                                     const float x0, const float y0)
+{
+#ifdef GD_NO_STRIP_CULL   // A/B builds only (tools/, tests never define it)
+    return 0xFu;
+#endif
+    const float a = co.x, b = co.y, c = co.z;
+    const float dxa = xy.x - (x0 + 15.0f), dxb = xy.x - x0;
+    const float ra = __builtin_amdgcn_rcpf(a), rc = __builtin_amdgcn_rcpf(c);
+    const bool xin = dxa <= 0.0f && dxb >= 0.0f;
+    const float tA = -b * dxa * rc, tB = -b * dxb * rc;          // unconstrained dy* on the two vertical edges
+    const float hA = 0.5f * a * dxa * dxa, hB = 0.5f * a * dxb * dxb;
+    const float bA = b * dxa, bB = b * dxb;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const float dya = xy.y - (y0 + 4.0f * s + 3.0f), dyb = xy.y - (y0 + 4.0f * s);
+        const bool yin = dya <= 0.0f && dyb >= 0.0f;
+        float t = fminf(fmaxf(tA, dya), dyb);
+        const float v1 = hA + t * (bA + 0.5f * c * t);
+        t = fminf(fmaxf(tB, dya), dyb);
+        const float v2 = hB + t * (bB + 0.5f * c * t);
+        t = fminf(fmaxf(-b * dya * ra, dxa), dxb);
+        const float v3 = 0.5f * c * dya * dya + t * (b * dya + 0.5f * a * t);
+        t = fminf(fmaxf(-b * dyb * ra, dxa), dxb);
+        const float v4 = 0.5f * c * dyb * dyb + t * (b * dyb + 0.5f * a * t);
+        const float fmin_ = (xin && yin) ? 0.0f : fminf(fminf(v1, v2), fminf(v3, v4));
+        if (!(fmin_ > tau)) mask |= 1u << s;   // NaN -> alive
+    }
+    return mask;
+}
+
 __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
@@ -139,6 +179,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     __shared__ float4 s_co[kTilePix];
     __shared__ float4 s_fd[kTilePix];
     __shared__ float s_thr[kTilePix];   // ln(1/(255 opacity)) - margin: below it alpha < 1/255 for certain
+    __shared__ uint32_t s_mask[kTilePix];  // strip_alive_mask per staged entry (0 beyond the list end)
 
     const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
     const uint32_t tpv = gx * gy;
@@ -154,53 +195,79 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
 
     bool done = !inside;
     const uint2 range = ranges[tile];
-    const int rounds = (int)((range.y - range.x + kTilePix - 1) / kTilePix);
-    int toDo = (int)(range.y - range.x);
+    const int total = (int)(range.y - range.x);
+    const int rounds = (total + kTilePix - 1) / kTilePix;
+    int toDo = total;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave w owns strip w (tile rows 4w .. 4w+3)
+    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
 
     float T = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0, blended = 0;
+    // contributor = entries walked while the pixel was live (forward.cu:336): the whole list unless the pixel
+    // saturates at entry g, then g + 1
+    uint32_t contributor = (uint32_t)total, last_contributor = 0, blended = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f;
 
     for (int i = 0; i < rounds; i++, toDo -= kTilePix) {
         if (__syncthreads_count(done) == kTilePix) break;
         const uint32_t progress = (uint32_t)i * kTilePix + tid;
+        uint32_t alive = 0;
         if (range.x + progress < range.y) {
             const uint32_t id = point_list[range.x + progress];
-            s_xy[tid] = means2D[id];
+            const float2 xy = means2D[id];
+            s_xy[tid] = xy;
             const float4 c4 = conic_opacity[id];
             s_co[tid] = c4;
-            s_thr[tid] = -__logf(255.0f * c4.w) - 1e-3f;
+            const float thr = -__logf(255.0f * c4.w) - 1e-3f;
+            s_thr[tid] = thr;
             s_fd[tid] = rgbd[id];
+            alive = strip_alive_mask(xy, c4, -thr + 1e-2f + 1e-3f * fabsf(thr), tile_x0, tile_y0);
         }
+        s_mask[tid] = alive;
         __syncthreads();
         const int n = min(kTilePix, toDo);
-        for (int j = 0; !done && j < n; j++) {
-            contributor++;
-            const float2 xy = s_xy[j];
-            const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
-            const float4 co = s_co[j];
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            if (power > 0.0f) continue;
-            // cheap certain reject: o*exp(power) < 1/255 whenever power < ln(1/(255 o)) - 1e-3 (the margin
-            // covers the rounding of the fast log); everything else takes the reference's exact test below
-            if (power < s_thr[j]) continue;
-            const float alpha = fminf(0.99f, co.w * expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1 - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
+        const uint32_t cbase = (uint32_t)i * kTilePix;
+        bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;
+        for (int c = 0; wave_live && c < n; c += 64) {
+            // 64 entries' strip bits -> one scalar bitmap of the entries this wave must look at
+            uint64_t bits = __builtin_amdgcn_ballot_w64(((s_mask[c + lane] >> wave) & 1u) != 0);
+            while (bits) {
+                const int j = c + (int)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (!done) {
+                    const float2 xy = s_xy[j];
+                    const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
+                    const float4 co = s_co[j];
+                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                    // cheap certain reject: o*exp(power) < 1/255 whenever power < ln(1/(255 o)) - 1e-3 (the margin
+                    // covers the rounding of the fast log); everything else takes the reference's exact test below
+                    if (!(power > 0.0f) && !(power < s_thr[j])) {
+                        const float alpha = fminf(0.99f, co.w * expf(power));
+                        if (!(alpha < 1.0f / 255.0f)) {
+                            const float test_T = T * (1 - alpha);
+                            if (test_T < 0.0001f) {
+                                done = true;
+                                contributor = cbase + (uint32_t)j + 1u;
+                            } else {
+                                const float4 fd = s_fd[j];
+                                const float w = alpha * T;
+                                C0 += fd.x * alpha * T;
+                                C1 += fd.y * alpha * T;
+                                C2 += fd.z * alpha * T;
+                                weight += w;
+                                Dd += fd.w * alpha * T;
+                                T = test_T;
+                                last_contributor = cbase + (uint32_t)j + 1u;
+                                blended++;
+                            }
+                        }
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) {
+                    wave_live = false;
+                    break;
+                }
             }
-            const float4 fd = s_fd[j];
-            const float w = alpha * T;
-            C0 += fd.x * alpha * T;
-            C1 += fd.y * alpha * T;
-            C2 += fd.z * alpha * T;
-            weight += w;
-            Dd += fd.w * alpha * T;
-            T = test_T;
-            last_contributor = contributor;
-            blended++;
         }
     }
     if (inside) {
@@ -249,6 +316,7 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
     __shared__ uint32_t s_id[ROUND];
     __shared__ float s_thr[ROUND];                // ln(1 / (255 opacity)): alpha >= 1/255  <=>  power >= s_thr
     __shared__ float s_acc[ROUND * kAcc];
+    __shared__ uint32_t s_mask[ROUND];            // strip_alive_mask per staged entry (0 beyond the list end)
     __shared__ uint32_t s_wmax[4];
 
     const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
@@ -256,7 +324,8 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
     const uint32_t view = tile / tpv;
     const uint32_t lt = tile - view * tpv;
     const uint32_t ty = lt / gx, tx = lt - ty * gx;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t px = tx * kTile + (tid & 15u);
     const float pixf_x = (float)px;
     const size_t HW = (size_t)H * W;
@@ -265,6 +334,11 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
     const int total = (int)(range.y - range.x);
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const float bg0 = bg_color[0], bg1 = bg_color[1], bg2 = bg_color[2];
+
+    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
+    uint32_t wave_strips = 0;                     // slot q of this wave covers strip wave + q * WAVES
+#pragma unroll
+    for (int q = 0; q < PPL; q++) wave_strips |= 1u << (wave + q * WAVES);
 
     PixState ps[PPL];
     uint32_t lane_max = 0;
@@ -309,18 +383,36 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
         const int round_base = i * ROUND;
         const int n = min(ROUND, total - round_base);
         __syncthreads();  // previous round's flush is complete
-        for (int e = tid; e < n; e += THREADS) {
-            const uint32_t id = point_list[range.y - (uint32_t)(round_base + e) - 1];
-            s_id[e] = id;
-            s_xy[e] = means2D[id];
-            const float4 c4 = conic_opacity[id];
-            s_co[e] = c4;
-            s_thr[e] = -__logf(255.0f * c4.w);
-            s_fd[e] = rgbd[id];
+        {
+            const int e = (int)tid;                   // ROUND == THREADS: one entry per thread
+            uint32_t alive = 0;
+            if (e < n) {
+                const uint32_t id = point_list[range.y - (uint32_t)(round_base + e) - 1];
+                s_id[e] = id;
+                const float2 xy = means2D[id];
+                s_xy[e] = xy;
+                const float4 c4 = conic_opacity[id];
+                s_co[e] = c4;
+                const float thr = -__logf(255.0f * c4.w);
+                s_thr[e] = thr;
+                s_fd[e] = rgbd[id];
+                alive = strip_alive_mask(xy, c4, -thr + 1e-2f + 1e-3f * fabsf(thr), tile_x0, tile_y0);
+            }
+            s_mask[e] = alive;
         }
         __syncthreads();
         if (wmax != 0) {
-            for (int j = max(0, first_p_wave - round_base); j < n; j++) {
+            const int jstart = max(0, first_p_wave - round_base);
+            for (int c = jstart & ~63; c < n; c += 64) {
+              // 64 entries' strip bits -> scalar bitmap of the entries that can reach one of this wave's strips
+              const uint32_t mv = s_mask[c + lane];
+              uint64_t bits = __builtin_amdgcn_ballot_w64((mv & wave_strips) != 0);
+              if (c < jstart) bits &= ~0ull << (jstart - c);
+              while (bits) {
+                const int jl = (int)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                const int j = c + jl;
+                const uint32_t mj = PPL > 1 ? (uint32_t)__builtin_amdgcn_readlane((int)mv, jl) : 0u;
                 const uint32_t ordinal = (uint32_t)(total - 1 - (round_base + j));
                 const float2 xy = s_xy[j];
                 const float4 co = s_co[j];
@@ -334,6 +426,7 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
                 bool any_valid = false;
 #pragma unroll
                 for (int q = 0; q < PPL; q++) {
+                    if (PPL > 1 && !((mj >> (wave + q * WAVES)) & 1u)) continue;   // strip of slot q cannot be reached
                     PixState& p = ps[q];
                     const float dy = xy.y - p.pixf_y;
                     const float power = fmaf(fmaf(pc, dy, pb), dy, pa);
@@ -394,6 +487,7 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
                     else atomicAdd(&s_acc[j * kAcc + vid], z);
                 }
 #endif
+              }
             }
         }
         __syncthreads();
@@ -430,9 +524,11 @@ void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int
                             const float* dL_dalphas, float* acc)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
-    // pixels per lane: fewer, fatter lanes amortise the per-entry wave reduction; needs enough tiles to
-    // fill 256 CUs x 4 SIMDs (GD_RASTER_BWD_PPL overrides, for tuning)
-    int ppl = tiles_total >= 2048 ? 2 : 1;   // measured: 893 us (2) vs 931 (1) vs 959 (4) at 8192 tiles
+    // pixels per lane (GD_RASTER_BWD_PPL overrides, for tuning).  With the per-strip culling each wave of the
+    // PPL = 1 kernel walks only the entries that can reach ITS 16x4 strip; fatter lanes (PPL 2 / 4) share the
+    // per-entry reduction between strips but must walk the union of their strips' entries.  Measured at 8192
+    // tiles (8 views x 512^2, 100k Gaussians): 857 us (1) vs 889 (2) vs 911 (4).
+    int ppl = 1;
     if (const char* e = getenv("GD_RASTER_BWD_PPL")) ppl = atoi(e);
 #define GD_BWD(PPL_)                                                                                               \
     hipLaunchKernelGGL(render_backward_kernel<PPL_>, dim3(tiles_total), dim3(kTilePix / PPL_), 0, s, W, H,         \

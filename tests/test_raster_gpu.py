@@ -62,11 +62,11 @@ def _check_forward(inp, st, out, exact_ncontrib=True):
     return sc
 
 
-def _check_grads(name, g, o, rtol=1e-3):
+def _check_grads(name, g, o, rtol=1e-3, atol_scale=2e-5):
     g = g.detach().cpu().numpy().reshape(o.shape)
     scale = np.abs(o).max() + 1e-20
     err = np.abs(g - o)
-    tol = rtol * np.abs(o) + 2e-5 * scale
+    tol = rtol * np.abs(o) + atol_scale * scale
     assert (err <= tol).all(), f"{name}: max err {err.max():.3e} at scale {scale:.3e}, {(err > tol).sum()} bad"
 
 
@@ -115,6 +115,64 @@ def test_backward_parity(P, HW, deg):
              "dL_drotations")
     for n, g in zip(names, grads):
         _check_grads(n, g, ref[n])
+
+
+def _needle_inputs(P, HW, seed):
+    """Strongly anisotropic splats (axis ratio up to ~60:1, random orientation) with opacities down to the
+    1/255 threshold: the hard case for the render kernels' per-strip reachability test (a needle that
+    crosses a 16x4 strip diagonally, or clips its corner, must not be dropped)."""
+    inp = h.raster_inputs(P=P, H=HW, W=HW, seed=seed, scale_mul=1.0)
+    rng = np.random.default_rng(seed)
+    sc = inp["scales"].copy()
+    sc[:, 0] *= rng.uniform(5.0, 30.0, size=P).astype(np.float32)
+    sc[:, 1] *= rng.uniform(0.5, 2.0, size=P).astype(np.float32)
+    sc[:, 2] *= rng.uniform(0.3, 1.0, size=P).astype(np.float32)
+    inp["scales"] = sc
+    op = inp["opacities"].copy()
+    op[: P // 4] = rng.uniform(0.002, 0.02, size=(P // 4, 1)).astype(np.float32)   # around and below 1/255
+    inp["opacities"] = op
+    return inp
+
+
+@pytest.mark.parametrize("P,HW,seed", [(3000, 128, 11), (20000, 256, 12)])
+def test_strip_culling_needles_forward_and_backward(P, HW, seed):
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    from oracle import gd_oracle
+    inp = _needle_inputs(P, HW, seed)
+    st = h.oracle_forward(inp)
+    args, out = _run_gpu_forward(inp)
+    sc = _check_forward(inp, st, out)
+    # blended-pair count: culling must not drop a single contributing (pixel, Gaussian) pair
+    ok = sc["n_contrib"][0] == st.n_contrib
+    assert ok.mean() > 0.9999
+    gc, gd, ga = h.random_image_grads(HW, HW, seed=seed)
+    ref = gd_oracle.backward(st, gc, gd, ga)
+    R, color, depth, alpha, radii, geom, binning, img = out
+    t = lambda a: torch.as_tensor(a, device=DEV)
+    (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, _, _) = args
+    for ppl in ("1", "2", "4"):
+        import os
+        os.environ["GD_RASTER_BWD_PPL"] = ppl
+        try:
+            grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx,
+                                                    ty, t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning,
+                                                    img, alpha, False)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["GD_RASTER_BWD_PPL"]
+        names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+                 "dL_drotations")
+        # Needles are ill-conditioned in fp32: power = -0.5 (a dx^2 + c dy^2) - b dx dy cancels terms of ~1e4
+        # down to O(1), so G = exp(power) carries ~1e-3 relative rounding that depends on the expression order
+        # (ours: Horner in dy; the oracle: the reference's source order without contraction; nvcc's own
+        # contraction of the reference is unspecified).  The A/B build without culling (-DGD_NO_STRIP_CULL)
+        # shows the same deviations to 4 digits, i.e. none of it comes from the culling.
+        # Only the render kernel's own accumulators are compared here; the preprocess-backward chain
+        # (cov2D -> cov3D -> scales / rotations) amplifies the same rounding further for 60:1 needles and is
+        # covered at the standard tolerance by test_backward_parity.
+        for n, g in zip(names, grads):
+            if n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity"):
+                _check_grads(f"{n} (ppl {ppl})", g, ref[n], rtol=5e-3, atol_scale=2e-3)
 
 
 def test_colors_precomp_and_cov3d_precomp_paths():
