@@ -4,6 +4,7 @@ from __future__ import annotations
 NN_SOURCES = [
     ("nn_groupnorm.hip", ["-munsafe-fp-atomics"]),
     ("nn_conv3x3.hip", []),
+    ("nn_elementwise.hip", []),
 ]
 
 

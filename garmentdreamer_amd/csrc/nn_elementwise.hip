@@ -1,0 +1,177 @@
+// nn_elementwise.hip -- row-wise fused passes of the UNet's transformer blocks (bf16, inference):
+//
+//   gd_nn_geglu_forward          y = h * gelu(gate),  [h | gate] = the two halves of one GEGLU projection row
+//                                (diffusers GEGLU: hidden, gate = proj(x).chunk(2, -1); hidden * F.gelu(gate)).
+//                                PyTorch runs chunk -> gelu (read+write) -> mul (2 reads + write): 5 row passes,
+//                                the gelu over a strided half at ~2 TB/s; here 3 passes at stream rate.
+//   gd_nn_add_layernorm_forward  s = x + r (optional r, optional store of s);  y = LayerNorm(s) * w + b.
+//                                BasicTransformerBlock: x = x + attn(norm(x)) followed by the next norm
+//                                (threestudio/diffusers attention.py).  PyTorch: add (3 passes) + a LayerNorm
+//                                kernel that reaches ~1 TB/s on C = 320 rows; here 4 passes, one wave per row.
+//
+// Both are pure HBM/MALL streams: 16-byte (8 x bf16) accesses, fp32 math, erf-based (exact) GELU like
+// F.gelu's default.  LayerNorm statistics: two-pass over registers (mean, then centred sum of squares) in
+// fp32, wave-wide DPP/shuffle reduction, no LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gd_nn.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+int fail(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+struct alignas(16) bf16x8 {
+    uint16_t v[8];
+};
+
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// x: [rows][2*inner] (hidden | gate), y: [rows][inner]; one thread per 8 output channels
+__global__ __launch_bounds__(256) void geglu_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y, int64_t nvec,
+                                                    int vin /* inner / 8 */)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / vin;
+        const int c = (int)(i - row * vin);
+        const bf16x8 h = x[row * 2 * vin + c];
+        const bf16x8 g = x[row * 2 * vin + vin + c];
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float gv = bf2f(g.v[k]);
+            // F.gelu on a bf16 tensor rounds its result to bf16 before the multiply; keep that rounding
+            const float ge = bf2f(f2bf(0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f))));
+            o.v[k] = f2bf(bf2f(h.v[k]) * ge);
+        }
+        y[i] = o;
+    }
+}
+
+// One wave per row; VPL = 16-byte vectors per lane (C <= 64 * 8 * VPL).
+template <int VPL>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ r,
+                                                            const bf16x8* __restrict__ w, const bf16x8* __restrict__ b,
+                                                            bf16x8* __restrict__ s_out, bf16x8* __restrict__ y,
+                                                            int64_t rows, int vpr /* C / 8 */, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16x8* xr = x + row * vpr;
+    float v[VPL][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < vpr) {
+            const bf16x8 a = xr[c];
+            if (r) {
+                const bf16x8 rr = r[row * vpr + c];
+                bf16x8 so;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    so.v[k] = f2bf(bf2f(a.v[k]) + bf2f(rr.v[k]));   // the residual stream stays bf16, as in eager
+                    v[i][k] = bf2f(so.v[k]);
+                }
+                if (s_out) s_out[row * vpr + c] = so;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[i][k] = bf2f(a.v[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += v[i][k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[i][k] = 0.f;
+        }
+    }
+    const float inv_c = 1.0f / (float)(vpr * 8);
+    const float mean = wave_sum(sum) * inv_c;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        if (lane + 64 * i < vpr) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float d = v[i][k] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_c + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < vpr) {
+            const bf16x8 ww = w[c], bb = b[c];
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = f2bf((v[i][k] - mean) * rstd * bf2f(ww.v[k]) + bf2f(bb.v[k]));
+            y[row * vpr + c] = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gd_nn_elementwise_last_error(void) { return g_err; }
+
+int gd_nn_geglu_forward(void* stream, const void* x, void* y, int64_t rows, int inner)
+{
+    if (!x || !y) return fail(GD_NN_ERR_INVALID_ARG, "geglu: null pointer");
+    if (rows <= 0 || inner <= 0 || inner % 8) return fail(GD_NN_ERR_INVALID_ARG, "geglu: need inner % 8 == 0");
+    const int64_t nvec = rows * (inner / 8);
+    const int64_t blocks = (nvec + 255) / 256;
+    const int grid = (int)(blocks < 16384 ? blocks : 16384);
+    hipLaunchKernelGGL(geglu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, (bf16x8*)y, nvec,
+                       inner / 8);
+    return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "geglu: launch failed");
+}
+
+int gd_nn_add_layernorm_forward(void* stream, const void* x, const void* residual, const void* weight, const void* bias,
+                                float eps, void* sum_out, void* y, int64_t rows, int C)
+{
+    if (!x || !weight || !bias || !y) return fail(GD_NN_ERR_INVALID_ARG, "add_layernorm: null pointer");
+    if (rows <= 0 || C <= 0 || C % 8 || C > 64 * 8 * 4)
+        return fail(GD_NN_ERR_INVALID_ARG, "add_layernorm: need C % 8 == 0 and C <= 2048");
+    if (sum_out && !residual) return fail(GD_NN_ERR_INVALID_ARG, "add_layernorm: sum_out without residual");
+    const int vpr = C / 8;
+    const int vpl = (vpr + 63) / 64;
+    const int64_t blocks = (rows + 3) / 4;
+    if (blocks > 2147483647LL) return fail(GD_NN_ERR_INVALID_ARG, "add_layernorm: too many rows");
+#define GD_LN(V_)                                                                                                      \
+    hipLaunchKernelGGL(add_layernorm_kernel<V_>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,            \
+                       (const bf16x8*)x, (const bf16x8*)residual, (const bf16x8*)weight, (const bf16x8*)bias,          \
+                       (bf16x8*)sum_out, (bf16x8*)y, rows, vpr, eps)
+    if (vpl == 1) GD_LN(1);
+    else if (vpl == 2) GD_LN(2);
+    else if (vpl == 3) GD_LN(3);
+    else GD_LN(4);
+#undef GD_LN
+    return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "add_layernorm: launch failed");
+}
+
+}  // extern "C"

@@ -34,7 +34,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..nn_ops import conv1x1, conv3x3, conv3x3_small_cin, conv3x3_supported, group_norm_silu
+from ..nn_ops import (add_layer_norm, conv1x1, conv3x3, conv3x3_small_cin, conv3x3_supported, geglu,
+                      group_norm_silu)
 
 
 def _gn(norm: nn.GroupNorm, x, silu: bool):
@@ -145,8 +146,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        h, gate = self.proj(x).chunk(2, dim=-1)
-        return h * F.gelu(gate)
+        return geglu(self.proj(x))   # h * gelu(gate), fused on the GPU (nn_ops.geglu)
 
 
 class FeedForward(nn.Module):
@@ -169,10 +169,12 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, context):
-        x = x + self.attn1(self.norm1(x))
-        x = x + self.attn2(self.norm2(x), context)
-        x = x + self.ff(self.norm3(x))
-        return x
+        # x = x + attn1(norm1(x)); x = x + attn2(norm2(x), ctx); x = x + ff(norm3(x)) with each residual add fused
+        # into the LayerNorm that follows it (nn_ops.add_layer_norm; plain torch ops when gradients are needed)
+        _, n = add_layer_norm(x, None, self.norm1)
+        x, n = add_layer_norm(x, self.attn1(n), self.norm2)
+        x, n = add_layer_norm(x, self.attn2(n, context), self.norm3)
+        return x + self.ff(n)
 
 
 class Transformer2DModel(nn.Module):

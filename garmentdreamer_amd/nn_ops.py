@@ -26,7 +26,10 @@ SIGNATURES = {
     "gd_nn_conv_profile_enable": (_i, [_i]),
     "gd_nn_conv_profile_reset": (_i, []),
     "gd_nn_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "gd_nn_geglu_forward": (_i, [_vp, _vp, _vp, C.c_int64, _i]),
+    "gd_nn_add_layernorm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, C.c_int64, _i]),
     "gd_nn_conv_last_error": (C.c_char_p, []),
+    "gd_nn_elementwise_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
 }
 
@@ -251,3 +254,54 @@ def conv_profile(enable=None, reset=False):
     ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
     L.gd_nn_conv_profile_read(C.byref(ms), C.byref(n), C.byref(fl))
     return ms.value, n.value, fl.value
+
+
+# ---------------------------------------------------------------------------------------------
+# transformer-block row passes (inference): GEGLU, residual add + LayerNorm
+# ---------------------------------------------------------------------------------------------
+
+def _rowwise_ok(*ts):
+    return (not torch.is_grad_enabled() or not any(t.requires_grad for t in ts if t is not None)) and \
+        all(t is None or (t.is_cuda and t.dtype == torch.bfloat16) for t in ts)
+
+
+def geglu(x):
+    """``h * gelu(gate)`` with ``h, gate = x.chunk(2, -1)`` (diffusers GEGLU).  One HIP pass for bf16 GPU
+    tensors that need no gradient; the PyTorch ops otherwise (CPU, fp32, LoRA training)."""
+    inner = x.shape[-1] // 2
+    if _rowwise_ok(x) and inner % 8 == 0 and x.shape[-1] == 2 * inner:
+        x = x.contiguous()
+        y = torch.empty(x.shape[:-1] + (inner,), dtype=x.dtype, device=x.device)
+        L = lib()
+        with torch.cuda.device(x.device):
+            ret = L.gd_nn_geglu_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(),
+                                        x.numel() // (2 * inner), inner)
+        if ret < 0:
+            raise RuntimeError(f"gd_nn_geglu_forward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
+        return y
+    h, gate = x.chunk(2, dim=-1)
+    return h * F.gelu(gate)
+
+
+def add_layer_norm(x, residual, norm, want_sum: bool = True):
+    """``s = x + residual; return s, norm(s)`` (``residual`` None -> ``s = x``).  One HIP pass for bf16 GPU
+    tensors that need no gradient (frozen UNet); the PyTorch ops otherwise."""
+    Cc = x.shape[-1]
+    if _rowwise_ok(x, residual, norm.weight, norm.bias) and Cc % 8 == 0 and Cc <= 2048 and \
+            norm.weight.dtype == torch.bfloat16:
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        s = torch.empty_like(x) if (residual is not None and want_sum) else None
+        y = torch.empty_like(x)
+        L = lib()
+        with torch.cuda.device(x.device):
+            ret = L.gd_nn_add_layernorm_forward(
+                torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
+                None if residual is None else residual.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(),
+                float(norm.eps), None if s is None else s.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc)
+        if ret < 0:
+            raise RuntimeError(f"gd_nn_add_layernorm_forward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
+        return (x if residual is None else s), y
+    s = x if residual is None else x + residual
+    return s, norm(s)

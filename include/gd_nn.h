@@ -62,7 +62,21 @@ int gd_nn_conv_profile_enable(int on);
 int gd_nn_conv_profile_reset(void);
 int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_flops);
 
+/* y[rows, inner] = x[rows, :inner] * gelu(x[rows, inner:])  (erf GELU, bf16, inner % 8 == 0): diffusers'
+ * GEGLU activation of the transformer blocks' feed-forward (``hidden, gate = proj(x).chunk(2, -1);
+ * hidden * F.gelu(gate)``; the UNet skeleton is un-vendored, call site stable_diffusion_guidance.py:153-157).
+ * Replaces chunk + gelu + mul (5 row passes) by one 3-pass kernel.  Inference only. */
+int gd_nn_geglu_forward(void* stream, const void* x, void* y, int64_t rows, int inner);
+
+/* s = x + residual (residual may be NULL -> s = x); if sum_out != NULL store s (bf16) there;
+ * y = LayerNorm_C(s) * weight + bias.  x, residual, sum_out, y: bf16 [rows, C]; weight, bias: bf16 [C];
+ * C % 8 == 0, C <= 2048.  Fuses BasicTransformerBlock's ``x = x + attn(...)`` with the following
+ * ``norm(x)`` (one wave per row, fp32 statistics).  Inference only. */
+int gd_nn_add_layernorm_forward(void* stream, const void* x, const void* residual, const void* weight, const void* bias,
+                                float eps, void* sum_out, void* y, int64_t rows, int C);
+
 const char* gd_nn_conv_last_error(void);
+const char* gd_nn_elementwise_last_error(void);
 const char* gd_nn_last_error(void);
 
 #ifdef __cplusplus

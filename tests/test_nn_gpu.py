@@ -179,3 +179,47 @@ def test_hip_graph_replay_matches_eager_guidance():
     for (l0, g0), (l1, g1) in zip(outs[False], outs[True]):
         assert abs(l0 - l1) <= 2e-2 * abs(l0) + 1e-3, (l0, l1)
         assert F.cosine_similarity(g0.flatten(), g1.flatten(), dim=0).item() > 0.999
+
+
+@pytest.mark.parametrize("rows,inner", [(4096, 1280), (777, 2560), (64, 5120), (3, 8)])
+def test_geglu_matches_fp32_reference_and_eager_bf16(rows, inner):
+    from garmentdreamer_amd.nn_ops import geglu
+    g = torch.Generator(DEV).manual_seed(inner)
+    x = (torch.randn(rows, 2 * inner, device=DEV, generator=g) * 2.0).to(torch.bfloat16)
+    with torch.no_grad():
+        y = geglu(x)
+        h, gate = x.chunk(2, dim=-1)
+        eager = h * F.gelu(gate)
+        ref = h.float() * F.gelu(gate.float())
+    assert y.shape == (rows, inner) and y.dtype == torch.bfloat16
+    assert (y.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-3   # two bf16 roundings
+    # same rounding points as the eager bf16 ops -> (almost) bit-identical; allow 1 bf16 ulp for erf
+    assert (y.float() - eager.float()).abs().max().item() <= 2 ** -7 * eager.float().abs().max().item()
+    assert (y != eager).float().mean().item() < 1e-2
+
+
+@pytest.mark.parametrize("rows,C,with_res", [(4096, 320, True), (1024, 640, True), (256, 1280, True), (64, 1280, False),
+                                             (5, 2048, True), (7, 8, True)])
+def test_add_layernorm_matches_fp32_reference(rows, C, with_res):
+    from garmentdreamer_amd.nn_ops import add_layer_norm
+    g = torch.Generator(DEV).manual_seed(C + rows)
+    x = (torch.randn(rows, C, device=DEV, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    r = (torch.randn(rows, C, device=DEV, generator=g)).to(torch.bfloat16) if with_res else None
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, device=DEV, generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(C, device=DEV, generator=g) * 0.3)
+    norm = norm.to(torch.bfloat16)
+    with torch.no_grad():
+        s, y = add_layer_norm(x, r, norm)
+        s_ref = x if r is None else x + r                     # the residual stream is bf16 in eager too
+        y_ref = F.layer_norm(s_ref.float(), (C,), norm.weight.float(), norm.bias.float(), norm.eps)
+    assert torch.equal(s, s_ref)
+    assert y.dtype == torch.bfloat16 and y.shape == x.shape
+    err = (y.float() - y_ref).abs().max().item()
+    assert err <= 1e-2 * y_ref.abs().max().item() + 1e-2, err    # one bf16 output rounding
+    # with gradients required the wrapper must leave the autograd path intact
+    x2 = x.clone().requires_grad_(True)
+    s2, y2 = add_layer_norm(x2, r, norm)
+    y2.float().sum().backward()
+    assert x2.grad is not None and torch.isfinite(x2.grad).all()
