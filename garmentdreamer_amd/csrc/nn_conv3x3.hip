@@ -87,13 +87,28 @@ __device__ __forceinline__ void bload_lds16(__amdgpu_buffer_rsrc_t rsrc, uint32_
 
 constexpr uint32_t kOOB = 0x80000000u;   // voffset that fails the buffer range check (tensors are < 2 GiB)
 
+// Geometry of one implicit-GEMM launch.  GEMM row m = (image n, grid point (a, b)) on an Hg x Wg grid; its
+// K dimension walks `ntaps` taps x Cin channels, tap t reading input pixel (a*sy + ty[t], b*sx + tx[t]) (zero
+// outside the image) against weight tap widx[t] of the [Cout][9][Cin] weight tensor; the result goes to output
+// pixel (a*osy + ooy, b*osx + oox) of an Hout x Wout image.  This one description covers
+//   3x3 / stride 1 / pad 1        : grid = image, taps (ky-1, kx-1)
+//   3x3 / stride 2 / pad (lo, 1)  : grid = output image, sy = sx = 2, taps (ky - lo, kx - lo)
+//   input gradient of the latter  : four launches, one per input-pixel parity class (py, px), each with only the
+//                                   taps that reach that class (4 + 2 + 2 + 1 = 9 taps in total, no zero-insertion
+//                                   waste), osy = osx = 2, (ooy, oox) = (py, px).
+// ty / tx / widx are packed 4 bits per tap (ty, tx biased by +8) so the tap walk stays in scalar registers.
+struct ConvGeom {
+    int Hin, Win, Hg, Wg, sy, sx, Hout, Wout, osy, osx, ooy, oox, ntaps, back;
+    uint64_t ty4, tx4, w4;
+};
+
 // Tile = BN output channels x BM pixels, WN x WM waves, each wave (BN/WN) x (BM/WM) built from
 // 32x32x16 MFMAs.  bias_img_stride: 0 -> bias[co]; Cout -> bias[n][co].
 template <int BN, int BM, int WN, int WM>
 __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
-    int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, int H, int W,
-    int Cin, int Cout, const uint16_t* __restrict__ zeros, int tiles_n, int nwg)
+    int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, const ConvGeom g,
+    int Cin, int Cout, int tiles_n, int nwg)
 {
     constexpr int THREADS = 64 * WN * WM;
     constexpr int NA = BM * 8 / THREADS;      // 16-B chunks of the pixel tile per thread per K-step
@@ -102,7 +117,6 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     constexpr int FB = BM / WM / 32;          // ... along pixels
     constexpr int kStage = (BM + BN) * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    (void)zeros;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware tile order: consecutive logical tiles (same pixel tile, different Cout tile, then
@@ -111,16 +125,18 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int tn = bid % tiles_n, tm = bid / tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int HW = H * W;
+    const int HW = g.Hg * g.Wg;
     const int64_t M = (int64_t)Nimg * HW;
+    const int H = g.Hin, W = g.Win;
 
-    // Buffer descriptors.  The activation descriptor's base is moved back by one image row + one
-    // pixel so that per-lane voffsets (pixel m, chunk) and the wave-uniform soffset (tap, channel
-    // step) are both non-negative; valid lanes never address bytes before `in`.
+    // Buffer descriptors.  The activation descriptor's base is moved back by `back` pixels (one image row +
+    // one pixel for the pad-1 convolution) so that per-lane voffsets (base pixel of row m, chunk) and the
+    // wave-uniform soffset (tap, channel step) are both non-negative; valid lanes never address bytes
+    // before `in`.
     const uint32_t row_bytes = (uint32_t)Cin * 2u;
-    const uint32_t back = ((uint32_t)W + 1u) * row_bytes;
+    const uint32_t back = (uint32_t)g.back * row_bytes;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)in - back), 0, (int)((uint32_t)(M * row_bytes) + back), 0x00020000);
+        (void*)((const char*)in - back), 0, (int)((uint32_t)Nimg * (uint32_t)(H * W) * row_bytes + back), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         (void*)wt, 0, (int)((uint32_t)Cout * 9u * row_bytes), 0x00020000);
 
@@ -141,9 +157,10 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
         if (m < M) {
             const int nimg = (int)(m / HW);
             const int rem = (int)(m - (int64_t)nimg * HW);
-            a_y[i] = rem / W;
-            a_x[i] = rem - a_y[i] * W;
-            a_off[i] = (uint32_t)m * row_bytes + (uint32_t)(c & 7) * 16u;
+            const int ga = rem / g.Wg;
+            a_y[i] = ga * g.sy;
+            a_x[i] = (rem - ga * g.Wg) * g.sx;
+            a_off[i] = (uint32_t)((nimg * H + a_y[i]) * W + a_x[i]) * row_bytes + (uint32_t)(c & 7) * 16u;
         } else {
             a_y[i] = -100000; a_x[i] = 0; a_off[i] = kOOB;
         }
@@ -157,14 +174,14 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
         b_off[i] = co < Cout ? (uint32_t)co * 9u * row_bytes + (uint32_t)(c & 7) * 16u : kOOB;
     }
     const int kc = Cin / BK;         // K-steps per tap
-    const int nsteps = 9 * kc;
+    const int nsteps = g.ntaps * kc;
 
     // loader state: (tap, channel step) of the NEXT stage to fetch; halo validity is re-evaluated
     // once per tap, the per-K-step cost is one scalar add
     int ld_tap = 0, ld_c = 0;
     uint32_t a_voff[NA];
     auto set_tap = [&](int tap) {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int dy = (int)((g.ty4 >> (4 * tap)) & 15u) - 8, dx = (int)((g.tx4 >> (4 * tap)) & 15u) - 8;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
@@ -176,9 +193,9 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     auto issue = [&](int buf) {
         char* sA = smem + buf * kStage;                      // pixel tile  [BM][64] bf16
         char* sB = sA + BM * BK * 2;                         // weight tile [BN][64] bf16
-        const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
-        const uint32_t soff_a = (uint32_t)(ky * W + kx) * row_bytes + (uint32_t)ld_c * (BK * 2);
-        const uint32_t soff_b = (uint32_t)ld_tap * row_bytes + (uint32_t)ld_c * (BK * 2);
+        const int dy = (int)((g.ty4 >> (4 * ld_tap)) & 15u) - 8, dx = (int)((g.tx4 >> (4 * ld_tap)) & 15u) - 8;
+        const uint32_t soff_a = (uint32_t)(dy * W + dx + g.back) * row_bytes + (uint32_t)ld_c * (BK * 2);
+        const uint32_t soff_b = (uint32_t)((g.w4 >> (4 * ld_tap)) & 15u) * row_bytes + (uint32_t)ld_c * (BK * 2);
 #if GD_CONV_ABLATE != 1 && GD_CONV_ABLATE != 2 && GD_CONV_ABLATE < 6
 #pragma unroll
         for (int i = 0; i < NA; i++) bload_lds16(rs_in, a_voff[i], soff_a, sA + (wave * 64 + THREADS * i) * 16);
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
 #endif
         if (++ld_c == kc) {
             ld_c = 0;
-            if (++ld_tap < 9) set_tap(ld_tap);
+            if (++ld_tap < g.ntaps) set_tap(ld_tap);
         }
     };
 
@@ -262,6 +279,9 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
         const int64_t m = (int64_t)m0 + wp * (BM / WM) + b * 32 + (lane & 31);
         if (m >= M) continue;
         const int nimg = (int)(m / HW);
+        const int rem = (int)(m - (int64_t)nimg * HW);
+        const int ga = rem / g.Wg, gb = rem - ga * g.Wg;
+        const size_t opix = ((size_t)nimg * g.Hout + (size_t)(ga * g.osy + g.ooy)) * g.Wout + (size_t)(gb * g.osx + g.oox);
         const uint16_t* bias_n = bias ? bias + (size_t)nimg * bias_img_stride : nullptr;
 #pragma unroll
         for (int a = 0; a < FA; a++) {
@@ -278,14 +298,14 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
                     v[2] += bf2f((uint16_t)(bb.y & 0xffff)); v[3] += bf2f((uint16_t)(bb.y >> 16));
                 }
                 if (residual) {
-                    const uint2 rr = *(const uint2*)(residual + (size_t)m * Cout + co);
+                    const uint2 rr = *(const uint2*)(residual + opix * Cout + co);
                     v[0] += bf2f((uint16_t)(rr.x & 0xffff)); v[1] += bf2f((uint16_t)(rr.x >> 16));
                     v[2] += bf2f((uint16_t)(rr.y & 0xffff)); v[3] += bf2f((uint16_t)(rr.y >> 16));
                 }
                 uint2 o;
                 o.x = pack_bf16(v[0], v[1]);
                 o.y = pack_bf16(v[2], v[3]);
-                *(uint2*)(out + (size_t)m * Cout + co) = o;
+                *(uint2*)(out + opix * Cout + co) = o;
             }
         }
     }
@@ -304,7 +324,6 @@ __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint
     }
 }
 
-uint16_t* g_zeros[16] = {nullptr};
 int g_force_variant = -1;  // tuning hook: 0 = 128x128, 1 = 128x256, 2 = 256x256, -1 = heuristic
 
 // optional event timing of the conv kernel (bench.py's roofline line)
@@ -337,23 +356,23 @@ extern "C" {
 
 const char* gd_nn_conv_last_error(void) { return g_err; }
 
-int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const void* bias, int bias_img_stride,
-                          const void* residual, void* y, int N, int H, int W, int Cin, int Cout)
+// host side of one launch: tile variant choice, event profiling, kernel launch
+static int launch_conv(hipStream_t s, const void* x, const void* weight, const void* bias, int bias_img_stride,
+                       const void* residual, void* y, int N, ConvGeom g, int Cin, int Cout)
 {
-    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
-    if (N <= 0 || H <= 0 || W <= 0 || Cin % BK || Cout % 4 || Cin <= 0 || Cout <= 0)
-        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3: need Cin % 64 == 0 and Cout % 4 == 0");
-    if ((double)N * H * W * Cin * 2.0 + ((double)W + 1.0) * Cin * 2.0 >= 2147483648.0 ||
-        (double)Cout * 9.0 * Cin * 2.0 >= 2147483648.0)
-        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3: activation / weight tensor must be < 2 GiB (32-bit buffer offsets)");
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
-    hipStream_t s = (hipStream_t)stream;
-    if (!g_zeros[dev]) {
-        if (hipMalloc((void**)&g_zeros[dev], 256) != hipSuccess) return fail(GD_NN_ERR_HIP, "hipMalloc failed");
-        if (hipMemset(g_zeros[dev], 0, 256) != hipSuccess) return fail(GD_NN_ERR_HIP, "hipMemset failed");
+    // taps -> how far the activation descriptor must reach back so every soffset is >= 0
+    int minlin = 0;
+    for (int t = 0; t < g.ntaps; t++) {
+        const int dy = (int)((g.ty4 >> (4 * t)) & 15u) - 8, dx = (int)((g.tx4 >> (4 * t)) & 15u) - 8;
+        minlin = dy * g.Win + dx < minlin ? dy * g.Win + dx : minlin;
     }
-    const int64_t M = (int64_t)N * H * W;
+    g.back = -minlin;
+    if (((double)N * g.Hin * g.Win + g.back) * Cin * 2.0 >= 2147483648.0 || (double)Cout * 9.0 * Cin * 2.0 >= 2147483648.0)
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3: activation / weight tensor must be < 2 GiB (32-bit buffer offsets)");
+    const int64_t M = (int64_t)N * g.Hg * g.Wg;
+    if (M <= 0) return GD_NN_OK;
     // tile choice: the 256x256 / 8-wave tile has twice the MFMA work per byte staged through LDS;
     // use it when Cout fills it and there are enough tiles for 256 CUs, else 128 channels x 256
     // pixels, else the 128x128 / 4-wave tile.
@@ -387,8 +406,7 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
         const int nwg = tiles_m * tiles_n;                                                                         \
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WN_ * WM_), lds, s, (const uint16_t*)x,                      \
                            (const uint16_t*)weight, (const uint16_t*)bias, bias_img_stride,                        \
-                           (const uint16_t*)residual, (uint16_t*)y, N, H, W, Cin, Cout, g_zeros[dev], tiles_n,     \
-                           nwg);                                                                                   \
+                           (const uint16_t*)residual, (uint16_t*)y, N, g, Cin, Cout, tiles_n, nwg);                \
     } while (0)
     if (variant == 2) GD_LAUNCH(256, 256, 2, 4);
     else if (variant == 1) GD_LAUNCH(128, 256, 2, 4);
@@ -398,10 +416,82 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
         (void)hipEventRecord(eb, s);
         std::lock_guard<std::mutex> lk(g_cprof.mu);
         g_cprof.pending.push_back({ea, eb});
-        g_cprof.total_flops += 2.0 * (double)M * Cout * 9.0 * Cin;
+        g_cprof.total_flops += 2.0 * (double)M * Cout * (double)g.ntaps * Cin;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+static void add_tap(ConvGeom& g, int dy, int dx, int widx)
+{
+    g.ty4 |= (uint64_t)(dy + 8) << (4 * g.ntaps);
+    g.tx4 |= (uint64_t)(dx + 8) << (4 * g.ntaps);
+    g.w4 |= (uint64_t)widx << (4 * g.ntaps);
+    g.ntaps++;
+}
+
+int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const void* bias, int bias_img_stride,
+                          const void* residual, void* y, int N, int H, int W, int Cin, int Cout)
+{
+    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || Cin % BK || Cout % 4 || Cin <= 0 || Cout <= 0)
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3: need Cin % 64 == 0 and Cout % 4 == 0");
+    ConvGeom g = {};
+    g.Hin = g.Hg = g.Hout = H;
+    g.Win = g.Wg = g.Wout = W;
+    g.sy = g.sx = g.osy = g.osx = 1;
+    for (int ky = 0; ky < 3; ky++)
+        for (int kx = 0; kx < 3; kx++) add_tap(g, ky - 1, kx - 1, ky * 3 + kx);
+    return launch_conv((hipStream_t)stream, x, weight, bias, bias_img_stride, residual, y, N, g, Cin, Cout);
+}
+
+int gd_nn_conv3x3_s2_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int Hin,
+                             int Win, int Cin, int Cout, int pad_lo)
+{
+    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || Hin < 2 || Win < 2 || Cin % BK || Cout % 4 || Cin <= 0 || Cout <= 0 || (pad_lo != 0 && pad_lo != 1))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3 s2: need Cin % 64 == 0, Cout % 4 == 0, pad_lo in {0, 1}");
+    ConvGeom g = {};
+    g.Hin = Hin; g.Win = Win;
+    g.Hg = g.Hout = (Hin + pad_lo - 2) / 2 + 1;      // pad (pad_lo, 1): floor((Hin + pad_lo + 1 - 3) / 2) + 1
+    g.Wg = g.Wout = (Win + pad_lo - 2) / 2 + 1;
+    g.sy = g.sx = 2;
+    g.osy = g.osx = 1;
+    for (int ky = 0; ky < 3; ky++)
+        for (int kx = 0; kx < 3; kx++) add_tap(g, ky - pad_lo, kx - pad_lo, ky * 3 + kx);
+    return launch_conv((hipStream_t)stream, x, weight, bias, 0, nullptr, y, N, g, Cin, Cout);
+}
+
+int gd_nn_conv3x3_s2_dgrad(void* stream, const void* dy, const void* weight_flipped, void* dx, int N, int Hin, int Win,
+                           int Cin, int Cout, int pad_lo)
+{
+    if (!dy || !weight_flipped || !dx) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || Hin < 2 || Win < 2 || Cout % BK || Cin % 4 || Cin <= 0 || Cout <= 0 || (pad_lo != 0 && pad_lo != 1))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3 s2 dgrad: need Cout % 64 == 0, Cin % 4 == 0, pad_lo in {0, 1}");
+    const int Ho = (Hin + pad_lo - 2) / 2 + 1, Wo = (Win + pad_lo - 2) / 2 + 1;
+    // dx[2a+py, 2b+px] = sum over (ky, kx) with (py + pad - ky), (px + pad - kx) even of
+    //                    dy[a + (py + pad - ky)/2, b + (px + pad - kx)/2] . w[:, ky, kx, :]
+    // weight_flipped[ci][8 - (3 ky + kx)][co] = w[co][ky][kx][ci]  (gd_nn_conv3x3_flip_weights)
+    for (int py = 0; py < 2; py++)
+        for (int px = 0; px < 2; px++) {
+            ConvGeom g = {};
+            g.Hin = Ho; g.Win = Wo;
+            g.Hg = (Hin - py + 1) / 2; g.Wg = (Win - px + 1) / 2;
+            g.sy = g.sx = 1;
+            g.Hout = Hin; g.Wout = Win;
+            g.osy = g.osx = 2; g.ooy = py; g.oox = px;
+            for (int ky = 0; ky < 3; ky++) {
+                if ((py + pad_lo - ky) & 1) continue;
+                for (int kx = 0; kx < 3; kx++) {
+                    if ((px + pad_lo - kx) & 1) continue;
+                    add_tap(g, (py + pad_lo - ky) / 2, (px + pad_lo - kx) / 2, 8 - (ky * 3 + kx));
+                }
+            }
+            if (g.Hg <= 0 || g.Wg <= 0) continue;
+            const int r = launch_conv((hipStream_t)stream, dy, weight_flipped, nullptr, 0, nullptr, dx, N, g, Cout, Cin);
+            if (r < 0) return r;
+        }
     return GD_NN_OK;
 }
 

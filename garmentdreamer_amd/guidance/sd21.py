@@ -34,8 +34,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..nn_ops import (add_layer_norm, conv1x1, conv3x3, conv3x3_small_cin, conv3x3_supported, geglu,
-                      group_norm_silu)
+from ..nn_ops import (add_layer_norm, conv1x1, conv3x3, conv3x3_s2, conv3x3_s2_supported, conv3x3_small_cin,
+                      conv3x3_supported, geglu, group_norm_silu)
 
 
 def _gn(norm: nn.GroupNorm, x, silu: bool):
@@ -204,6 +204,9 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=padding)
 
     def forward(self, x):
+        if conv3x3_s2_supported(x, self.conv.weight):
+            # stride-2 MFMA kernel; the VAE encoder's asymmetric pad (0,1,0,1) is part of its tap geometry
+            return conv3x3_s2(x, self.conv.weight, self.conv.bias, self.padding)
         if self.padding == 0:  # VAE encoder: asymmetric pad (0,1,0,1)
             x = F.pad(x, (0, 1, 0, 1))
         return self.conv(x)

@@ -22,6 +22,8 @@ SIGNATURES = {
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
+    "gd_nn_conv3x3_s2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_s2_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "gd_nn_conv_force_variant": (_i, [_i]),
     "gd_nn_conv_profile_enable": (_i, [_i]),
     "gd_nn_conv_profile_reset": (_i, []),
@@ -254,6 +256,63 @@ def conv_profile(enable=None, reset=False):
     ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
     L.gd_nn_conv_profile_read(C.byref(ms), C.byref(n), C.byref(fl))
     return ms.value, n.value, fl.value
+
+
+class _Conv3x3S2(torch.autograd.Function):
+    """3x3 / stride 2 / pad (pad_lo, 1) convolution, frozen weights: forward and input gradient on the MFMA kernel
+    (the gradient as four parity-class launches)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad_lo):
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        Ho, Wo = (H + pad_lo - 2) // 2 + 1, (W + pad_lo - 2) // 2 + 1
+        y = torch.empty((N, Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        L = lib()
+        with torch.cuda.device(x.device):
+            ret = L.gd_nn_conv3x3_s2_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
+                                             weight.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                             N, H, W, Cin, Cout, pad_lo)
+        if ret < 0:
+            raise RuntimeError(f"gd_nn_conv3x3_s2_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+        ctx.weight, ctx.pad_lo, ctx.in_shape = weight, pad_lo, (N, Cin, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Cin, H, W = ctx.in_shape
+        Cout = ctx.weight.shape[0]
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = torch.empty((N, Cin, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+        wf = _flipped(ctx.weight)
+        L = lib()
+        with torch.cuda.device(dy.device):
+            ret = L.gd_nn_conv3x3_s2_dgrad(torch.cuda.current_stream(dy.device).cuda_stream, dy.data_ptr(), wf.data_ptr(),
+                                           dx.data_ptr(), N, H, W, Cin, Cout, ctx.pad_lo)
+        if ret < 0:
+            raise RuntimeError(f"gd_nn_conv3x3_s2_dgrad failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+        return dx, None, None, None
+
+
+def conv3x3_s2_supported(x, weight) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4
+            and weight.shape[2:] == (3, 3) and x.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0
+            and x.shape[2] >= 2 and x.shape[3] >= 2 and not weight.requires_grad)
+
+
+def conv3x3_s2(x, weight, bias, pad_lo: int):
+    """``conv2d(pad(x, (pad_lo, 1, pad_lo, 1)), weight, bias, stride=2)`` for frozen bf16 weights on the GPU."""
+    if not conv3x3_s2_supported(x, weight):
+        raise RuntimeError("conv3x3_s2: unsupported tensor (need bf16 GPU NHWC, Cin % 64 == 0, Cout % 64 == 0)")
+    if bias is not None and bias.requires_grad:
+        raise RuntimeError("conv3x3_s2 computes input gradients only (frozen weights)")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    w = weight if weight.is_contiguous(memory_format=torch.channels_last) else \
+        weight.contiguous(memory_format=torch.channels_last)
+    return _Conv3x3S2.apply(x, w, bias, pad_lo)
 
 
 # ---------------------------------------------------------------------------------------------

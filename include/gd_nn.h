@@ -62,6 +62,21 @@ int gd_nn_conv_profile_enable(int on);
 int gd_nn_conv_profile_reset(void);
 int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_flops);
 
+/* 3x3 convolution with stride 2 and padding (pad_lo, 1) per spatial dim -- pad_lo = 1: Conv2d(k3, s2, p1), the
+ * UNet's Downsample2D; pad_lo = 0: the VAE encoder's F.pad(x, (0,1,0,1)) + Conv2d(k3, s2, p0) (diffusers
+ * Downsample2D; un-vendored, reached through stable_diffusion_guidance.py:153-166) without materialising the
+ * padded tensor.  x: bf16 [N,Hin,Win,Cin]; weight: bf16 [Cout][3][3][Cin]; bias: bf16 [Cout] or NULL;
+ * y: bf16 [N,Ho,Wo,Cout], Ho = (Hin + pad_lo - 2) / 2 + 1.  Same MFMA kernel as gd_nn_conv3x3_forward. */
+int gd_nn_conv3x3_s2_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int Hin,
+                             int Win, int Cin, int Cout, int pad_lo);
+
+/* Input gradient of gd_nn_conv3x3_s2_forward: dx[N,Hin,Win,Cin] from dy[N,Ho,Wo,Cout] and
+ * weight_flipped = gd_nn_conv3x3_flip_weights(weight) ([Cin][3][3][Cout]).  Four launches, one per parity
+ * class of the input pixel, each walking only the taps that reach it (9 taps in total: no zero-insertion
+ * waste); every dx element is written exactly once.  Needs Cout % 64 == 0. */
+int gd_nn_conv3x3_s2_dgrad(void* stream, const void* dy, const void* weight_flipped, void* dx, int N, int Hin, int Win,
+                           int Cin, int Cout, int pad_lo);
+
 /* y[rows, inner] = x[rows, :inner] * gelu(x[rows, inner:])  (erf GELU, bf16, inner % 8 == 0): diffusers'
  * GEGLU activation of the transformer blocks' feed-forward (``hidden, gate = proj(x).chunk(2, -1);
  * hidden * F.gelu(gate)``; the UNet skeleton is un-vendored, call site stable_diffusion_guidance.py:153-157).

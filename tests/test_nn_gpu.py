@@ -223,3 +223,32 @@ def test_add_layernorm_matches_fp32_reference(rows, C, with_res):
     s2, y2 = add_layer_norm(x2, r, norm)
     y2.float().sum().backward()
     assert x2.grad is not None and torch.isfinite(x2.grad).all()
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,pad_lo", [(2, 128, 128, 32, 32, 0), (1, 256, 256, 17, 23, 0), (2, 320, 320, 16, 16, 1),
+                                                   (1, 64, 192, 9, 14, 1), (3, 128, 64, 6, 5, 0), (1, 512, 512, 64, 64, 0)])
+def test_conv3x3_stride2_forward_and_dgrad_match_fp32_reference(N, Cin, Cout, H, W, pad_lo):
+    """Downsample2D: UNet Conv2d(k3,s2,p1) (pad_lo 1) and the VAE's F.pad(0,1,0,1)+Conv2d(k3,s2,p0) (pad_lo 0)."""
+    from garmentdreamer_amd.nn_ops import conv3x3_s2
+    g = torch.Generator(DEV).manual_seed(Cin + H)
+    x = torch.randn(N, Cin, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (3 * Cin ** 0.5)).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    b = torch.randn(Cout, device=DEV, generator=g).to(torch.bfloat16)
+    x.requires_grad_(True)
+    y = conv3x3_s2(x, w, b, pad_lo)
+    xr = x.detach().float().requires_grad_(True)
+    xp = F.pad(xr, (pad_lo, 1, pad_lo, 1))
+    yr = F.conv2d(xp, w.float(), b.float(), stride=2)
+    assert y.shape == yr.shape and y.dtype == torch.bfloat16
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    err = (y.float() - yr).abs().max().item()
+    assert err <= 1e-2 * yr.abs().max().item() + 1e-2, err
+    gy = torch.randn(yr.shape, device=DEV, generator=g).to(torch.bfloat16)
+    y.backward(gy)
+    yr.backward(gy.float())
+    assert x.grad.shape == x.shape
+    gerr = (x.grad.float() - xr.grad).abs().max().item()
+    assert gerr <= 1e-2 * xr.grad.abs().max().item() + 1e-3, gerr
+    cos = F.cosine_similarity(x.grad.float().flatten(), xr.grad.flatten(), dim=0).item()
+    assert cos > 0.9999, cos
