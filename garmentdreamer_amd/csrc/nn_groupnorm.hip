@@ -95,6 +95,19 @@ __global__ void gn_stats_kernel(const bf16x8* __restrict__ x, int HW, int C, int
     reduce_to_groups(s, ss, vpp, rows, tv, tr, C, G, ws + (size_t)n * G * 2, lds);
 }
 
+// ws[n][g] = {sum, sum of squares} (fp64)  ->  mean_rstd[n][g] = {mean, rstd} (same arithmetic as gn_apply_kernel)
+__global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean_rstd, int NG, double M,
+                                   float eps)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NG) return;
+    const double mean = ws[2 * i] / M;
+    double var = ws[2 * i + 1] / M - mean * mean;
+    var = var < 0 ? 0 : var;
+    mean_rstd[2 * i] = (float)mean;
+    mean_rstd[2 * i + 1] = rsqrtf((float)var + eps);
+}
+
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 
 __global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y,
@@ -280,6 +293,25 @@ int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const voi
                        g.ppb_stats, stats_ws);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (bf16x8*)y, (const uint16_t*)gamma,
                        (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, eps, apply_silu, stats_ws, mean_rstd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_groupnorm_stats(void* stream, const void* x, int N, int HW, int C, int G, float eps, double* stats_ws,
+                          float* mean_rstd)
+{
+    Geo g;
+    if (!x || !stats_ws || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats_ws, 0, gd_nn_groupnorm_ws_bytes(N, G), s) != hipSuccess)
+        return fail(GD_NN_ERR_HIP, "hipMemsetAsync failed");
+    dim3 block(g.threads), grid_s(g.nchunks_stats, N);
+    hipLaunchKernelGGL(gn_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows,
+                       g.ppb_stats, stats_ws);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * G + 255) / 256), dim3(256), 0, s, stats_ws, mean_rstd, N * G,
+                       (double)HW * (C / G), eps);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

@@ -22,6 +22,8 @@ SIGNATURES = {
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
+    "gd_nn_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "gd_nn_conv3x3_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "gd_nn_conv_force_variant": (_i, [_i]),
@@ -256,6 +258,80 @@ def conv_profile(enable=None, reset=False):
     ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
     L.gd_nn_conv_profile_read(C.byref(ms), C.byref(n), C.byref(fl))
     return ms.value, n.value, fl.value
+
+
+class _GNConv3x3(torch.autograd.Function):
+    """``conv3x3(act(group_norm(x))) + bias (+ residual)`` as statistics pass + ONE convolution kernel that
+    normalises / activates in its activation loader (gd_nn_conv3x3_gn_forward).  Backward (frozen weights):
+    dgrad convolution, then the GroupNorm(+SiLU) input-gradient kernel on the saved x and statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gn_weight, gn_bias, groups, eps, silu, weight, bias, residual):
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        L = lib()
+        ws = torch.empty(N * groups * 2, dtype=torch.float64, device=x.device)
+        mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+        y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        gw, gb = gn_weight.contiguous(), gn_bias.contiguous()
+        stride = 0
+        if bias is not None:
+            bias = bias.contiguous()
+            stride = Cout if bias.dim() == 2 else 0
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _check(L.gd_nn_groupnorm_stats(stream, x.data_ptr(), N, H * W, Cin, groups, float(eps), ws.data_ptr(),
+                                           mr.data_ptr()), "gd_nn_groupnorm_stats")
+            ret = L.gd_nn_conv3x3_gn_forward(stream, x.data_ptr(), mr.data_ptr(), gw.data_ptr(), gb.data_ptr(), groups,
+                                             int(silu), weight.data_ptr(), None if bias is None else bias.data_ptr(),
+                                             stride, None if residual is None else residual.data_ptr(), y.data_ptr(),
+                                             N, H, W, Cin, Cout)
+        if ret < 0:
+            raise RuntimeError(f"gd_nn_conv3x3_gn_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+        ctx.save_for_backward(x, gw, gb, mr)
+        ctx.weight, ctx.groups, ctx.silu, ctx.has_res = weight, groups, silu, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gw, gb, mr = ctx.saved_tensors
+        w = ctx.weight
+        N, Cin, H, W = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dact = _conv_launch(dy, _flipped(w), None, None, Cin)          # gradient w.r.t. act(GN(x))
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            ws = torch.empty(N * ctx.groups * 2, dtype=torch.float64, device=x.device)
+            L = lib()
+            with torch.cuda.device(x.device):
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+                _check(L.gd_nn_groupnorm_silu_backward(stream, x.data_ptr(), dact.data_ptr(), gw.data_ptr(),
+                                                       gb.data_ptr(), mr.data_ptr(), dx.data_ptr(), N, H * W, Cin,
+                                                       ctx.groups, int(ctx.silu), ws.data_ptr()),
+                       "gd_nn_groupnorm_silu_backward")
+        return dx, None, None, None, None, None, None, None, (dy if ctx.has_res else None)
+
+
+def gn_conv3x3_supported(x, norm_weight, weight) -> bool:
+    return (conv3x3_supported(x, weight) and weight.shape[0] % 64 == 0 and x.shape[1] % norm_weight.numel() == 0
+            and not norm_weight.requires_grad)
+
+
+def gn_conv3x3(x, norm_weight, norm_bias, groups: int, eps: float, silu: bool, weight, bias=None, residual=None):
+    """Fused ``conv2d(act(group_norm(x)), weight, padding=1) + bias (+ residual)`` for frozen bf16 weights on the
+    GPU; ``bias`` may be per image ([N, Cout])."""
+    if not gn_conv3x3_supported(x, norm_weight, weight):
+        raise RuntimeError("gn_conv3x3: unsupported tensor (need bf16 GPU, Cin % 64 == 0, Cout % 64 == 0)")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    w = weight if weight.is_contiguous(memory_format=torch.channels_last) else \
+        weight.contiguous(memory_format=torch.channels_last)
+    if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+        residual = residual.contiguous(memory_format=torch.channels_last)
+    return _GNConv3x3.apply(x, norm_weight, norm_bias, groups, eps, silu, w, bias, residual)
 
 
 class _Conv3x3S2(torch.autograd.Function):

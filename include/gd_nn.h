@@ -62,6 +62,21 @@ int gd_nn_conv_profile_enable(int on);
 int gd_nn_conv_profile_reset(void);
 int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_flops);
 
+/* GroupNorm statistics only: mean_rstd[N][G][2] = {mean, 1/sqrt(var + eps)} of x (bf16 [N,HW,C]); stats_ws as in
+ * gd_nn_groupnorm_silu_forward.  Feeds gd_nn_conv3x3_gn_forward (and gd_nn_groupnorm_silu_backward). */
+int gd_nn_groupnorm_stats(void* stream, const void* x, int N, int HW, int C, int G, float eps, double* stats_ws,
+                          float* mean_rstd);
+
+/* y = conv3x3_s1_p1( act( GroupNorm_G(x) * gamma + beta ) ) + bias (+ residual): diffusers ResnetBlock2D's
+ * ``conv(nonlinearity(norm(x)))`` (skeleton: Garment_Deformer_NeTF/netf/vsd/lora_unet.py:119-160) as ONE kernel --
+ * the normalised / activated tensor is produced in the convolution's activation loader (16x16 spatial patch
+ * staged once per 64 channels, nine taps read it from LDS) and never written to HBM.  mean_rstd from
+ * gd_nn_groupnorm_stats (NULL: plain convolution of x); act = SiLU if apply_silu.  Other arguments as
+ * gd_nn_conv3x3_forward. */
+int gd_nn_conv3x3_gn_forward(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
+                             int groups, int apply_silu, const void* weight, const void* bias, int bias_img_stride,
+                             const void* residual, void* y, int N, int H, int W, int Cin, int Cout);
+
 /* 3x3 convolution with stride 2 and padding (pad_lo, 1) per spatial dim -- pad_lo = 1: Conv2d(k3, s2, p1), the
  * UNet's Downsample2D; pad_lo = 0: the VAE encoder's F.pad(x, (0,1,0,1)) + Conv2d(k3, s2, p0) (diffusers
  * Downsample2D; un-vendored, reached through stable_diffusion_guidance.py:153-166) without materialising the

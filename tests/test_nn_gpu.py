@@ -252,3 +252,42 @@ def test_conv3x3_stride2_forward_and_dgrad_match_fp32_reference(N, Cin, Cout, H,
     assert gerr <= 1e-2 * xr.grad.abs().max().item() + 1e-3, gerr
     cos = F.cosine_similarity(x.grad.float().flatten(), xr.grad.flatten(), dim=0).item()
     assert cos > 0.9999, cos
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,silu,per_image_bias,res", [
+    (2, 128, 128, 32, 32, True, False, True), (1, 128, 256, 48, 40, True, False, False),
+    (2, 320, 320, 16, 16, True, True, False), (1, 256, 256, 21, 19, False, False, True),
+    (2, 512, 512, 16, 16, True, False, True), (1, 64, 64, 7, 9, True, False, False)])
+def test_gn_conv3x3_fused_matches_fp32_reference(N, Cin, Cout, H, W, silu, per_image_bias, res):
+    """conv3x3(silu(group_norm(x))) in one kernel (patch-staged, GroupNorm applied in the activation loader)."""
+    from garmentdreamer_amd.nn_ops import gn_conv3x3
+    g = torch.Generator(DEV).manual_seed(Cin + H + W)
+    cl = torch.channels_last
+    x = (torch.randn(N, Cin, H, W, device=DEV, generator=g) * 1.7 + 0.4).to(torch.bfloat16).contiguous(memory_format=cl)
+    gw = (torch.randn(Cin, device=DEV, generator=g) * 0.5 + 1.0).to(torch.bfloat16)
+    gb = (torch.randn(Cin, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (3 * Cin ** 0.5)).to(torch.bfloat16).contiguous(memory_format=cl)
+    b = torch.randn((N, Cout) if per_image_bias else (Cout,), device=DEV, generator=g).to(torch.bfloat16)
+    r = torch.randn(N, Cout, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl) if res else None
+    x.requires_grad_(True)
+    y = gn_conv3x3(x, gw, gb, 32, 1e-5, silu, w, b, r)
+    xr = x.detach().float().requires_grad_(True)
+    a = F.group_norm(xr, 32, gw.float(), gb.float(), 1e-5)
+    a = F.silu(a) if silu else a
+    yr = F.conv2d(a, w.float(), None if per_image_bias else b.float(), padding=1)
+    if per_image_bias:
+        yr = yr + b.float()[:, :, None, None]
+    if res:
+        yr = yr + r.float()
+    assert y.shape == yr.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=cl)
+    err = (y.float() - yr).abs().max().item()
+    assert err <= 2e-2 * yr.abs().max().item() + 2e-2, err      # bf16 activations into the MFMA + bf16 output
+    cos = F.cosine_similarity(y.float().flatten(), yr.flatten(), dim=0).item()
+    assert cos > 0.9998, cos
+    gy = torch.randn(yr.shape, device=DEV, generator=g).to(torch.bfloat16)
+    y.backward(gy)
+    yr.backward(gy.float())
+    gcos = F.cosine_similarity(x.grad.float().flatten(), xr.grad.flatten(), dim=0).item()
+    assert gcos > 0.999, gcos
+    gerr = (x.grad.float() - xr.grad).abs().max().item()
+    assert gerr <= 3e-2 * xr.grad.abs().max().item() + 1e-3, gerr
