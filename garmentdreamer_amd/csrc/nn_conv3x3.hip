@@ -108,7 +108,7 @@ template <int BN, int BM, int WN, int WM>
 __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
     int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, const ConvGeom g,
-    int Cin, int Cout, int tiles_n, int nwg)
+    int Cin, int Cout, int tiles_n, int nwg, float* __restrict__ partial, int taps_per_split)
 {
     constexpr int THREADS = 64 * WN * WM;
     constexpr int NA = BM * 8 / THREADS;      // 16-B chunks of the pixel tile per thread per K-step
@@ -174,11 +174,14 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
         b_off[i] = co < Cout ? (uint32_t)co * 9u * row_bytes + (uint32_t)(c & 7) * 16u : kOOB;
     }
     const int kc = Cin / BK;         // K-steps per tap
-    const int nsteps = g.ntaps * kc;
+    // split-K over taps (small-M layers): blockIdx.y walks tap subsets, fp32 partial sums go to partial[split]
+    const int tap0 = partial ? (int)blockIdx.y * taps_per_split : 0;
+    const int tap1 = partial ? min(g.ntaps, tap0 + taps_per_split) : g.ntaps;
+    const int nsteps = (tap1 - tap0) * kc;
 
     // loader state: (tap, channel step) of the NEXT stage to fetch; halo validity is re-evaluated
     // once per tap, the per-K-step cost is one scalar add
-    int ld_tap = 0, ld_c = 0;
+    int ld_tap = tap0, ld_c = 0;
     uint32_t a_voff[NA];
     auto set_tap = [&](int tap) {
         const int dy = (int)((g.ty4 >> (4 * tap)) & 15u) - 8, dx = (int)((g.tx4 >> (4 * tap)) & 15u) - 8;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
             a_voff[i] = ok ? a_off[i] : kOOB;
         }
     };
-    set_tap(0);
+    set_tap(tap0);
     auto issue = [&](int buf) {
         char* sA = smem + buf * kStage;                      // pixel tile  [BM][64] bf16
         char* sB = sA + BM * BK * 2;                         // weight tile [BN][64] bf16
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
 #endif
         if (++ld_c == kc) {
             ld_c = 0;
-            if (++ld_tap < g.ntaps) set_tap(ld_tap);
+            if (++ld_tap < tap1) set_tap(ld_tap);
         }
     };
 
@@ -292,6 +295,11 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[a][b][4 * q + e];
+                if (partial) {
+                    const size_t Mo = (size_t)Nimg * g.Hout * g.Wout;
+                    *(float4*)(partial + ((size_t)blockIdx.y * Mo + opix) * Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
+                }
                 if (bias_n) {
                     const uint2 bb = *(const uint2*)(bias_n + co);
                     v[0] += bf2f((uint16_t)(bb.x & 0xffff)); v[1] += bf2f((uint16_t)(bb.x >> 16));
@@ -555,6 +563,40 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_gn_patch_kernel(
     }
 }
 
+// out = bf16( sum_s partial[s] + bias + residual ): second half of the split-K path; 8 channels per thread
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ partial, int S, size_t MC,
+                                                                 int Cout, size_t pix_per_img,
+                                                                 const uint16_t* __restrict__ bias, int bias_img_stride,
+                                                                 const uint16_t* __restrict__ residual,
+                                                                 uint16_t* __restrict__ out)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= MC) return;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = 0.f;
+    for (int sidx = 0; sidx < S; sidx++) {
+        const float4 p0 = *(const float4*)(partial + (size_t)sidx * MC + i);
+        const float4 p1 = *(const float4*)(partial + (size_t)sidx * MC + i + 4);
+        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
+        v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+    }
+    const size_t pix = i / Cout;
+    const int co = (int)(i - pix * Cout);
+    if (bias) {
+        const uint16_t* bn = bias + (pix / pix_per_img) * (size_t)bias_img_stride + co;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] += bf2f(bn[k]);
+    }
+    if (residual) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] += bf2f(residual[i + k]);
+    }
+    uint4 o;
+    o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
+    *(uint4*)(out + i) = o;
+}
+
 // w'[ci][tap][co] = w[co][8 - tap][ci]  (dgrad weights; run once per layer, weights are frozen)
 __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ wf, int Cout,
                                             int Cin)
@@ -568,6 +610,7 @@ __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint
     }
 }
 
+int g_force_split = -1;    // tuning hook: -1 heuristic, 1 = never split, 3 / 9 = force
 int g_force_variant = -1;  // tuning hook: 0 = 128x128, 1 = 128x256, 2 = 256x256, -1 = heuristic
 
 // optional event timing of the conv kernel (bench.py's roofline line)
@@ -601,8 +644,19 @@ extern "C" {
 const char* gd_nn_conv_last_error(void) { return g_err; }
 
 // host side of one launch: tile variant choice, event profiling, kernel launch
+// Split-K factor for layers whose 128x128 tile grid cannot fill the chip (2 workgroups x 256 CUs): the nine taps
+// are dealt to 3 or 9 workgroups per tile, fp32 partials are combined by conv_splitk_reduce_kernel.
+static int choose_split(int64_t M, int Cout, int ntaps)
+{
+    if (g_force_split >= 0) return (g_force_split == 3 || g_force_split == 9) && ntaps == 9 ? g_force_split : 1;
+    const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
+    if (ntaps != 9 || tiles >= 256 || Cout % 8) return 1;
+    return tiles * 3 >= 384 ? 3 : 9;
+}
+
 static int launch_conv(hipStream_t s, const void* x, const void* weight, const void* bias, int bias_img_stride,
-                       const void* residual, void* y, int N, ConvGeom g, int Cin, int Cout)
+                       const void* residual, void* y, int N, ConvGeom g, int Cin, int Cout, void* ws = nullptr,
+                       size_t ws_bytes = 0)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
@@ -620,7 +674,12 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
     // tile choice: the 256x256 / 8-wave tile has twice the MFMA work per byte staged through LDS;
     // use it when Cout fills it and there are enough tiles for 256 CUs, else 128 channels x 256
     // pixels, else the 128x128 / 4-wave tile.
-    int variant = g_force_variant;
+    const int64_t Mo = (int64_t)N * g.Hout * g.Wout;
+    int split = ws ? choose_split(M, Cout, g.ntaps) : 1;
+    if (split > 1 && ws_bytes < (size_t)split * Mo * Cout * sizeof(float)) split = 1;
+    float* partial = split > 1 ? (float*)ws : nullptr;
+    const int tps = split > 1 ? g.ntaps / split : g.ntaps;
+    int variant = split > 1 ? 0 : g_force_variant;
     if (variant < 0) {
         // rules distilled from tools/conv_kernel_bench.py on MI355X: the 256x256 tile wins whenever Cout fills it
         // and there is most of a wave of tiles; 128 ch x 256 px wins for long pixel dimensions with deep K or huge M;
@@ -648,14 +707,20 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
         }                                                                                                          \
         const int tiles_m = (int)((M + BM_ - 1) / BM_), tiles_n = (Cout + BN_ - 1) / BN_;                          \
         const int nwg = tiles_m * tiles_n;                                                                         \
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WN_ * WM_), lds, s, (const uint16_t*)x,                      \
+        hipLaunchKernelGGL(kern, dim3(nwg, split), dim3(64 * WN_ * WM_), lds, s, (const uint16_t*)x,               \
                            (const uint16_t*)weight, (const uint16_t*)bias, bias_img_stride,                        \
-                           (const uint16_t*)residual, (uint16_t*)y, N, g, Cin, Cout, tiles_n, nwg);                \
+                           (const uint16_t*)residual, (uint16_t*)y, N, g, Cin, Cout, tiles_n, nwg, partial, tps);  \
     } while (0)
     if (variant == 2) GD_LAUNCH(256, 256, 2, 4);
     else if (variant == 1) GD_LAUNCH(128, 256, 2, 4);
     else GD_LAUNCH(128, 128, 2, 2);
 #undef GD_LAUNCH
+    if (split > 1) {
+        const size_t MC = (size_t)Mo * Cout;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((MC / 8 + 255) / 256)), dim3(256), 0, s, partial,
+                           split, MC, Cout, (size_t)g.Hout * g.Wout, (const uint16_t*)bias, bias_img_stride,
+                           (const uint16_t*)residual, (uint16_t*)y);
+    }
     if (ea && eb) {
         (void)hipEventRecord(eb, s);
         std::lock_guard<std::mutex> lk(g_cprof.mu);
@@ -673,6 +738,37 @@ static void add_tap(ConvGeom& g, int dy, int dx, int widx)
     g.tx4 |= (uint64_t)(dx + 8) << (4 * g.ntaps);
     g.w4 |= (uint64_t)widx << (4 * g.ntaps);
     g.ntaps++;
+}
+
+size_t gd_nn_conv3x3_ws_bytes(int N, int H, int W, int Cin, int Cout)
+{
+    (void)Cin;
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    const int64_t M = (int64_t)N * H * W;
+    const int split = choose_split(M, Cout, 9);
+    return split > 1 ? (size_t)split * M * Cout * sizeof(float) : 0;
+}
+
+int gd_nn_conv_force_split(int s)
+{
+    g_force_split = s;
+    return GD_NN_OK;
+}
+
+int gd_nn_conv3x3_forward_ws(void* stream, const void* x, const void* weight, const void* bias, int bias_img_stride,
+                             const void* residual, void* y, int N, int H, int W, int Cin, int Cout, void* ws,
+                             size_t ws_bytes)
+{
+    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || Cin % BK || Cout % 4 || Cin <= 0 || Cout <= 0)
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3: need Cin % 64 == 0 and Cout % 4 == 0");
+    ConvGeom g = {};
+    g.Hin = g.Hg = g.Hout = H;
+    g.Win = g.Wg = g.Wout = W;
+    g.sy = g.sx = g.osy = g.osx = 1;
+    for (int ky = 0; ky < 3; ky++)
+        for (int kx = 0; kx < 3; kx++) add_tap(g, ky - 1, kx - 1, ky * 3 + kx);
+    return launch_conv((hipStream_t)stream, x, weight, bias, bias_img_stride, residual, y, N, g, Cin, Cout, ws, ws_bytes);
 }
 
 int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const void* bias, int bias_img_stride,

@@ -45,13 +45,15 @@ def _gn(norm: nn.GroupNorm, x, silu: bool):
 
 def _conv3(conv: nn.Conv2d, x, image_bias=None, residual=None):
     """3x3/s1/p1 convolution with the bias (or a per-image bias [N,Cout]) and an optional residual
-    fused into the MFMA kernel's epilogue (nn_ops.conv3x3); falls back to torch's conv for layers the
-    kernel does not cover (Cin % 64 != 0, fp32, CPU, or too few 128x128 tiles to fill the chip)."""
+    fused into the MFMA kernel's epilogue (nn_ops.conv3x3; small feature maps run split over the nine taps);
+    falls back to torch's conv for layers the kernel does not cover (Cin % 64 != 0, fp32, CPU)."""
     bias = conv.bias if image_bias is None else image_bias
-    if conv3x3_supported(x, conv.weight) and conv.stride == (1, 1) and conv.padding == (1, 1):
-        tiles = -(-x.shape[0] * x.shape[2] * x.shape[3] // 128) * -(-conv.out_channels // 128)
-        if tiles >= 128:
-            return conv3x3(x, conv.weight, bias, residual)
+    frozen = not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
+    if frozen and conv3x3_supported(x, conv.weight) and conv.stride == (1, 1) and conv.padding == (1, 1):
+        if bias is not None and bias.requires_grad:   # LoRA training: the time/camera embedding bias needs a gradient
+            y = conv3x3(x, conv.weight, None, None) + (bias[:, :, None, None] if bias.dim() == 2 else bias[None, :, None, None])
+            return y if residual is None else y + residual
+        return conv3x3(x, conv.weight, bias, residual)
     y = F.conv2d(x, conv.weight, None if image_bias is not None else conv.bias, conv.stride, conv.padding)
     if image_bias is not None:
         y = y + image_bias[:, :, None, None]
@@ -63,8 +65,13 @@ def _gn_conv3(norm: nn.GroupNorm, conv: nn.Conv2d, x, image_bias=None, residual=
     as ONE patch-staged kernel that normalises in its activation loader (nn_ops.gn_conv3x3: 1.05-1.26x faster
     than GroupNorm kernel + convolution on MI355X, tools/gn_conv_bench.py); small maps, where a 16x16-patch grid
     cannot fill 256 CUs, keep the GroupNorm kernel + implicit-GEMM convolution."""
-    hw = x.shape[2] * x.shape[3]
-    if x.is_cuda and (hw >= 128 * 128 or (hw >= 64 * 64 and conv.out_channels % 256 == 0)) and \
+    # workgroups of the patch kernel: one per (image, 16x16 patch, 128/256-channel slab); below ~1.5 waves of
+    # the 256 CUs (small maps or one view per GPU) the implicit-GEMM kernel's finer tiles fill the chip better
+    bn = 256 if conv.out_channels % 256 == 0 else 128
+    wgs = x.shape[0] * -(-x.shape[2] // 16) * -(-x.shape[3] // 16) * -(-conv.out_channels // bn)
+    frozen = not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
+    frozen = frozen and (image_bias is None or not image_bias.requires_grad)
+    if x.is_cuda and frozen and x.shape[2] * x.shape[3] >= 64 * 64 and wgs >= 384 and \
             gn_conv3x3_supported(x, norm.weight, conv.weight):
         return gn_conv3x3(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True, conv.weight,
                           conv.bias if image_bias is None else image_bias, residual)

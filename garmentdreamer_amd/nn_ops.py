@@ -21,6 +21,9 @@ SIGNATURES = {
     "gd_nn_groupnorm_silu_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_ws_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_forward_ws": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t]),
+    "gd_nn_conv_force_split": (_i, [_i]),
     "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
     "gd_nn_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "gd_nn_conv3x3_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
@@ -124,11 +127,15 @@ def _conv_launch(x, w_khwc, bias, residual, out_channels):
     if bias is not None:
         bias = bias.contiguous()
         stride = out_channels if bias.dim() == 2 else 0
+    # small-M layers run split over the taps and need fp32 scratch (torch's allocator: hipGraph-capture safe)
+    ws_bytes = L.gd_nn_conv3x3_ws_bytes(N, H, W, Cin, out_channels)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        ret = L.gd_nn_conv3x3_forward(stream, x.data_ptr(), w_khwc.data_ptr(), None if bias is None else bias.data_ptr(),
-                                      stride, None if residual is None else residual.data_ptr(), y.data_ptr(), N, H,
-                                      W, Cin, out_channels)
+        ret = L.gd_nn_conv3x3_forward_ws(stream, x.data_ptr(), w_khwc.data_ptr(),
+                                         None if bias is None else bias.data_ptr(), stride,
+                                         None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
+                                         out_channels, None if ws is None else ws.data_ptr(), ws_bytes)
     if ret < 0:
         raise RuntimeError(f"gd_nn_conv3x3_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
     return y

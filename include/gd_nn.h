@@ -62,6 +62,17 @@ int gd_nn_conv_profile_enable(int on);
 int gd_nn_conv_profile_reset(void);
 int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_flops);
 
+/* gd_nn_conv3x3_forward with a caller-provided scratch buffer: layers whose 128x128 tile grid cannot fill the
+ * chip (small feature maps, one view per GPU) are split over the nine taps (3 or 9 workgroups per tile, fp32
+ * partials in `ws`, combined with bias / residual by a second small kernel).  gd_nn_conv3x3_ws_bytes() gives
+ * the bytes needed (0: the layer is not split); with ws == NULL the call behaves like gd_nn_conv3x3_forward. */
+size_t gd_nn_conv3x3_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int gd_nn_conv3x3_forward_ws(void* stream, const void* x, const void* weight, const void* bias, int bias_img_stride,
+                             const void* residual, void* y, int N, int H, int W, int Cin, int Cout, void* ws,
+                             size_t ws_bytes);
+/* tuning hook: -1 heuristic (default), 1 never split, 3 / 9 force that split factor */
+int gd_nn_conv_force_split(int s);
+
 /* GroupNorm statistics only: mean_rstd[N][G][2] = {mean, 1/sqrt(var + eps)} of x (bf16 [N,HW,C]); stats_ws as in
  * gd_nn_groupnorm_silu_forward.  Feeds gd_nn_conv3x3_gn_forward (and gd_nn_groupnorm_silu_backward). */
 int gd_nn_groupnorm_stats(void* stream, const void* x, int N, int HW, int C, int G, float eps, double* stats_ws,

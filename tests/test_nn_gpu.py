@@ -65,10 +65,22 @@ def test_unet_and_vae_bf16_hip_path_tracks_fp32_torch_path():
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,per_image_bias,res", [
     (2, 64, 128, 16, 16, False, False), (1, 128, 128, 32, 40, False, True), (3, 320, 320, 16, 16, True, True),
-    (2, 192, 64, 9, 13, True, False), (1, 64, 8, 16, 16, False, False), (2, 640, 320, 8, 8, False, True)])
-def test_conv3x3_mfma_matches_fp32_reference(N, Cin, Cout, H, W, per_image_bias, res):
+    (2, 192, 64, 9, 13, True, False), (1, 64, 8, 16, 16, False, False), (2, 640, 320, 8, 8, False, True),
+    (8, 128, 128, 64, 64, False, True), (2, 320, 320, 64, 64, True, True), (16, 1280, 1280, 8, 8, True, False)])
+@pytest.mark.parametrize("split", [-1, 1])
+def test_conv3x3_mfma_matches_fp32_reference(N, Cin, Cout, H, W, per_image_bias, res, split):
     """Asymmetric random data (catches operand / C-layout transposes), halo zero padding, ragged
-    pixel and channel tiles, fused per-image bias and residual; plus the input gradient."""
+    pixel and channel tiles, fused per-image bias and residual; plus the input gradient.  split = -1: the
+    library's heuristic (the small shapes here run split over the taps, x3 or x9); 1: never split."""
+    from garmentdreamer_amd.nn_ops import conv3x3, conv3x3_supported, lib
+    lib().gd_nn_conv_force_split(split)
+    try:
+        _conv3x3_case(N, Cin, Cout, H, W, per_image_bias, res)
+    finally:
+        lib().gd_nn_conv_force_split(-1)
+
+
+def _conv3x3_case(N, Cin, Cout, H, W, per_image_bias, res):
     from garmentdreamer_amd.nn_ops import conv3x3, conv3x3_supported
     g = torch.Generator(DEV).manual_seed(Cin * 7 + Cout)
     x = torch.randn(N, Cin, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
