@@ -309,13 +309,18 @@ def main():
     if conv_n > 0:
         ach = conv_flops / (conv_ms * 1e-3) / 1e12
         roofline_conv = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "kernel": "conv3x3_nhwc_bf16_kernel",
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "conv3x3_nhwc_bf16_kernel + conv3x3_gn_patch_kernel",
                          "avg_launch_us": conv_ms / conv_n * 1e3, "launches": conv_n,
                          "flops_per_launch": conv_flops / conv_n, "ms_per_step": conv_ms / max(conv_steps, 1),
                          "timing": conv_note,
-                         "note": ("dominant kernel of the step (largest share of GPU time): bf16 MFMA implicit-GEMM 3x3 "
-                                  "convolution of the VAE encoder / UNet; algorithmic FLOPs = 2*N*H*W*Cout*9*Cin per "
-                                  "launch, summed over the launches of the timed region")}
+                         "note": ("dominant kernel family of the step (largest share of GPU time): the bf16 MFMA 3x3 "
+                                  "convolution of the VAE encoder / UNet -- implicit-GEMM kernel (stride 1 / 2, dgrad, "
+                                  "split-K) and its patch-staged sibling with GroupNorm+SiLU fused into the loader; "
+                                  "algorithmic FLOPs = 2*M*Cout*taps*Cin per launch, summed over the launches of the "
+                                  "timed region.  The MFMA stream alone (no loads / LDS reads / barriers) measures "
+                                  "1.2-1.45 PFLOP/s on this chip with random data (power-limited clock, "
+                                  "profiles/r01_conv_ablation.txt), i.e. the practical ceiling is ~0.55 of `peak`")}
     if bwd_n > 0:
         avg_s = bwd_ms / bwd_n * 1e-3
         ach = flops_launch / avg_s / 1e12

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_gn_patch_kernel(
             if (s + 1 < nsteps) issueB(bufB ^ 1, tap == 8 ? 0 : tap + 1, tap == 8 ? c + 1 : c);
             if (c + 1 < kc) {
                 if (tap == 0) loadA(c + 1);
-                else if (tap == 1) storeA((c + 1) & 1, c + 1);
+                else if (tap == 1) storeA((c + 1) & 1, c + 1);   // (staggering the store per wave pair: slower, tried)
             }
             const char* pb = sB + bufB * kBStage;
             const int tapoff = (tap / 3) * kPatch + (tap % 3);
