@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--per-view-raster", action="store_true", help="reference-style Python loop over views")
     ap.add_argument("--raster-only", action="store_true", help="time only rasterizer fwd+bwd (diagnostic)")
     ap.add_argument("--no-graphs", action="store_true", help="eager launches instead of hipGraph replay of UNet/VAE")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="six nn.Parameters + torch.optim.Adam(fused) instead of the flat-buffer GaussianModel")
     ap.add_argument("--vsd", action="store_true",
                     help="BASELINE configs[4] diagnostic: NeTF VSD iteration (VAE + 2 frozen UNet + LoRA UNet fwd, "
                          "LoRA UNet fwd+bwd) on a synthetic 512^2 render, one view per GPU")
@@ -222,7 +224,11 @@ def main():
 
     view_ids = gdist.shard_views(args.views, rk, ws)
     scene = synthetic_gaussians(args.gaussians, seed=0, sh_degree=0)
-    gaussians = GaussianParams(scene, sh_degree=0, device=device)
+    if args.torch_adam:
+        gaussians = GaussianParams(scene, sh_degree=0, device=device)
+    else:   # flat parameter / gradient buffers, one HIP Adam launch, native densification statistics
+        from garmentdreamer_amd.gaussian_model import GaussianModel
+        gaussians = GaussianModel.from_activated(scene, sh_degree=0, device=device)
     bg = torch.ones(3, device=device)
     if args.raster_only:
         guidance, prompt = None, None

@@ -24,6 +24,7 @@ RASTER_SOURCES = [
     ("raster_binning.hip", []),
     ("raster_render.hip", ["-munsafe-fp-atomics"]),
     ("raster_api.hip", []),
+    ("raster_scene.hip", ["-ffp-contract=off"]),
 ]
 
 

@@ -62,6 +62,16 @@ SIGNATURES = {
     "gd_raster_last_error": (C.c_char_p, []),
     "gd_raster_build_info": (C.c_char_p, []),
 }
+# scene-side kernels in the same library (include/gd_scene.h)
+_I64P = C.POINTER(C.c_int64)
+SCENE_SIGNATURES = {
+    "gd_scene_dist2_scratch_bytes": (C.c_size_t, [_i]),
+    "gd_scene_dist2": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "gd_scene_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _I64P, C.POINTER(C.c_double), C.c_double,
+                                C.c_double, C.c_double, _i]),
+    "gd_scene_densify_stats": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gd_scene_last_error": (C.c_char_p, []),
+}
 
 
 class NativeLibraryError(RuntimeError):
@@ -89,7 +99,7 @@ def lib():
             L = C.CDLL(_LIB_PATH)
         except OSError as e:  # e.g. libamdhip64 missing
             raise NativeLibraryError(f"cannot load {_LIB_PATH}: {e}") from e
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(SCENE_SIGNATURES.items()):
             fn = getattr(L, name)  # AttributeError here == ABI drift; let it surface
             fn.restype = res
             fn.argtypes = args
@@ -101,6 +111,12 @@ def check(ret: int, what: str) -> int:
     if ret < 0:
         msg = lib().gd_raster_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed ({ret}): {msg}")
+    return ret
+
+
+def check_scene(ret: int, what: str) -> int:
+    if ret < 0:
+        raise RuntimeError(f"{what} failed ({ret}): {lib().gd_scene_last_error().decode('utf-8', 'replace')}")
     return ret
 
 

@@ -38,18 +38,24 @@ class SDSLoop:
             from .gaussian_renderer import render_batch as render_batch_fn  # HIP rasterizer (no fallback)
         self.render_batch_fn = render_batch_fn
         self.lambda_sds, self.lambda_sparsity = lambda_sds, lambda_sparsity
-        groups = gaussians.param_groups()
-        for g in groups:
-            g["lr"] *= lr_scale
         dev = gaussians.get_xyz.device
-        if fused_adam is None:
-            fused_adam = dev.type == "cuda"
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=fused_adam)
-        self.params = [p for g in groups for p in g["params"]]
-        P = gaussians.get_xyz.shape[0]
-        self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
-        self.denom = torch.zeros((P, 1), device=dev)
-        self.max_radii2D = torch.zeros((P,), device=dev)
+        # gaussian_model.GaussianModel: flat parameter / gradient buffers, one HIP Adam launch, native statistics
+        self.native_scene = hasattr(gaussians, "flat_grad")
+        if self.native_scene:
+            self.optimizer = None
+            self.params = []
+        else:
+            groups = gaussians.param_groups()
+            for g in groups:
+                g["lr"] *= lr_scale
+            if fused_adam is None:
+                fused_adam = dev.type == "cuda"
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=fused_adam)
+            self.params = [p for g in groups for p in g["params"]]
+            P = gaussians.get_xyz.shape[0]
+            self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
+            self.denom = torch.zeros((P, 1), device=dev)
+            self.max_radii2D = torch.zeros((P,), device=dev)
         self.global_step = 0
         self._bucket = None
 
@@ -80,23 +86,36 @@ class SDSLoop:
         loss_sds = g_out["loss_sds"]
         loss_sparsity = (out["opacity"] ** 2 + 0.01).sqrt().mean()
         loss = loss_sds * self.lambda_sds + loss_sparsity * self.lambda_sparsity
-        self.optimizer.zero_grad(set_to_none=True)
+        if self.native_scene:
+            self.gaussians.zero_grad()               # one memset of the flat gradient buffer
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
 
         with torch.no_grad():
             vs_grad = out["viewspace_points"].grad.sum(0)  # sum over this rank's views
             radii = out["radii"].max(dim=0).values
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-            for p, g in zip(self.params, grads):
-                p.grad = g
+            if self.native_scene:
+                grads = [self.gaussians.flat_grad]   # every parameter's .grad is a view into this buffer
+            else:
+                grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+                for p, g in zip(self.params, grads):
+                    p.grad = g
             if gdist.world_size() > 1:
                 tensors = grads + [vs_grad]
                 if self._bucket is None:
                     self._bucket = gdist.GradBucket(tensors)
                 self._bucket.all_reduce_mean_(tensors)
                 gdist.all_reduce_max_(radii)
-            self._densification_stats(vs_grad, radii)
-        self.optimizer.step()
+            if self.native_scene:
+                if self.global_step < 900:
+                    self.gaussians.add_densification_stats(vs_grad, radii)
+            else:
+                self._densification_stats(vs_grad, radii)
+        if self.native_scene:
+            self.gaussians.step()
+        else:
+            self.optimizer.step()
         self.global_step += 1
         return {"loss": loss.detach(), "loss_sds": loss_sds.detach(), "loss_sparsity": loss_sparsity.detach(),
                 "grad_norm": g_out["grad_norm"], "num_visible": (radii > 0).sum()}

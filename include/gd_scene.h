@@ -1,0 +1,62 @@
+/*
+ * gd_scene.h -- C-ABI of the scene-side kernels either side of the rasterizer,
+ * exported by libgd_raster.so.  Plain device pointers, caller's HIP stream, no torch types.
+ *
+ *   gd_scene_dist2        <- distCUDA2 / SimpleKNN::knn
+ *                            (Garment_3DGS/gaussiansplatting/submodules/simple-knn/simple_knn.cu:63-220,
+ *                             spatial.cu:14-25): mean squared distance to the 3 nearest neighbours, used once by
+ *                            GaussianModel.create_from_pcd (scene/gaussian_model.py:135-136) for the initial scales.
+ *   gd_scene_adam_step    <- torch.optim.Adam(l, lr=0.0, eps=1e-15).step() over the six per-attribute groups
+ *                            (scene/gaussian_model.py:156-167): ONE launch over a flat fp32 parameter buffer with a
+ *                            per-group learning rate (the flat gradient buffer is also what the view-sharded
+ *                            all-reduce sends, garmentdreamer_amd/dist.py).
+ *   gd_scene_densify_stats <- on_before_optimizer_step + add_densification_stats
+ *                            (Garment_3DGS/threestudio/systems/GaussianDreamer.py:268-279,
+ *                             scene/gaussian_model.py:415-419): max_radii2D / xyz_gradient_accum / denom update.
+ *
+ * Return 0 on success, negative on error (gd_scene_last_error()).
+ */
+#ifndef GD_SCENE_H_INCLUDED
+#define GD_SCENE_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GD_SCENE_MAX_GROUPS 8
+#define GD_SCENE_KNN_BOX 1024 /* BOX_SIZE of simple_knn.cu */
+
+/* bytes of device scratch gd_scene_dist2 needs for P points */
+size_t gd_scene_dist2_scratch_bytes(int P);
+
+/* points: float [P][3]; mean_dists: float [P] out; scratch: gd_scene_dist2_scratch_bytes(P) bytes.
+ * Same algorithm and quirks as the reference: bounding box reduced with an initial value of 0 (so it always
+ * contains the origin), 30-bit Morton codes of the truncated normalised coordinates, stable sort, boxes of 1024
+ * consecutive codes, 3 best squared distances averaged as (b0 + b1 + b2) / 3.  P < 4 follows the reference
+ * too (missing neighbours stay FLT_MAX). */
+int gd_scene_dist2(void* stream, int P, const float* points, float* mean_dists, void* scratch);
+
+/* One Adam step over a flat parameter buffer split into ngroups consecutive ranges [group_end[g-1], group_end[g])
+ * (elements), each with its own learning rate; torch.optim.Adam semantics (no amsgrad, no weight decay):
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = step >= 1
+ * Scalars are doubles, as torch's Python-side hyper-parameters are (1 - beta and lr / (1 - beta1^t) are formed in
+ * double before the fp32 kernel sees them). */
+int gd_scene_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       int ngroups, const int64_t* group_end, const double* lr, double beta1, double beta2, double eps,
+                       int step);
+
+/* vis = radii > 0:  max_radii2D = vis ? max(max_radii2D, radii) : max_radii2D;
+ *                   xyz_gradient_accum += vis ? |viewspace_grad.xy| : 0;   denom += vis ? 1 : 0.
+ * radii: int32 [P]; viewspace_grad: float [P][3]; the three accumulators: float [P]. */
+int gd_scene_densify_stats(void* stream, int P, const int* radii, const float* viewspace_grad, float* max_radii2D,
+                           float* xyz_gradient_accum, float* denom);
+
+const char* gd_scene_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -168,3 +168,35 @@ def mark_visible(means3D, viewmatrix, projmatrix) -> np.ndarray:
 
 def higher_msb(n: int) -> int:
     return int(lib().gdo_higher_msb(n))
+
+
+# ---------------------------------------------------------------------------------------------
+# scene-side oracle (oracle/gd_scene_oracle.c): simple-knn distCUDA2
+# ---------------------------------------------------------------------------------------------
+_SLIB = None
+
+
+def build_scene(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libgd_scene_oracle.so")
+    src = os.path.join(_HERE, "gd_scene_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libgd_scene_oracle.so"])
+    return so
+
+
+def dist2(points, return_order: bool = False):
+    """Mean squared distance to the 3 nearest neighbours, the reference's boxed Morton search
+    (simple_knn.cu:153-220).  points: [P,3] float32."""
+    global _SLIB
+    if _SLIB is None:
+        _SLIB = C.CDLL(build_scene())
+        _SLIB.gdso_dist2.restype = None
+        _SLIB.gdso_dist2.argtypes = [C.c_int, _f32p, _f32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    P = pts.shape[0]
+    out = np.zeros(P, np.float32)
+    codes = np.zeros(P, np.uint32)
+    order = np.zeros(P, np.uint32)
+    _SLIB.gdso_dist2(P, pts.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p), codes.ctypes.data_as(C.POINTER(C.c_uint32)),
+                     order.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return (out, codes, order) if return_order else out

@@ -27,6 +27,23 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in L.gd_raster_build_info()
 
 
+def test_scene_symbols_declared_exported_and_bound():
+    text = open(os.path.join(ROOT, "include", "gd_scene.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(gd_scene_[a-z0-9_]+)\s*\(", text)))
+    from garmentdreamer_amd import _native
+    L = _native.lib()
+    assert len(declared) >= 5
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/gd_scene.h but not exported"
+    assert sorted(_native.SCENE_SIGNATURES) == declared
+    # argument validation before any device work
+    assert L.gd_scene_dist2(None, -1, None, None, None) == -1 and b"P must be" in L.gd_scene_last_error()
+    assert L.gd_scene_dist2(None, 0, None, None, None) == 0
+    assert L.gd_scene_adam_step(None, None, None, None, None, 10, 0, None, None, 0.9, 0.999, 1e-15, 1) == -1
+    assert L.gd_scene_dist2_scratch_bytes(100000) > 100000 * 28
+
+
 def test_scratch_size_queries_and_sort_plan():
     from garmentdreamer_amd import _native
     L = _native.lib()
