@@ -61,17 +61,17 @@ def _conv3(conv: nn.Conv2d, x, image_bias=None, residual=None):
 
 
 def _gn_conv3(norm: nn.GroupNorm, conv: nn.Conv2d, x, image_bias=None, residual=None):
-    """``conv(silu(norm(x)))`` of a ResnetBlock.  Large feature maps (the VAE encoder's 512^2 .. 64^2 levels) run
+    """``conv(silu(norm(x)))`` of a ResnetBlock.  Large feature maps (the VAE encoder's 512^2 .. 128^2 levels) run
     as ONE patch-staged kernel that normalises in its activation loader (nn_ops.gn_conv3x3: 1.05-1.26x faster
-    than GroupNorm kernel + convolution on MI355X, tools/gn_conv_bench.py); small maps, where a 16x16-patch grid
-    cannot fill 256 CUs, keep the GroupNorm kernel + implicit-GEMM convolution."""
+    than GroupNorm kernel + convolution on MI355X, tools/gn_conv_bench.py); on 64^2 and smaller maps the
+    GroupNorm kernel + plain convolution (LDS-DMA patch kernel or implicit GEMM, chosen by the library) is faster."""
     # workgroups of the patch kernel: one per (image, 16x16 patch, 128/256-channel slab); below ~1.5 waves of
     # the 256 CUs (small maps or one view per GPU) the implicit-GEMM kernel's finer tiles fill the chip better
     bn = 256 if conv.out_channels % 256 == 0 else 128
     wgs = x.shape[0] * -(-x.shape[2] // 16) * -(-x.shape[3] // 16) * -(-conv.out_channels // bn)
     frozen = not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
     frozen = frozen and (image_bias is None or not image_bias.requires_grad)
-    if x.is_cuda and frozen and x.shape[2] * x.shape[3] >= 64 * 64 and wgs >= 384 and \
+    if x.is_cuda and frozen and x.shape[2] * x.shape[3] >= 128 * 128 and wgs >= 384 and \
             gn_conv3x3_supported(x, norm.weight, conv.weight):
         return gn_conv3x3(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True, conv.weight,
                           conv.bias if image_bias is None else image_bias, residual)

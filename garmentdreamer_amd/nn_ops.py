@@ -141,6 +141,25 @@ def _conv_launch(x, w_khwc, bias, residual, out_channels):
     return y
 
 
+def _patch_launch(x, w_khwc, bias, residual, out_channels):
+    """Plain 3x3/s1/p1 convolution on the patch-staged kernel (LDS-DMA patch, no GroupNorm)."""
+    N, Cin, H, W = x.shape
+    L = lib()
+    y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    stride = 0
+    if bias is not None:
+        bias = bias.contiguous()
+        stride = out_channels if bias.dim() == 2 else 0
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_conv3x3_gn_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), None, None, None,
+                                         0, 0, w_khwc.data_ptr(), None if bias is None else bias.data_ptr(), stride,
+                                         None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
+                                         out_channels)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_conv3x3_gn_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+    return y
+
+
 def _flipped(weight):
     """Cached dgrad weights [Cin][3][3][Cout] for a frozen conv weight (stored channels_last)."""
     f = getattr(weight, "_gd_flipped", None)

@@ -303,3 +303,26 @@ def test_gn_conv3x3_fused_matches_fp32_reference(N, Cin, Cout, H, W, silu, per_i
     assert gcos > 0.999, gcos
     gerr = (x.grad.float() - xr.grad).abs().max().item()
     assert gerr <= 3e-2 * xr.grad.abs().max().item() + 1e-3, gerr
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,per_image_bias,res", [(2, 128, 128, 64, 64, False, True), (1, 192, 320, 21, 19, True, False),
+                                                             (3, 64, 64, 16, 16, False, False), (1, 256, 512, 40, 24, True, True),
+                                                             (16, 320, 320, 64, 64, False, True)])
+def test_plain_conv_on_patch_kernel_matches_fp32_reference(N, Cin, Cout, H, W, per_image_bias, res):
+    """Plain 3x3 convolution on the patch-staged kernel (LDS-DMA patch): ragged patches, halo zero fill, both
+    channel-slab widths; the last shape is one the library routes there by itself."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(Cin + Cout + H)
+    cl = torch.channels_last
+    x = torch.randn(N, Cin, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (3 * Cin ** 0.5)).to(torch.bfloat16).contiguous(memory_format=cl)
+    b = torch.randn((N, Cout) if per_image_bias else (Cout,), device=DEV, generator=g).to(torch.bfloat16)
+    r = torch.randn(N, Cout, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl) if res else None
+    yr = F.conv2d(x.float(), w.float(), None, padding=1) + (b.float()[:, :, None, None] if per_image_bias else b.float()[None, :, None, None])
+    if res:
+        yr = yr + r.float()
+    for y in (nn_ops._patch_launch(x, w, b, r, Cout), nn_ops.conv3x3(x, w, b, r)):
+        assert y.shape == yr.shape and y.is_contiguous(memory_format=cl)
+        err = (y.float() - yr).abs().max().item()
+        assert err <= 1.5e-2 * yr.abs().max().item() + 1e-2, err
+        assert F.cosine_similarity(y.float().flatten(), yr.flatten(), dim=0).item() > 0.9999
