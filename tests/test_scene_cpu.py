@@ -176,3 +176,67 @@ def test_ply_round_trip_and_header_layout(tmp_path):
             f.write(" ".join(repr(float(x)) for x in r) + "\n")
     n2, d2 = gm.read_ply(apath)
     assert n2 == names and np.array_equal(d2, data)
+
+
+def test_export_helpers_match_reference_golden_and_camera_record():
+    import json
+    from garmentdreamer_amd import export as ex
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "export_helpers.json")))
+    for i, f in enumerate(gold["fov"]):
+        for j, p in enumerate(gold["pixels"]):
+            assert ex.fov2focal(f, p) == gold["fov2focal"][i][j]
+            assert ex.focal2fov(ex.fov2focal(f, p), 777) == gold["focal2fov"][i][j]
+    for k, v in gold["hash"].items():
+        model, prompt = k.split("-a wedding", 1)[0], "a wedding" + k.split("-a wedding", 1)[1]
+        assert ex.hash_prompt(model, prompt) == v
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, :3] = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], np.float32)
+    c2w[:3, 3] = [1.0, 2.0, 3.0]
+    keep = c2w.copy()
+    rec = ex.camera_info_entry(c2w, 7, 640, 480, 0.9)
+    assert np.array_equal(c2w, keep)                                   # the caller's matrix is not negated in place
+    assert rec["id"] == 7 and rec["img_name"] == "7" and rec["width"] == 640 and rec["height"] == 480
+    assert rec["position"] == [1.0, 2.0, 3.0]
+    assert np.array_equal(np.array(rec["rotation"]), -keep[:3, :3])    # GaussianDreamer.py:356 ``rot[:, :] *= -1``
+    assert rec["fy"] == ex.fov2focal(0.9, 480) and abs(rec["fx"] - rec["fy"]) < 1e-9 * rec["fy"]
+
+
+def test_rgba_png_dump_and_cameras_json(tmp_path):
+    import json
+    import struct
+    import zlib
+    from garmentdreamer_amd import export as ex
+    rng = np.random.default_rng(0)
+    H, W = 37, 53
+    out = {"comp_rgb": torch.from_numpy(rng.uniform(-0.1, 1.1, size=(1, H, W, 3)).astype(np.float32)),
+           "alphas": torch.from_numpy(rng.uniform(size=(1, H, W, 1)).astype(np.float32))}
+    batch = {"index": torch.tensor([12]), "fovy": torch.tensor([0.96]), "c2w": torch.eye(4)[None], "width": W, "height": H}
+    cams = []
+    path = ex.dump_test_view(str(tmp_path), out, batch, cams, alpha_threshold=0.5)
+    assert path.endswith(os.path.join("gs_rendered_rgba", "12.png")) and len(cams) == 1 and cams[0]["id"] == 12
+    raw = open(path, "rb").read()
+    assert raw[:8] == bytes([0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A])
+    # independent decode: walk the chunks, check CRCs, inflate, strip filter bytes
+    pos, chunks = 8, {}
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        chunks[tag] = chunks.get(tag, b"") + data
+        pos += 12 + n
+    assert struct.unpack(">IIBBBBB", chunks[b"IHDR"]) == (W, H, 8, 6, 0, 0, 0)
+    px = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), np.uint8).reshape(H, 1 + 4 * W)
+    assert (px[:, 0] == 0).all()
+    px = px[:, 1:].reshape(H, W, 4)
+    exp_rgb = np.rint(out["comp_rgb"][0].numpy().clip(0, 1) * 255.0).astype(np.uint8)
+    exp_a = np.where(out["alphas"][0, :, :, 0].numpy() >= 0.5, 255, 0).astype(np.uint8)
+    assert np.array_equal(px[..., :3], exp_rgb) and np.array_equal(px[..., 3], exp_a)
+    try:
+        from PIL import Image
+        im = np.array(Image.open(path))
+        assert im.shape == (H, W, 4) and np.array_equal(im, px)
+    except ImportError:
+        pass
+    jpath = str(tmp_path / "cameras.json")
+    ex.save_cameras_json(jpath, cams)
+    assert json.load(open(jpath)) == cams
