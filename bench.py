@@ -258,7 +258,10 @@ def main():
             out = loop.render_views(batch)
             w = torch.randn(out["comp_rgb"].shape, device=device, generator=gen)
             loss = (out["comp_rgb"] * w).sum() + (out["opacity"] ** 2 + 0.01).sqrt().mean()
-            loop.optimizer.zero_grad(set_to_none=True)
+            if loop.native_scene:
+                gaussians.zero_grad()
+            else:
+                loop.optimizer.zero_grad(set_to_none=True)
             loss.backward()
             return
         noise = torch.randn(V, 4, 64, 64, device=device, generator=gen)

@@ -128,6 +128,41 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
+// power = -0.5 (a dx^2 + c dy^2) - b dx dy in EXACTLY the reference's evaluation order, every operation rounded
+// on its own (forward.cu:341 / backward.cu:528 as the oracle compiles them, no FMA contraction): the forward
+// blend, the backward blend and the oracle then agree on the bits of `power`, hence on which (pixel, Gaussian)
+// pairs pass the 1/255 test -- a flipped pair is a discontinuous step in the gradients, amplified by 0.5 W in
+// dL/dmean2D.  t1 = (a dx) dx and bdx = b dx may be hoisted by the caller.  (-0.5 s is exact, so the final fma
+// equals the separately rounded subtraction.)
+__device__ __forceinline__ float power_exact(const float t1, const float bdx, const float c, const float dy)
+{
+    const float t2 = __fmul_rn(__fmul_rn(c, dy), dy);
+    const float s = __fadd_rn(t1, t2);
+    return fmaf(-0.5f, s, -__fmul_rn(bdx, dy));
+}
+
+// Smallest fp32 exponent p with  !(min(0.99, o * expf(p)) < 1/255): `power >= thr` is then the forward pass's
+// contribution test itself (forward.cu:346-348), decided without evaluating the exponential per pair.
+// A few accurate expf per STAGED entry (once per tile and entry).
+__device__ __forceinline__ float alpha_threshold_exact(const float o)
+{
+    const float k = 1.0f / 255.0f;
+    float t = -logf(255.0f * o);
+    if (!(o > 0.0f) || !isfinite(t)) return INFINITY;     // opacity 0 (or NaN): nothing ever contributes
+#pragma unroll 1
+    for (int it = 0; it < 8; it++) {      // walk down while the next lower exponent still passes
+        const float d = nextafterf(t, -INFINITY);
+        if (fminf(0.99f, o * expf(d)) < k) break;
+        t = d;
+    }
+#pragma unroll 1
+    for (int it = 0; it < 16; it++) {     // walk up while this exponent fails
+        if (!(fminf(0.99f, o * expf(t)) < k)) break;
+        t = nextafterf(t, INFINITY);
+    }
+    return t;
+}
+
 // Which of the tile's four 16x4 pixel strips can an entry reach?  Bit s is CLEAR only if the minimum of the
 // conic's quadratic form  f(d) = 0.5 (a dx^2 + c dy^2) + b dx dy,  d = centre - pixel,  over the strip's
 // rectangle exceeds tau (= ln(255 opacity) + margin): then every pixel of the strip has power < ln(1/(255 o))
@@ -218,7 +253,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
             s_xy[tid] = xy;
             const float4 c4 = conic_opacity[id];
             s_co[tid] = c4;
-            const float thr = -__logf(255.0f * c4.w) - 1e-3f;
+            const float thr = alpha_threshold_exact(c4.w);
             s_thr[tid] = thr;
             s_fd[tid] = rgbd[id];
             alive = strip_alive_mask(xy, c4, -thr + 1e-2f + 1e-3f * fabsf(thr), tile_x0, tile_y0);
@@ -238,12 +273,12 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
                     const float2 xy = s_xy[j];
                     const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
                     const float4 co = s_co[j];
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    // cheap certain reject: o*exp(power) < 1/255 whenever power < ln(1/(255 o)) - 1e-3 (the margin
-                    // covers the rounding of the fast log); everything else takes the reference's exact test below
+                    const float power = power_exact(__fmul_rn(__fmul_rn(co.x, dx), dx), __fmul_rn(co.y, dx), co.z, dy);
+                    // alpha >= 1/255  <=>  power >= s_thr (exact, alpha_threshold_exact): only contributing pairs pay
+                    // for the exponential
                     if (!(power > 0.0f) && !(power < s_thr[j])) {
                         const float alpha = fminf(0.99f, co.w * expf(power));
-                        if (!(alpha < 1.0f / 255.0f)) {
+                        {
                             const float test_T = T * (1 - alpha);
                             if (test_T < 0.0001f) {
                                 done = true;
@@ -393,7 +428,7 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
                 s_xy[e] = xy;
                 const float4 c4 = conic_opacity[id];
                 s_co[e] = c4;
-                const float thr = -__logf(255.0f * c4.w);
+                const float thr = alpha_threshold_exact(c4.w);
                 s_thr[e] = thr;
                 s_fd[e] = rgbd[id];
                 alive = strip_alive_mask(xy, c4, -thr + 1e-2f + 1e-3f * fabsf(thr), tile_x0, tile_y0);
@@ -418,8 +453,10 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
                 const float4 co = s_co[j];
                 const float thr = s_thr[j];
                 const float dx = xy.x - pixf_x;
-                // power(dy) = pa + dy * (pb + pc * dy): two FMAs per pixel, no exp on the visited-only path
-                const float pa = -0.5f * co.x * dx * dx, pb = -co.y * dx, pc = -0.5f * co.z;
+                // power in the reference's expression order (backward.cu:528, as the forward pass): for large splats
+                // a dx^2, c dy^2 and b dx dy reach 1e3..1e4 and cancel to O(1), so a re-associated (Horner) form
+                // differs from the forward pass's G by up to 1e-3 relative.  a dx^2 and b dx are per-lane constants.
+                const float pa = __fmul_rn(__fmul_rn(co.x, dx), dx), pb = __fmul_rn(co.y, dx);
                 float v[kAcc];
 #pragma unroll
                 for (int k = 0; k < kAcc; k++) v[k] = 0.f;
@@ -429,10 +466,9 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
                     if (PPL > 1 && !((mj >> (wave + q * WAVES)) & 1u)) continue;   // strip of slot q cannot be reached
                     PixState& p = ps[q];
                     const float dy = xy.y - p.pixf_y;
-                    const float power = fmaf(fmaf(pc, dy, pb), dy, pa);
-                    // alpha >= 1/255 decided on the exponent (power >= ln(1/(255 o))): the exp is only paid by
-                    // contributing pairs.  Pairs within rounding of the threshold may be classified differently
-                    // from the forward pass; their alpha is ~1/255 and the effect is far inside the tolerance.
+                    const float power = power_exact(pa, pb, co.z, dy);
+                    // alpha >= 1/255 decided on the exponent, with the exact per-entry threshold: the same pairs as
+                    // the forward pass and the oracle, and the exp is only paid by contributing pairs
                     const bool valid = (ordinal < p.last_contributor) && !(power > 0.0f) && (power >= thr);
                     if (valid) {
                         any_valid = true;
