@@ -163,7 +163,8 @@ def _patch_launch(x, w_khwc, bias, residual, out_channels):
 def _flipped(weight):
     """Cached dgrad weights [Cin][3][3][Cout] for a frozen conv weight (stored channels_last)."""
     f = getattr(weight, "_gd_flipped", None)
-    if f is None or f.device != weight.device:
+    key = (weight.data_ptr(), weight._version)      # re-derive after load_state_dict / in-place edits of the weight
+    if f is None or f.device != weight.device or getattr(weight, "_gd_flipped_key", None) != key:
         Cout, Cin = weight.shape[0], weight.shape[1]
         f = torch.empty((Cin, Cout, 3, 3), dtype=torch.bfloat16, device=weight.device,
                         memory_format=torch.channels_last)
@@ -173,7 +174,7 @@ def _flipped(weight):
                                                weight.data_ptr(), f.data_ptr(), Cout, Cin)
         if ret < 0:
             raise RuntimeError("gd_nn_conv3x3_flip_weights failed")
-        weight._gd_flipped = f
+        weight._gd_flipped, weight._gd_flipped_key = f, key
     return f
 
 
@@ -218,7 +219,8 @@ class _ConvSmallCin(torch.autograd.Function):
         w = ctx.weight
         Cout, Cin = w.shape[0], w.shape[1]
         f = getattr(w, "_gd_flipped4", None)
-        if f is None or f.device != w.device:
+        key = (w.data_ptr(), w._version)
+        if f is None or f.device != w.device or getattr(w, "_gd_flipped4_key", None) != key:
             f = torch.zeros((4, Cout, 3, 3), dtype=torch.bfloat16, device=w.device).contiguous(
                 memory_format=torch.channels_last)
             wc = w.contiguous(memory_format=torch.channels_last)
@@ -227,7 +229,7 @@ class _ConvSmallCin(torch.autograd.Function):
                                                        f.data_ptr(), Cout, Cin)
             if ret < 0:
                 raise RuntimeError("gd_nn_conv3x3_flip_weights failed")
-            w._gd_flipped4 = f
+            w._gd_flipped4, w._gd_flipped4_key = f, key
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx4 = _conv_launch(dy, f, None, None, 4)
         return dx4[:, :Cin], None, None

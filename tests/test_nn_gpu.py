@@ -326,3 +326,21 @@ def test_plain_conv_on_patch_kernel_matches_fp32_reference(N, Cin, Cout, H, W, p
         err = (y.float() - yr).abs().max().item()
         assert err <= 1.5e-2 * yr.abs().max().item() + 1e-2, err
         assert F.cosine_similarity(y.float().flatten(), yr.flatten(), dim=0).item() > 0.9999
+
+
+def test_flipped_weight_cache_follows_weight_updates():
+    """The dgrad weights are cached per weight tensor; loading new values in place (load_state_dict) must refresh them."""
+    from garmentdreamer_amd.nn_ops import conv3x3
+    cl = torch.channels_last
+    g = torch.Generator(DEV).manual_seed(0)
+    w = (torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05).to(torch.bfloat16).contiguous(memory_format=cl)
+    x = torch.randn(2, 64, 16, 16, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+    gy = torch.randn(2, 64, 16, 16, device=DEV, generator=g).to(torch.bfloat16)
+    for _ in range(2):
+        xg = x.clone().requires_grad_(True)
+        conv3x3(xg, w, None, None).backward(gy)
+        xr = x.float().requires_grad_(True)
+        F.conv2d(xr, w.float(), padding=1).backward(gy.float())
+        assert F.cosine_similarity(xg.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.9995
+        with torch.no_grad():
+            w.copy_((torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05).to(torch.bfloat16))   # "load_state_dict"
