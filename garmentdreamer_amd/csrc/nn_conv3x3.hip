@@ -26,6 +26,7 @@
 // The same kernel computes the input gradient of the convolution (weights frozen, so dgrad is
 // the only backward): conv3x3(dy, w') with w'[ci][tap][co] = w[co][8 - tap][ci].
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -621,6 +622,86 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
     *(uint4*)(out + i) = o;
 }
 
+// First convolution of the VAE encoder / UNet: Cin <= 4 (image or latent -> features), 3x3 / s1 / p1, + bias.
+// K = 9 * Cin <= 36 is far too short for the MFMA pipeline to matter; the layer is an output-write stream
+// (N*H*W*Cout*2 bytes).  One thread = 4 consecutive pixels of a row x 8 output channels: per input row the 6 x Cin
+// window sits in registers, every weight octet (LDS, fp32) is read once per 4 pixels; outputs leave as 16-byte
+// NHWC stores.  Workgroup = Cout/8 channel octets x (256 / (Cout/8)) pixel groups.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const uint16_t* __restrict__ in,
+                                                            const uint16_t* __restrict__ wt,
+                                                            const uint16_t* __restrict__ bias,
+                                                            uint16_t* __restrict__ out, int Nimg, int H, int W, int Cout)
+{
+    constexpr int PX = 4;                                          // pixels per thread
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // [9*CIN][Cout]
+    const int K = 9 * CIN;
+    for (int i = threadIdx.x; i < K * Cout; i += 256) {
+        const int k = i / Cout, co = i - k * Cout;                 // wt: [Cout][3][3][CIN]
+        s_w[i] = bf2f(wt[(size_t)co * K + k]);
+    }
+    __syncthreads();
+    const int octs = Cout >> 3;
+    const int oct = threadIdx.x % octs, grp = threadIdx.x / octs;
+    const int gpb = 256 / octs;                                    // pixel groups per workgroup
+    const int gx = (W + PX - 1) / PX;                              // pixel groups per row
+    const int64_t total = (int64_t)Nimg * H * gx;
+    if (grp >= gpb) return;
+    // persistent workgroups: the weights are staged once per workgroup, then it walks its share of the pixel groups
+    for (int64_t g = (int64_t)blockIdx.x * gpb + grp; g < total; g += (int64_t)gridDim.x * gpb) {
+    const int n = (int)((uint32_t)g / (uint32_t)(H * gx));          // total < 2^31 is checked by the host
+    const int rem = (int)((uint32_t)g - (uint32_t)n * (uint32_t)(H * gx));
+    const int y = rem / gx, x0 = (rem - y * gx) * PX;
+
+    float acc[PX][8];
+    {
+        const uint4 bq = bias ? *(const uint4*)(bias + oct * 8) : make_uint4(0, 0, 0, 0);
+        const uint32_t bw[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[p][k] = bf2f((uint16_t)(bw[k >> 1] >> ((k & 1) * 16)));
+    }
+#pragma unroll 1
+    for (int r = 0; r < 3; r++) {
+        const int yy = y + r - 1;
+        if ((unsigned)yy >= (unsigned)H) continue;                 // zero row: contributes nothing
+        const uint16_t* row = in + ((size_t)n * H + yy) * W * CIN;
+        float win[PX + 2][CIN];
+#pragma unroll
+        for (int c = 0; c < PX + 2; c++) {
+            const int xx = x0 + c - 1;
+            const bool ok = (unsigned)xx < (unsigned)W;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci++) win[c][ci] = ok ? bf2f(row[(size_t)(ok ? xx : 0) * CIN + ci]) : 0.f;
+        }
+        const float* wr = s_w + (size_t)r * 3 * CIN * Cout + oct * 8;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ci++) {
+                const float4 w0 = *(const float4*)(wr + (kx * CIN + ci) * Cout);
+                const float4 w1 = *(const float4*)(wr + (kx * CIN + ci) * Cout + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int p = 0; p < PX; p++) {
+                    const float xv = win[p + kx][ci];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc[p][k] += xv * wv[k];
+                }
+            }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        if (x0 + p >= W) break;
+        uint4 o;
+        o.x = pack_bf16(acc[p][0], acc[p][1]); o.y = pack_bf16(acc[p][2], acc[p][3]);
+        o.z = pack_bf16(acc[p][4], acc[p][5]); o.w = pack_bf16(acc[p][6], acc[p][7]);
+        *(uint4*)(out + (((size_t)n * H + y) * W + x0 + p) * Cout + oct * 8) = o;
+    }
+    }
+}
+
 // w'[ci][tap][co] = w[co][8 - tap][ci]  (dgrad weights; run once per layer, weights are frozen)
 __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ wf, int Cout,
                                             int Cin)
@@ -634,6 +715,7 @@ __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint
     }
 }
 
+int g_first_grid = 2048;   // persistent workgroups of the first-conv kernel (GD_NN_FIRST_GRID overrides, tuning)
 int g_force_split = -1;    // tuning hook: -1 heuristic, 1 = never split, 3 / 9 = force
 int g_force_variant = -1;  // tuning hook: 0 = 128x128, 1 = 128x256, 2 = 256x256, -1 = heuristic
 
@@ -895,6 +977,33 @@ int gd_nn_conv3x3_gn_forward(void* stream, const void* x, const float* mean_rstd
 {
     return launch_patch(stream, x, mean_rstd, gamma, beta, groups, apply_silu, weight, bias, bias_img_stride, residual, y,
                         N, H, W, Cin, Cout);
+}
+
+int gd_nn_conv3x3_first_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int H,
+                                int W, int Cin, int Cout)
+{
+    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 1 || Cin > 4 || Cout % 8 || Cout <= 0 || Cout > 2048 || 256 % (Cout / 8))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first: need 1 <= Cin <= 4, Cout % 8 == 0 and Cout/8 a divisor of 256");
+    const int octs = Cout / 8, gpb = 256 / octs;
+    const int64_t groups = (int64_t)N * H * ((W + 3) / 4);
+    const int64_t blocks = (groups + gpb - 1) / gpb;
+    if (blocks > 2147483647LL) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first: tensor too large");
+    const size_t lds = (size_t)9 * Cin * Cout * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (groups > 2147483647LL) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first: tensor too large");
+    if (const char* e = getenv("GD_NN_FIRST_GRID")) g_first_grid = atoi(e) > 0 ? atoi(e) : g_first_grid;
+#define GD_FIRST(C_)                                                                                               \
+    hipLaunchKernelGGL(conv3x3_first_kernel<C_>, dim3((unsigned)(blocks < g_first_grid ? blocks : g_first_grid)), dim3(256), lds, s, (const uint16_t*)x,    \
+                       (const uint16_t*)weight, (const uint16_t*)bias, (uint16_t*)y, N, H, W, Cout)
+    if (Cin == 1) GD_FIRST(1);
+    else if (Cin == 2) GD_FIRST(2);
+    else if (Cin == 3) GD_FIRST(3);
+    else GD_FIRST(4);
+#undef GD_FIRST
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
 }
 
 int gd_nn_conv3x3_s2_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int Hin,

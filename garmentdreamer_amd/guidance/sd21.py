@@ -441,7 +441,7 @@ class _VAEAttention(nn.Module):
             # one head of dim 512: three plain GEMMs + a softmax (hipBLASLt) beat the fused kernel, whose
             # backward for head_dim 512 runs at ~180 TFLOP/s; the [B,N,N] bf16 score matrix (34 MB per
             # image at N = 4096) is cheap on a 288 GB part
-            p = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * (C ** -0.5), dim=-1)
+            p = torch.softmax(torch.bmm(q * (C ** -0.5), k.transpose(1, 2)), dim=-1)   # scale q (N x C), not the N x N scores
             o = torch.bmm(p, v)
         else:
             o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]

@@ -27,6 +27,7 @@ SIGNATURES = {
     "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
     "gd_nn_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "gd_nn_conv3x3_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "gd_nn_conv_force_variant": (_i, [_i]),
@@ -201,14 +202,28 @@ class _Conv3x3(torch.autograd.Function):
 
 
 class _ConvSmallCin(torch.autograd.Function):
-    """First VAE convolution (Cin = 3): forward through torch's conv, input gradient through the MFMA
-    kernel with the flipped weights zero-padded to 4 output channels (the library dgrad for this shape
-    costs 2.7 ms per step on MI355X; this path ~1 ms)."""
+    """First VAE convolution (Cin = 3): forward on the small-Cin VALU kernel (gd_nn_conv3x3_first_forward; an
+    output-write stream), input gradient through the MFMA kernel with the flipped weights zero-padded to 4 output
+    channels (the library dgrad for this shape costs 2.7 ms per step on MI355X; this path ~0.6 ms)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.weight = weight
         ctx.x_shape = x.shape
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        if 256 % (Cout // 8) == 0 and (bias is None or bias.dtype == torch.bfloat16):
+            xc = x.contiguous(memory_format=torch.channels_last)
+            wc = weight.contiguous(memory_format=torch.channels_last)
+            y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+            L = lib()
+            with torch.cuda.device(x.device):
+                ret = L.gd_nn_conv3x3_first_forward(torch.cuda.current_stream(x.device).cuda_stream, xc.data_ptr(),
+                                                    wc.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                    y.data_ptr(), N, H, W, Cin, Cout)
+            if ret < 0:
+                raise RuntimeError(f"gd_nn_conv3x3_first_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+            return y
         with torch.no_grad():
             return F.conv2d(x, weight, bias, padding=1)
 

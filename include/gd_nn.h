@@ -88,6 +88,12 @@ int gd_nn_conv3x3_gn_forward(void* stream, const void* x, const float* mean_rstd
                              int groups, int apply_silu, const void* weight, const void* bias, int bias_img_stride,
                              const void* residual, void* y, int N, int H, int W, int Cin, int Cout);
 
+/* First convolution (image / latent -> features): 3x3 / s1 / p1 with Cin <= 4, + bias.  x: bf16 [N,H,W,Cin];
+ * weight: bf16 [Cout][3][3][Cin]; y: bf16 [N,H,W,Cout]; Cout % 8 == 0 and Cout/8 divides 256 (128, 256, 320 is
+ * NOT -> use torch there).  VALU kernel, output-write bound (diffusers `conv_in`). */
+int gd_nn_conv3x3_first_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int H,
+                                int W, int Cin, int Cout);
+
 /* 3x3 convolution with stride 2 and padding (pad_lo, 1) per spatial dim -- pad_lo = 1: Conv2d(k3, s2, p1), the
  * UNet's Downsample2D; pad_lo = 0: the VAE encoder's F.pad(x, (0,1,0,1)) + Conv2d(k3, s2, p0) (diffusers
  * Downsample2D; un-vendored, reached through stable_diffusion_guidance.py:153-166) without materialising the
