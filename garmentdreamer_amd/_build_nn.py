@@ -5,6 +5,7 @@ NN_SOURCES = [
     ("nn_groupnorm.hip", ["-munsafe-fp-atomics"]),
     ("nn_conv3x3.hip", []),
     ("nn_elementwise.hip", []),
+    ("nn_attention.hip", []),
 ]
 
 

@@ -1,0 +1,278 @@
+// nn_attention.hip -- fused self-attention forward for head_dim 64 (bf16, no mask, inference): the UNet's
+// spatial self-attention (diffusers Attention -> F.scaled_dot_product_attention; reached through
+// Garment_3DGS/threestudio/models/guidance/stable_diffusion_guidance.py:153-157).  S = 4096 / 1024 / 256 keys.
+//
+// CDNA4 mapping.  Workgroup = 4 wave64s x 32 query rows; K and V tiles of 64 keys stream through LDS by LDS-DMA
+// (double buffered, source-side XOR swizzle -> conflict-free ds_read_b128 fragments).  Scores are computed
+// TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_bf16 with K as the A operand), so a lane holds 32 scores of ONE
+// query: the row maximum / sum are in-lane loops plus a single cross-half exchange, and exp2 / rescaling never
+// leave the lane.  The same registers, packed to bf16, ARE the B operand of O^T += V^T P^T -- the PV product's
+// key order is simply defined by the accumulator layout ({0-3, 8-11} + 4*(lane>>5) within each 16 keys), and
+// the V^T tile is stored with that order baked in (attn_vt_kernel), so one ds_read_b128 yields a lane's eight
+// keys.  No shuffles, no LDS round trip for P.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gd_nn.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+int fail(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
+{
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+// byte offset of logical (row, 16-B chunk j) inside a swizzled [rows][64] bf16 tile image (256-byte lines)
+__device__ __forceinline__ int swz(int row, int j)
+{
+    return (row >> 1) * 256 + (((((row & 1) << 3) | j) ^ ((row >> 1) & 15)) << 4);
+}
+
+__device__ __forceinline__ void bload_lds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, char* lds_wave_base)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
+                                             0, 0);
+}
+
+constexpr int kTq = 128, kTk = 64, kD = 64;
+constexpr int kTile = kTk * kD * 2;   // 8 KB
+
+// V [B][Skv][H*64] (row stride v_rs elements)  ->  Vt [B][H][64][Skv] with the keys of every 16-group stored in
+// the order {0,1,2,3, 8,9,10,11, 4,5,6,7, 12,13,14,15} (see the header).  64 keys x 64 d per workgroup through LDS.
+__global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, int Skv,
+                                                      int H, int64_t v_bs, int v_rs)
+{
+    __shared__ uint16_t tile[64][66];
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+    const uint16_t* src = v + b * v_bs + (int64_t)k0 * v_rs + h * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int key = i >> 6, d = i & 63;
+        tile[key][d] = src[(int64_t)key * v_rs + d];
+    }
+    __syncthreads();
+    uint16_t* dst = vt + (((int64_t)b * H + h) * 64) * Skv + k0;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int d = i >> 6, pos = i & 63;
+        const int p16 = pos & 15;
+        const int key16 = p16 < 4 ? p16 : (p16 < 8 ? p16 + 4 : (p16 < 12 ? p16 - 4 : p16));
+        dst[(int64_t)d * Skv + pos] = tile[(pos & ~15) + key16][d];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                           const uint16_t* __restrict__ vt, uint16_t* __restrict__ o, int S,
+                                                           int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs,
+                                                           int64_t o_bs, int o_rs, float c /* scale * log2(e) */)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                 // 3 stages
+    char* sV = smem + 3 * kTile;     // 3 stages
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y / H, h = blockIdx.y - b * H;
+    const int fh = lane >> 5, fn = lane & 31;
+    const int qrow = blockIdx.x * kTq + wave * 32 + fn;
+    const int qld = qrow < S ? qrow : S - 1;
+
+    // Q fragments (B operand of S^T = K Q^T): lane (query fn, half fh) holds d = 16 kk + 8 fh .. + 7
+    bf16x8_t qf[4];
+    {
+        const uint16_t* qp = q + b * q_bs + (int64_t)qld * q_rs + h * kD + 8 * fh;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) qf[kk] = *(const bf16x8_t*)(qp + 16 * kk);
+    }
+    // K rows: [key][64 d], row stride k_rs elements; Vt rows: [d][Skv]
+    const uint32_t k_row_bytes = (uint32_t)k_rs * 2u, v_row_bytes = (uint32_t)Skv * 2u;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(k + b * k_bs + h * kD), 0, (int)((uint32_t)Skv * k_row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(vt + (((int64_t)b * H + h) * kD) * Skv), 0, (int)((uint32_t)kD * v_row_bytes), 0x00020000);
+    uint32_t k_off[2], v_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int cidx = tid + 256 * i;
+        const int line = cidx >> 4, cc = (cidx & 15) ^ (line & 15);
+        const int r = 2 * line + (cc >> 3);
+        k_off[i] = (uint32_t)r * k_row_bytes + (uint32_t)(cc & 7) * 16u;   // + tile * 64 rows (soffset)
+        v_off[i] = (uint32_t)r * v_row_bytes + (uint32_t)(cc & 7) * 16u;   // + tile * 128 bytes (soffset)
+    }
+    auto issue = [&](int buf, int t) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            bload_lds16(rs_k, k_off[i], (uint32_t)t * kTk * k_row_bytes, sK + buf * kTile + (wave * 64 + 256 * i) * 16);
+            bload_lds16(rs_v, v_off[i], (uint32_t)t * (kTk * 2), sV + buf * kTile + (wave * 64 + 256 * i) * 16);
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o0[r] = o1[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float grow_thr = 8.0f / c;     // 2^8 of head-room in exp2 units, expressed in raw score units
+    const int ntiles = Skv / kTk;
+    uint32_t krd[2], vrd[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        krd[j] = (uint32_t)swz(32 * j + fn, fh);       // K fragment of key block j, kk = 0 (kk: slot ^ 2kk)
+        vrd[j] = (uint32_t)swz(32 * j + fn, fh);       // V^T fragment of d block j, 16-key group 0
+    }
+    // S^T tile of 64 keys x 32 queries (two 32x32 accumulators) from the K stage at `pk`
+    auto qk = [&](const char* pk, f32x16& s0, f32x16& s1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) s0[r] = s1[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const bf16x8_t k0 = *(const bf16x8_t*)(pk + (krd[0] ^ (uint32_t)(kk << 5)));
+            const bf16x8_t k1 = *(const bf16x8_t*)(pk + (krd[1] ^ (uint32_t)(kk << 5)));
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kk], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], s1, 0, 0, 0);
+        }
+    };
+    // Part 1 of the online softmax of the lane's 64 scores: the (deferred) running maximum.
+    auto update_max = [&](const f32x16& s0, const f32x16& s1) {
+        float mx = s0[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s1[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // Deferred maximum: the running reference m_run only moves (and O, l are only rescaled) when some query's
+        // maximum grew by more than 2^8 in exp2 units; otherwise P = exp2((s - m_run) c) <= 256 stays well inside
+        // fp32 / bf16 range and the final division by l normalises it.  The maximum settles after the first
+        // tiles, so the 32-register rescale of O leaves the steady-state loop.
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + grow_thr) != 0) {      // wave-uniform, rare
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
+        }
+    };
+    // Part 2: P = exp2((s - m) c) in place, row sum, O^T += V^T P^T from the V stage at `pv`.
+    auto exp_pv = [&](f32x16& s0, f32x16& s1, const char* pv) {
+        const float mc = m_run * c;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
+            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+            psum += s0[r] + s1[r];
+        }
+        l_run += psum;
+        // P (bf16) as the B operand: regs 8u..8u+7 of score block j  <->  16-key group 2j+u
+        bf16x8_t pb[4];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            uint32_t w0[4], w1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                w0[i] = pack_bf16(s0[8 * u + 2 * i], s0[8 * u + 2 * i + 1]);
+                w1[i] = pack_bf16(s1[8 * u + 2 * i], s1[8 * u + 2 * i + 1]);
+            }
+            pb[u] = __builtin_bit_cast(bf16x8_t, make_uint4(w0[0], w0[1], w0[2], w0[3]));
+            pb[2 + u] = __builtin_bit_cast(bf16x8_t, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+        }
+#pragma unroll
+        for (int g16 = 0; g16 < 4; g16++) {      // 16-key group g16 = 2j + u -> chunks 2 g16 + fh
+            const bf16x8_t v0 = *(const bf16x8_t*)(pv + (vrd[0] ^ (uint32_t)(g16 << 5)));
+            const bf16x8_t v1 = *(const bf16x8_t*)(pv + (vrd[1] ^ (uint32_t)(g16 << 5)));
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb[g16], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb[g16], o1, 0, 0, 0);
+        }
+    };
+
+    // Software pipeline over the KV tiles, three LDS stages: after the (rarely taken) rescale branch, ONE basic
+    // block holds the score MFMAs of tile t+1, the exp2 / sum / pack VALU work of tile t and its P V MFMAs, so the
+    // matrix pipe runs under the transcendental work; the LDS-DMA of tile t+2 is in flight meanwhile.  The loop is
+    // unrolled by two so the score registers ping-pong without copies.
+    issue(0, 0);
+    if (ntiles > 1) issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 sa0, sa1, sb0, sb1;
+    qk(sK, sa0, sa1);
+    auto iteration = [&](int t, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t+1 (issued one iteration ago) has landed
+        __syncthreads();                                      // ... for every wave; stage (t+2)%3 is free again
+        if (t + 2 < ntiles) issue((t + 2) % 3, t + 2);
+        update_max(c0, c1);
+        qk(sK + ((t + 1) % 3) * kTile, n0, n1);
+        exp_pv(c0, c1, sV + (t % 3) * kTile);
+    };
+    int t = 0;
+    for (; t + 2 < ntiles; t += 2) {
+        iteration(t, sa0, sa1, sb0, sb1);
+        iteration(t + 1, sb0, sb1, sa0, sa1);
+    }
+    if (t + 1 < ntiles) {            // one pipelined iteration left (even tile count)
+        iteration(t, sa0, sa1, sb0, sb1);
+        update_max(sb0, sb1);
+        exp_pv(sb0, sb1, sV + ((ntiles - 1) % 3) * kTile);
+    } else {
+        update_max(sa0, sa1);
+        exp_pv(sa0, sa1, sV + ((ntiles - 1) % 3) * kTile);
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < S) {
+        uint16_t* op = o + b * o_bs + (int64_t)qrow * o_rs + h * kD;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {         // rows d = (r & 3) + 8 (r >> 2) + 4 fh of each 32-d block
+            uint2 a, bq;
+            a.x = pack_bf16(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv);
+            a.y = pack_bf16(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
+            bq.x = pack_bf16(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv);
+            bq.y = pack_bf16(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv);
+            *(uint2*)(op + 8 * g4 + 4 * fh) = a;
+            *(uint2*)(op + 32 + 8 * g4 + 4 * fh) = bq;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gd_nn_attention_last_error(void) { return g_err; }
+
+size_t gd_nn_attention_ws_bytes(int B, int Skv, int H) { return (size_t)B * H * 64 * (size_t)Skv * 2; }
+
+int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, const void* v, void* o, void* vt_ws, int B, int S,
+                                int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs, int v_rs,
+                                int64_t o_bs, int o_rs, float scale)
+{
+    if (!q || !k || !v || !o || !vt_ws) return fail(GD_NN_ERR_INVALID_ARG, "attention: null pointer");
+    if (B <= 0 || S <= 0 || H <= 0 || Skv <= 0 || Skv % 64)
+        return fail(GD_NN_ERR_INVALID_ARG, "attention: need Skv % 64 == 0 (head_dim is 64)");
+    if (q_rs % 8 || k_rs % 8 || o_rs % 4 || (double)Skv * k_rs * 2.0 >= 2147483648.0)
+        return fail(GD_NN_ERR_INVALID_ARG, "attention: row strides must keep 16-byte (q, k) / 8-byte (o) alignment");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_vt_kernel, dim3(Skv / 64, H, B), dim3(256), 0, s, (const uint16_t*)v, (uint16_t*)vt_ws, Skv, H,
+                       v_bs, v_rs);
+    hipLaunchKernelGGL(attn_fwd_d64_kernel, dim3((S + kTq - 1) / kTq, B * H), dim3(256), 6 * kTile, s, (const uint16_t*)q,
+                       (const uint16_t*)k, (const uint16_t*)vt_ws, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs, o_rs,
+                       scale * 1.4426950408889634f);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+}  // extern "C"

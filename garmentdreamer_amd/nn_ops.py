@@ -36,6 +36,10 @@ SIGNATURES = {
     "gd_nn_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gd_nn_geglu_forward": (_i, [_vp, _vp, _vp, C.c_int64, _i]),
     "gd_nn_add_layernorm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, C.c_int64, _i]),
+    "gd_nn_attention_ws_bytes": (C.c_size_t, [_i, _i, _i]),
+    "gd_nn_attention_d64_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i,
+                                         C.c_int64, _i, C.c_int64, _i, _f]),
+    "gd_nn_attention_last_error": (C.c_char_p, []),
     "gd_nn_conv_last_error": (C.c_char_p, []),
     "gd_nn_elementwise_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
@@ -483,3 +487,32 @@ def add_layer_norm(x, residual, norm, want_sum: bool = True):
         return (x if residual is None else s), y
     s = x if residual is None else x + residual
     return s, norm(s)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused self-attention forward (head_dim 64, inference)
+# ---------------------------------------------------------------------------------------------
+
+def attention_d64_supported(q, k, v) -> bool:
+    """q, k, v: [B, S, H, 64] views (any batch / row stride, head and channel dims contiguous)."""
+    ok = lambda t: (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[-1] == 64 and t.stride(-1) == 1
+                    and t.stride(2) == 64 and t.stride(1) % 8 == 0)   # noqa: E731
+    return (ok(q) and ok(k) and ok(v) and k.shape[1] % 64 == 0 and k.shape == v.shape and q.shape[0] == k.shape[0]
+            and q.shape[2] == k.shape[2] and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)))
+
+
+def attention_d64(q, k, v):
+    """softmax(q k^T / 8) v for [B, S, H, 64] views; returns [B, S, H*64] (contiguous)."""
+    B, S, H, _ = q.shape
+    Skv = k.shape[1]
+    L = lib()
+    o = torch.empty((B, S, H * 64), dtype=torch.bfloat16, device=q.device)
+    ws = torch.empty(L.gd_nn_attention_ws_bytes(B, Skv, H), dtype=torch.uint8, device=q.device)
+    with torch.cuda.device(q.device):
+        ret = L.gd_nn_attention_d64_forward(torch.cuda.current_stream(q.device).cuda_stream, q.data_ptr(), k.data_ptr(),
+                                            v.data_ptr(), o.data_ptr(), ws.data_ptr(), B, S, Skv, H, q.stride(0), q.stride(1),
+                                            k.stride(0), k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1),
+                                            64 ** -0.5)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_attention_d64_forward failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
+    return o
