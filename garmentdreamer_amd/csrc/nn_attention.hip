@@ -13,12 +13,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/gd_nn.h"
 
 namespace {
 
 thread_local char g_err[256] = "";
+int g_attn_waves = 0;   // GD_NN_ATTN_WAVES = 4 / 8 forces the workgroup size (tuning)
 int fail(int code, const char* msg)
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -48,7 +50,7 @@ __device__ __forceinline__ void bload_lds16(__amdgpu_buffer_rsrc_t rsrc, uint32_
                                              0, 0);
 }
 
-constexpr int kTq = 128, kTk = 64, kD = 64;
+constexpr int kTk = 64, kD = 64;
 constexpr int kTile = kTk * kD * 2;   // 8 KB
 
 // V [B][Skv][H*64] (row stride v_rs elements)  ->  Vt [B][H][64][Skv] with the keys of every 16-group stored in
@@ -73,7 +75,10 @@ __global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict
     }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+// WAVES = 4 or 8 wave64s per workgroup (32 query rows each).  Eight waves share every K / V^T tile: half the LDS-DMA
+// issue and LDS fill per query; four waves give twice the workgroups when the grid is small (one view per GPU).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                            const uint16_t* __restrict__ vt, uint16_t* __restrict__ o, int S,
                                                            int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs,
                                                            int64_t o_bs, int o_rs, float c /* scale * log2(e) */)
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const uint16_t* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y / H, h = blockIdx.y - b * H;
     const int fh = lane >> 5, fn = lane & 31;
-    const int qrow = blockIdx.x * kTq + wave * 32 + fn;
+    constexpr int THREADS = 64 * WAVES, NP = 512 / THREADS;   // 16-byte pieces of a 64 x 64 tile per thread
+    const int qrow = blockIdx.x * (32 * WAVES) + wave * 32 + fn;
     const int qld = qrow < S ? qrow : S - 1;
 
     // Q fragments (B operand of S^T = K Q^T): lane (query fn, half fh) holds d = 16 kk + 8 fh .. + 7
@@ -101,10 +107,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const uint16_t* __
         (void*)(k + b * k_bs + h * kD), 0, (int)((uint32_t)Skv * k_row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(vt + (((int64_t)b * H + h) * kD) * Skv), 0, (int)((uint32_t)kD * v_row_bytes), 0x00020000);
-    uint32_t k_off[2], v_off[2];
+    uint32_t k_off[NP], v_off[NP];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int cidx = tid + 256 * i;
+    for (int i = 0; i < NP; i++) {
+        const int cidx = tid + THREADS * i;
         const int line = cidx >> 4, cc = (cidx & 15) ^ (line & 15);
         const int r = 2 * line + (cc >> 3);
         k_off[i] = (uint32_t)r * k_row_bytes + (uint32_t)(cc & 7) * 16u;   // + tile * 64 rows (soffset)
@@ -112,9 +118,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const uint16_t* __
     }
     auto issue = [&](int buf, int t) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            bload_lds16(rs_k, k_off[i], (uint32_t)t * kTk * k_row_bytes, sK + buf * kTile + (wave * 64 + 256 * i) * 16);
-            bload_lds16(rs_v, v_off[i], (uint32_t)t * (kTk * 2), sV + buf * kTile + (wave * 64 + 256 * i) * 16);
+        for (int i = 0; i < NP; i++) {
+            bload_lds16(rs_k, k_off[i], (uint32_t)t * kTk * k_row_bytes, sK + buf * kTile + (wave * 64 + THREADS * i) * 16);
+            bload_lds16(rs_v, v_off[i], (uint32_t)t * (kTk * 2), sV + buf * kTile + (wave * 64 + THREADS * i) * 16);
         }
     };
 
@@ -265,11 +271,20 @@ int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, cons
     if (q_rs % 8 || k_rs % 8 || o_rs % 4 || (double)Skv * k_rs * 2.0 >= 2147483648.0)
         return fail(GD_NN_ERR_INVALID_ARG, "attention: row strides must keep 16-byte (q, k) / 8-byte (o) alignment");
     hipStream_t s = (hipStream_t)stream;
+    if (const char* e = getenv("GD_NN_ATTN_WAVES")) g_attn_waves = atoi(e);
     hipLaunchKernelGGL(attn_vt_kernel, dim3(Skv / 64, H, B), dim3(256), 0, s, (const uint16_t*)v, (uint16_t*)vt_ws, Skv, H,
                        v_bs, v_rs);
-    hipLaunchKernelGGL(attn_fwd_d64_kernel, dim3((S + kTq - 1) / kTq, B * H), dim3(256), 6 * kTile, s, (const uint16_t*)q,
-                       (const uint16_t*)k, (const uint16_t*)vt_ws, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs, o_rs,
-                       scale * 1.4426950408889634f);
+    const float c = scale * 1.4426950408889634f;
+    int waves = 4;     // 8 waves per workgroup measured the same at batch 16 and worse on small grids (tools/attn_bench.py)
+    if (g_attn_waves == 4 || g_attn_waves == 8) waves = g_attn_waves;
+    if (waves == 8)
+        hipLaunchKernelGGL(attn_fwd_d64_kernel<8>, dim3((S + 255) / 256, B * H), dim3(512), 6 * kTile, s, (const uint16_t*)q,
+                           (const uint16_t*)k, (const uint16_t*)vt_ws, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
+                           o_rs, c);
+    else
+        hipLaunchKernelGGL(attn_fwd_d64_kernel<4>, dim3((S + 127) / 128, B * H), dim3(256), 6 * kTile, s, (const uint16_t*)q,
+                           (const uint16_t*)k, (const uint16_t*)vt_ws, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
+                           o_rs, c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
