@@ -306,29 +306,18 @@ def test_batched_matches_per_view():
         assert float((vps[i].grad - pkg["viewspace_points"].grad[i]).abs().max()) <= 2e-4 * s
 
 
-def test_reference_config_1024_square_sh3_forward_and_backward():
-    """The reference's own Stage-1 render size (1024^2: 4096 tiles, 45 sort bits -> 5 radix passes; SH degree 3)
-    on one view, against the oracle: integers bit-exact, pixels and gradients at the standard tolerance.
-
-    The backward pass is fed the ORACLE's alpha image: this fork derives T_final = 1 - out_alpha
-    (backward.cu:463), and in a dense scene most pixels saturate at T_final ~ 1e-4, where one ulp of out_alpha
-    (the GPU's expf / FMA vs the oracle's) is a 6e-4 relative change of every gradient term of that pixel.  That
-    sensitivity belongs to the reference's formulation (its own CUDA build has it w.r.t. its own expf); with the
-    same alpha image the two backward passes agree at the standard tolerance, and the GPU's own alpha image is
-    checked separately at a tolerance that covers it."""
+def _check_backward_dense(st, args, out, seed):
+    """Backward parity for dense scenes.  This fork derives T_final = 1 - out_alpha (backward.cu:463); where most
+    pixels saturate (T_final ~ 1e-4) one ulp of out_alpha -- the GPU's expf / FMA vs the oracle's -- is a 6e-4
+    relative change of every gradient term of that pixel.  That sensitivity belongs to the reference's formulation
+    (its own CUDA build has it w.r.t. its own expf), so the standard tolerance is checked with the ORACLE's alpha
+    image as the saved forward output, and the GPU's own alpha image at a tolerance that covers the effect."""
     from garmentdreamer_amd.diff_gaussian_rasterization import _C
     from oracle import gd_oracle
-    HW = 1024
-    inp = h.raster_inputs(P=30000, H=HW, W=HW, sh_degree=3, seed=21, scale_mul=1.5)
-    st = h.oracle_forward(inp)
-    assert st.num_rendered > 100000
-    args, out = _run_gpu_forward(inp)
-    sc = _check_forward(inp, st, out)
-    assert int((sc["n_contrib"][0] != st.n_contrib).sum()) == 0
-    assert int(sc["pair_counts"][0, :, :, 1].sum()) == st.pairs_blended_fwd      # the same contributing pairs
-    gc, gd, ga = h.random_image_grads(HW, HW, seed=3)
-    ref = gd_oracle.backward(st, gc, gd, ga)
     R, color, depth, alpha, radii, geom, binning, img = out
+    HW_h, HW_w = alpha.shape[-2], alpha.shape[-1]
+    gc, gd, ga = h.random_image_grads(HW_h, HW_w, seed=seed)
+    ref = gd_oracle.backward(st, gc, gd, ga)
     t = lambda a: torch.as_tensor(a, device=DEV)
     (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, _, _) = args
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
@@ -340,3 +329,32 @@ def test_reference_config_1024_square_sh3_forward_and_backward():
         torch.cuda.synchronize()
         for n, g in zip(names, grads):
             _check_grads(n, g, ref[n], rtol=rtol, atol_scale=atol)
+
+
+def test_reference_config_1024_square_sh3_forward_and_backward():
+    """The reference's own Stage-1 render size (1024^2: 4096 tiles, 45 sort bits -> 5 radix passes; SH degree 3)
+    on one view, against the oracle: integers bit-exact, the same contributing pairs, pixels and gradients at the
+    standard tolerance (see _check_backward_dense for how the alpha image enters)."""
+    HW = 1024
+    inp = h.raster_inputs(P=30000, H=HW, W=HW, sh_degree=3, seed=21, scale_mul=1.5)
+    st = h.oracle_forward(inp)
+    assert st.num_rendered > 100000
+    args, out = _run_gpu_forward(inp)
+    sc = _check_forward(inp, st, out)
+    assert int((sc["n_contrib"][0] != st.n_contrib).sum()) == 0
+    assert int(sc["pair_counts"][0, :, :, 1].sum()) == st.pairs_blended_fwd      # the same contributing pairs
+    _check_backward_dense(st, args, out, seed=3)
+
+
+def test_full_benchmark_size_parity_100k_gaussians_512():
+    """BASELINE.json configs[1]: 100 000 Gaussians @ 512^2 (the per-view workload of the benchmark), forward and
+    backward against the oracle -- the full size, not a scaled-down stand-in."""
+    HW = 512
+    inp = h.raster_inputs(P=100000, H=HW, W=HW, sh_degree=0, seed=0)
+    st = h.oracle_forward(inp)
+    assert st.num_rendered > 300000
+    args, out = _run_gpu_forward(inp)
+    sc = _check_forward(inp, st, out)
+    assert int((sc["n_contrib"][0] != st.n_contrib).sum()) == 0
+    assert int(sc["pair_counts"][0, :, :, 1].sum()) == st.pairs_blended_fwd
+    _check_backward_dense(st, args, out, seed=8)
