@@ -38,6 +38,11 @@ from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, co
                       conv3x3_supported, geglu, gn_conv3x3, gn_conv3x3_supported, group_norm_silu)
 
 
+import os as _os
+
+_FUSED_QKV = _os.environ.get("GD_FUSED_QKV", "1") != "0"   # A/B toggle of the fused self-attention projection
+
+
 def _gn(norm: nn.GroupNorm, x, silu: bool):
     """GroupNorm (+SiLU): fused NHWC HIP kernel on the GPU (nn_ops), torch ops on CPU."""
     return group_norm_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu)
@@ -145,7 +150,16 @@ class Attention(nn.Module):
     def forward(self, x, context=None):
         B, N, _ = x.shape
         ctx = x if context is None else context
-        q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
+        if _FUSED_QKV and context is None and self.lora is None and x.is_cuda and self.to_q.bias is None and \
+                not self.to_q.weight.requires_grad and not torch.is_grad_enabled():
+            # frozen self-attention: ONE [C, 3C] projection; the attention kernel reads the three strided views
+            src = (self.to_q.weight.data_ptr(), self.to_q.weight._version, x.dtype)
+            if getattr(self, "_wqkv_src", None) != src:
+                self._wqkv = torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], dim=0).detach().contiguous()
+                self._wqkv_src = src
+            q, k, v = F.linear(x, self._wqkv).chunk(3, dim=-1)
+        else:
+            q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if self.lora is not None:
             q = q + self.lora_scale * self.lora["to_q_lora"](x)
             k = k + self.lora_scale * self.lora["to_k_lora"](ctx)
