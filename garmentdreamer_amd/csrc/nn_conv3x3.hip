@@ -983,8 +983,8 @@ int gd_nn_conv3x3_first_forward(void* stream, const void* x, const void* weight,
                                 int W, int Cin, int Cout)
 {
     if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
-    if (N <= 0 || H <= 0 || W <= 0 || Cin < 1 || Cin > 4 || Cout % 8 || Cout <= 0 || Cout > 2048 || 256 % (Cout / 8))
-        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first: need 1 <= Cin <= 4, Cout % 8 == 0 and Cout/8 a divisor of 256");
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 1 || Cin > 4 || Cout % 8 || Cout <= 0 || (size_t)9 * Cin * Cout * 4 > 65536)
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first: need 1 <= Cin <= 4, Cout % 8 == 0 and 36*Cin*Cout <= 64 KiB of LDS");
     const int octs = Cout / 8, gpb = 256 / octs;
     const int64_t groups = (int64_t)N * H * ((W + 3) / 4);
     const int64_t blocks = (groups + gpb - 1) / gpb;

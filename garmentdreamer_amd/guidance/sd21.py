@@ -382,7 +382,8 @@ class UNet2DConditionModel(nn.Module):
         extra = self.extra_embedding(sample.shape[0], **kwargs)
         if extra is not None:
             temb = temb + extra.to(dtype)
-        x = self.conv_in(sample.to(dtype).contiguous(memory_format=torch.channels_last))
+        x = conv3x3_small_cin(sample.to(dtype).contiguous(memory_format=torch.channels_last), self.conv_in.weight,
+                              self.conv_in.bias)
         ctx = encoder_hidden_states.to(dtype)
         skips = [x]
         for blk in self.down_blocks:

@@ -216,7 +216,7 @@ class _ConvSmallCin(torch.autograd.Function):
         ctx.x_shape = x.shape
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
-        if 256 % (Cout // 8) == 0 and (bias is None or bias.dtype == torch.bfloat16):
+        if Cout % 8 == 0 and 36 * Cin * Cout <= 65536 and (bias is None or bias.dtype == torch.bfloat16):
             xc = x.contiguous(memory_format=torch.channels_last)
             wc = weight.contiguous(memory_format=torch.channels_last)
             y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)

@@ -89,8 +89,8 @@ int gd_nn_conv3x3_gn_forward(void* stream, const void* x, const float* mean_rstd
                              const void* residual, void* y, int N, int H, int W, int Cin, int Cout);
 
 /* First convolution (image / latent -> features): 3x3 / s1 / p1 with Cin <= 4, + bias.  x: bf16 [N,H,W,Cin];
- * weight: bf16 [Cout][3][3][Cin]; y: bf16 [N,H,W,Cout]; Cout % 8 == 0 and Cout/8 divides 256 (128, 256, 320 is
- * NOT -> use torch there).  VALU kernel, output-write bound (diffusers `conv_in`). */
+ * weight: bf16 [Cout][3][3][Cin]; y: bf16 [N,H,W,Cout]; Cout % 8 == 0, 36*Cin*Cout bytes of LDS <= 64 KiB.
+ * VALU kernel (diffusers `conv_in` of the VAE encoder and of the UNet). */
 int gd_nn_conv3x3_first_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int H,
                                 int W, int Cin, int Cout);
 

@@ -124,6 +124,14 @@ def test_first_conv_small_cin_and_conv1x1_match_torch():
     assert xg.grad.shape == x.shape
     assert F.cosine_similarity(xg.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.9995
     assert (xg.grad.float() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item() + 1e-2
+    # ragged row groups (W % 4 != 0), Cin = 4 (UNet conv_in), another Cout
+    x4 = torch.rand(1, 4, 17, 53, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w4 = (torch.randn(320, 4, 3, 3, device=DEV, generator=g) / 6).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b4 = torch.randn(320, device=DEV, generator=g).to(torch.bfloat16)     # 40 channel octets: 240 of 256 threads used
+    with torch.no_grad():
+        y4 = conv3x3_small_cin(x4, w4, b4)
+        r4 = F.conv2d(x4.float(), w4.float(), b4.float(), padding=1)
+    assert y4.shape == r4.shape and (y4.float() - r4).abs().max().item() <= 2e-2 * r4.abs().max().item()
     x1 = torch.randn(2, 256, 12, 20, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w1 = (torch.randn(128, 256, 1, 1, device=DEV, generator=g) / 16).to(torch.bfloat16)
     b1 = torch.randn(128, device=DEV, generator=g).to(torch.bfloat16)
