@@ -124,8 +124,20 @@ class StableDiffusionGuidance(nn.Module):
         x, tt, ctx = latents.to(self.weights_dtype), t.to(self.weights_dtype), \
             encoder_hidden_states.to(self.weights_dtype)
         if self.cfg.use_hip_graphs and x.is_cuda and not torch.is_grad_enabled():
-            return self._graphed_unet(x, tt, ctx).to(input_dtype)
+            try:
+                return self._graphed_unet(x, tt, ctx).to(input_dtype)
+            except RuntimeError as e:      # capture refused (driver / allocator state): keep running, eagerly
+                self._graphs_failed(e)
         return self.unet(x, tt, encoder_hidden_states=ctx).to(input_dtype)
+
+    def _graphs_failed(self, err):
+        """hipGraph capture is an optimisation: if it cannot be set up, say so once and continue with eager launches."""
+        import warnings
+        warnings.warn(f"hipGraph capture failed ({err}); continuing with eager kernel launches")
+        self.cfg.use_hip_graphs = False
+        self._unet_graphs.clear()
+        self._vae_graphs.clear()
+        torch.cuda.synchronize()
 
     # ---- hipGraph replay ----------------------------------------------------------------------
     def _graphed_unet(self, x, t, ctx):
@@ -171,7 +183,11 @@ class StableDiffusionGuidance(nn.Module):
         imgs = imgs * 2.0 - 1.0
         if self.cfg.use_hip_graphs and imgs.is_cuda and torch.is_grad_enabled() and imgs.requires_grad:
             x = imgs.to(self.weights_dtype).contiguous(memory_format=torch.channels_last)
-            posterior = sd21.DiagonalGaussianDistribution(self._graphed_vae_moments(x))
+            try:
+                posterior = sd21.DiagonalGaussianDistribution(self._graphed_vae_moments(x))
+            except RuntimeError as e:
+                self._graphs_failed(e)
+                posterior = self.vae.encode(imgs.to(self.weights_dtype)).latent_dist
         else:
             posterior = self.vae.encode(imgs.to(self.weights_dtype)).latent_dist
         noise = None if vae_noise is None else vae_noise.to(self.weights_dtype)
