@@ -18,7 +18,7 @@ of one collective per parameter tensor.  Parameters and optimizer state are repl
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist

@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import numpy as np
 import torch
