@@ -107,7 +107,6 @@ def count_pairs(loop, batch, device):
 def cpu_baseline(args):
     """CPU oracle rasterizer (1 thread) + fp32 PyTorch-CPU VAE/UNet for ONE view, scaled to the 8-view
     iteration.  Test infrastructure used as the reported baseline only (never as the product path)."""
-    import numpy as np
     from garmentdreamer_amd.guidance import sd21
     from oracle import gd_oracle
     from tests import helpers as h
