@@ -33,6 +33,7 @@ __device__ __forceinline__ uint16_t f2bf(float f)
     return (uint16_t)(u >> 16);
 }
 
+int g_partials_max_hw = 4096;   // GD_GN_PARTIALS_HW overrides (tuning)
 bool g_partials = true;   // gd_nn_groupnorm_partials(0): atomic mode everywhere (A/B timing)
 constexpr int kMaxThreads = 320;  // C = 2560 -> 320 vectors per pixel
 
@@ -309,7 +310,7 @@ bool make_geo(int HW, int C, int G, int N, Geo* g)
     // atomics; see read_group_sums).
     // needs >= 128 statistics workgroups in the launch to fill the chip: 4+ images (with 1-2 images the atomic
     // form with 64 chunks per image measured faster: 15.05 vs 15.6 ms per step at one view per GPU)
-    const bool partials = g_partials && HW <= 4096 && N >= 4;
+    const bool partials = g_partials && HW <= g_partials_max_hw && N >= 4;
     const int cap = partials ? (N >= 8 ? 16 : kMaxParts) : (HW >= 65536 ? 256 : 64);
     int ppbs = (HW + cap - 1) / cap;
     if (ppbs < ppb) ppbs = ppb;
@@ -334,6 +335,7 @@ size_t gd_nn_groupnorm_ws_bytes(int N, int G) { return (size_t)kMaxParts * N * G
 
 int gd_nn_groupnorm_partials(int on)
 {
+    if (on > 1) g_partials_max_hw = on;      // on > 1: also sets the pixel-count limit of the partials mode
     g_partials = on != 0;
     return GD_NN_OK;
 }

@@ -57,8 +57,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if os.environ.get("GD_GN_PARTIALS") == "0":     # A/B toggle: fp64-atomic GroupNorm statistics everywhere
-            L.gd_nn_groupnorm_partials(0)
+        if os.environ.get("GD_GN_PARTIALS"):     # A/B toggle: 0 = fp64-atomic statistics everywhere, n > 1 = HW limit
+            L.gd_nn_groupnorm_partials(int(os.environ["GD_GN_PARTIALS"]))
         _lib = L
     return _lib
 
