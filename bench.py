@@ -307,8 +307,16 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- health (untimed): a fast step that has silently gone non-finite renders nothing and times "well" ----
+    with torch.no_grad():
+        params_finite = all(bool(torch.isfinite(p).all()) for p in gaussians.parameters())
+    if not params_finite:
+        raise SystemExit("bench.py: Gaussian parameters are not finite after the timed steps -- the measurement is void")
+
     # ---- work accounting (untimed) ----
     counts = count_pairs(loop, camera_batch(args, args.warmup, view_ids), device)
+    if counts["num_rendered"] <= 0:
+        raise SystemExit("bench.py: nothing is rendered after the timed steps -- the measurement is void")
     bwd_ms, bwd_n = prof["render_bwd"]
     flops_launch = FLOPS_VISITED_PAIR * counts["pairs_visited_bwd"] + FLOPS_CONTRIB_PAIR * counts["pairs_contrib"]
     roofline = None
@@ -365,6 +373,7 @@ def main():
             "roofline_raster_bwd": roofline,
             "raster_kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
             "pair_counts_rank0": counts,
+            "health": {"params_finite": params_finite, "visible_after_timed_steps": counts["visible"]},
         }
         if not args.raster_only:
             dense_tflop = V * (2 * UNET_TFLOP_PER_SAMPLE + 2 * VAE_TFLOP_PER_IMAGE)

@@ -33,15 +33,12 @@ __device__ __forceinline__ uint16_t f2bf(float f)
     return (uint16_t)(u >> 16);
 }
 
-int g_partials_max_hw = 4096;   // GD_GN_PARTIALS_HW overrides (tuning)
-bool g_partials = true;   // gd_nn_groupnorm_partials(0): atomic mode everywhere (A/B timing)
 constexpr int kMaxThreads = 320;  // C = 2560 -> 320 vectors per pixel
 
 // Sum over the workgroup of per-thread per-channel partials, folded to per-group totals and added
 // to ws[n][g][0..1] in fp64.  `a`, `b`: the thread's 8-channel partial sums of two quantities.
 __device__ __forceinline__ void reduce_to_groups(const float (&a)[8], const float (&b)[8], int vpp, int rows, int tv,
-                                                 int tr, int C, int G, double* __restrict__ ws_n, float* lds,
-                                                 bool store_partial)
+                                                 int tr, int C, int G, double* __restrict__ ws_n, float* lds)
 {
     // lds: [2][rows][C]
     float* la = lds;
@@ -70,40 +67,13 @@ __device__ __forceinline__ void reduce_to_groups(const float (&a)[8], const floa
             sa += la[c];
             sb += lb[c];
         }
-        if (store_partial) {          // partials mode: this workgroup's own slot, no zeroing, no atomics
-            ws_n[2 * g] = (double)sa;
-            ws_n[2 * g + 1] = (double)sb;
-        } else {
-            atomicAdd(&ws_n[2 * g], (double)sa);
-            atomicAdd(&ws_n[2 * g + 1], (double)sb);
-        }
-    }
-}
-
-// Statistics workspace, two modes (Geo::nparts):
-//   nparts == 0  "atomic": ws[n][g][2], zeroed by the caller, every statistics workgroup adds with fp64 atomics
-//                (big tensors: hundreds of workgroups per image).
-//   nparts  > 0  "partials": ws[part][n][g][2], workgroup `part` of image n stores its sums, readers add the nparts
-//                (16, or 32 for 4-7 images) slots themselves.  No memset launch, no atomics, bitwise reproducible -- used for the
-//                UNet-size maps (<= 4096 pixels), where a GroupNorm call is ~20 us and each launch counts.
-constexpr int kMaxParts = 32;
-__device__ __forceinline__ void read_group_sums(const double* __restrict__ ws, int nparts, int N, int n, int G, int g,
-                                                double& a, double& b)
-{
-    if (nparts == 0) {
-        a = ws[((size_t)n * G + g) * 2];
-        b = ws[((size_t)n * G + g) * 2 + 1];
-        return;
-    }
-    a = b = 0.0;
-    for (int p = 0; p < nparts; p++) {
-        a += ws[(((size_t)p * N + n) * G + g) * 2];
-        b += ws[(((size_t)p * N + n) * G + g) * 2 + 1];
+        atomicAdd(&ws_n[2 * g], (double)sa);
+        atomicAdd(&ws_n[2 * g + 1], (double)sb);
     }
 }
 
 __global__ void gn_stats_kernel(const bf16x8* __restrict__ x, int HW, int C, int G, int vpp, int rows, int ppb,
-                                double* __restrict__ ws, int nparts)
+                                double* __restrict__ ws)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = blockIdx.y;
@@ -122,20 +92,17 @@ __global__ void gn_stats_kernel(const bf16x8* __restrict__ x, int HW, int C, int
             ss[k] += f * f;
         }
     }
-    reduce_to_groups(s, ss, vpp, rows, tv, tr, C, G,
-                     ws + ((size_t)(nparts ? blockIdx.x : 0) * gridDim.y + n) * G * 2, lds, nparts != 0);
+    reduce_to_groups(s, ss, vpp, rows, tv, tr, C, G, ws + (size_t)n * G * 2, lds);
 }
 
 // ws[n][g] = {sum, sum of squares} (fp64)  ->  mean_rstd[n][g] = {mean, rstd} (same arithmetic as gn_apply_kernel)
-__global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean_rstd, int N, int G, double M,
-                                   float eps, int nparts)
+__global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean_rstd, int NG, double M,
+                                   float eps)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * G) return;
-    double sa, sb;
-    read_group_sums(ws, nparts, N, i / G, G, i % G, sa, sb);
-    const double mean = sa / M;
-    double var = sb / M - mean * mean;
+    if (i >= NG) return;
+    const double mean = ws[2 * i] / M;
+    double var = ws[2 * i + 1] / M - mean * mean;
     var = var < 0 ? 0 : var;
     mean_rstd[2 * i] = (float)mean;
     mean_rstd[2 * i + 1] = rsqrtf((float)var + eps);
@@ -146,7 +113,7 @@ __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z))
 __global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y,
                                 const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta, int HW, int C,
                                 int G, int vpp, int rows, int ppb, float eps, int apply_silu,
-                                const double* __restrict__ ws, float* __restrict__ mean_rstd, int nparts)
+                                const double* __restrict__ ws, float* __restrict__ mean_rstd)
 {
     const int n = blockIdx.y;
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
@@ -154,17 +121,11 @@ __global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict
     const int cg = C / G;
     const double M = (double)HW * cg;
     float a[8], b[8];
-    int g_prev = -1;
-    double sa = 0, sb = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int c = tv * 8 + k, g = c / cg;
-        if (g != g_prev) {            // a thread's 8 channels span 1-3 groups: read each group's sums once
-            read_group_sums(ws, nparts, gridDim.y, n, G, g, sa, sb);
-            g_prev = g;
-        }
-        const double mean = sa / M;
-        double var = sb / M - mean * mean;
+        const double mean = ws[((size_t)n * G + g) * 2] / M;
+        double var = ws[((size_t)n * G + g) * 2 + 1] / M - mean * mean;
         var = var < 0 ? 0 : var;
         const float rstd = rsqrtf((float)var + eps);
         a[k] = rstd * bf2f(gamma[c]);
@@ -193,7 +154,7 @@ __global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict
 __global__ void gn_bwd_stats_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy,
                                     const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                                     const float* __restrict__ mean_rstd, int HW, int C, int G, int vpp, int rows,
-                                    int ppb, int apply_silu, double* __restrict__ ws, int nparts)
+                                    int ppb, int apply_silu, double* __restrict__ ws)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = blockIdx.y;
@@ -229,15 +190,13 @@ __global__ void gn_bwd_stats_kernel(const bf16x8* __restrict__ x, const bf16x8* 
             s2[k] += t * xh;
         }
     }
-    reduce_to_groups(s1, s2, vpp, rows, tv, tr, C, G,
-                     ws + ((size_t)(nparts ? blockIdx.x : 0) * gridDim.y + n) * G * 2, lds, nparts != 0);
+    reduce_to_groups(s1, s2, vpp, rows, tv, tr, C, G, ws + (size_t)n * G * 2, lds);
 }
 
 __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy,
                                     const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                                     const float* __restrict__ mean_rstd, bf16x8* __restrict__ dx, int HW, int C,
-                                    int G, int vpp, int rows, int ppb, int apply_silu, const double* __restrict__ ws,
-                                    int nparts)
+                                    int G, int vpp, int rows, int ppb, int apply_silu, const double* __restrict__ ws)
 {
     const int n = blockIdx.y;
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
@@ -245,8 +204,6 @@ __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* 
     const int cg = C / G;
     const float invM = 1.f / ((float)HW * cg);
     float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
-    int g_prev = -1;
-    double sa = 0, sb = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int c = tv * 8 + k, g = c / cg;
@@ -254,12 +211,8 @@ __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* 
         rstd[k] = mean_rstd[((size_t)n * G + g) * 2 + 1];
         gm[k] = bf2f(gamma[c]);
         bt[k] = bf2f(beta[c]);
-        if (g != g_prev) {
-            read_group_sums(ws, nparts, gridDim.y, n, G, g, sa, sb);
-            g_prev = g;
-        }
-        m1[k] = (float)sa * invM;
-        m2[k] = (float)sb * invM;
+        m1[k] = (float)ws[((size_t)n * G + g) * 2] * invM;
+        m2[k] = (float)ws[((size_t)n * G + g) * 2 + 1] * invM;
     }
     const bf16x8* xn = x + (size_t)n * HW * vpp;
     const bf16x8* dn = dy + (size_t)n * HW * vpp;
@@ -286,7 +239,6 @@ __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* 
 struct Geo {
     int vpp, rows, threads, ppb, nchunks;
     int ppb_stats, nchunks_stats;   // statistics passes: fewer, larger chunks (see make_geo)
-    int nparts;                     // > 0: partials mode with this many workgroups per image (== nchunks_stats)
     size_t lds;
 };
 
@@ -306,17 +258,11 @@ bool make_geo(int HW, int C, int G, int N, Geo* g)
     // Every statistics workgroup ends with 2*G fp64 atomics onto the SAME 2*G addresses of its image;
     // with hundreds of chunks per image those serialise in L2 (35-75 us per call measured at batch 2).
     // Cap the chunks per image (64, or 256 for the big VAE tensors that need the parallelism).
-    // Maps of <= 4096 pixels (UNet): at most kMaxParts workgroups per image and the partials mode (no memset, no
-    // atomics; see read_group_sums).
-    // needs >= 128 statistics workgroups in the launch to fill the chip: 4+ images (with 1-2 images the atomic
-    // form with 64 chunks per image measured faster: 15.05 vs 15.6 ms per step at one view per GPU)
-    const bool partials = g_partials && HW <= g_partials_max_hw && N >= 4;
-    const int cap = partials ? (N >= 8 ? 16 : kMaxParts) : (HW >= 65536 ? 256 : 64);
+    const int cap = HW >= 65536 ? 256 : 64;
     int ppbs = (HW + cap - 1) / cap;
     if (ppbs < ppb) ppbs = ppb;
     g->ppb_stats = ppbs;
     g->nchunks_stats = (HW + ppbs - 1) / ppbs;
-    g->nparts = partials ? g->nchunks_stats : 0;
     g->lds = (size_t)2 * g->rows * C * sizeof(float);
     return true;
 }
@@ -331,14 +277,7 @@ int fail(int code, const char* msg)
 
 extern "C" {
 
-size_t gd_nn_groupnorm_ws_bytes(int N, int G) { return (size_t)kMaxParts * N * G * 2 * sizeof(double); }
-
-int gd_nn_groupnorm_partials(int on)
-{
-    if (on > 1) g_partials_max_hw = on;      // on > 1: also sets the pixel-count limit of the partials mode
-    g_partials = on != 0;
-    return GD_NN_OK;
-}
+size_t gd_nn_groupnorm_ws_bytes(int N, int G) { return (size_t)N * G * 2 * sizeof(double); }
 
 int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
                                  int HW, int C, int G, float eps, int apply_silu, double* stats_ws, float* mean_rstd)
@@ -347,14 +286,13 @@ int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const voi
     if (!x || !y || !gamma || !beta || !stats_ws || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
     hipStream_t s = (hipStream_t)stream;
-    if (g.nparts == 0 && hipMemsetAsync(stats_ws, 0, (size_t)N * G * 2 * sizeof(double), s) != hipSuccess)
+    if (hipMemsetAsync(stats_ws, 0, gd_nn_groupnorm_ws_bytes(N, G), s) != hipSuccess)
         return fail(GD_NN_ERR_HIP, "hipMemsetAsync failed");
     dim3 grid(g.nchunks, N), block(g.threads), grid_s(g.nchunks_stats, N);
     hipLaunchKernelGGL(gn_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows,
-                       g.ppb_stats, stats_ws, g.nparts);
+                       g.ppb_stats, stats_ws);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (bf16x8*)y, (const uint16_t*)gamma,
-                       (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, eps, apply_silu, stats_ws, mean_rstd,
-                       g.nparts);
+                       (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, eps, apply_silu, stats_ws, mean_rstd);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
@@ -367,13 +305,13 @@ int gd_nn_groupnorm_stats(void* stream, const void* x, int N, int HW, int C, int
     if (!x || !stats_ws || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
     hipStream_t s = (hipStream_t)stream;
-    if (g.nparts == 0 && hipMemsetAsync(stats_ws, 0, (size_t)N * G * 2 * sizeof(double), s) != hipSuccess)
+    if (hipMemsetAsync(stats_ws, 0, gd_nn_groupnorm_ws_bytes(N, G), s) != hipSuccess)
         return fail(GD_NN_ERR_HIP, "hipMemsetAsync failed");
     dim3 block(g.threads), grid_s(g.nchunks_stats, N);
     hipLaunchKernelGGL(gn_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows,
-                       g.ppb_stats, stats_ws, g.nparts);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * G + 255) / 256), dim3(256), 0, s, stats_ws, mean_rstd, N, G,
-                       (double)HW * (C / G), eps, g.nparts);
+                       g.ppb_stats, stats_ws);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * G + 255) / 256), dim3(256), 0, s, stats_ws, mean_rstd, N * G,
+                       (double)HW * (C / G), eps);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
@@ -388,15 +326,15 @@ int gd_nn_groupnorm_silu_backward(void* stream, const void* x, const void* dy, c
         return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
     hipStream_t s = (hipStream_t)stream;
-    if (g.nparts == 0 && hipMemsetAsync(stats_ws, 0, (size_t)N * G * 2 * sizeof(double), s) != hipSuccess)
+    if (hipMemsetAsync(stats_ws, 0, gd_nn_groupnorm_ws_bytes(N, G), s) != hipSuccess)
         return fail(GD_NN_ERR_HIP, "hipMemsetAsync failed");
     dim3 grid(g.nchunks, N), block(g.threads), grid_s(g.nchunks_stats, N);
     hipLaunchKernelGGL(gn_bwd_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, (const bf16x8*)dy,
                        (const uint16_t*)gamma, (const uint16_t*)beta, mean_rstd, HW, C, G, g.vpp, g.rows,
-                       g.ppb_stats, apply_silu, stats_ws, g.nparts);
+                       g.ppb_stats, apply_silu, stats_ws);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (const bf16x8*)dy,
                        (const uint16_t*)gamma, (const uint16_t*)beta, mean_rstd, (bf16x8*)dx, HW, C, G, g.vpp, g.rows,
-                       g.ppb, apply_silu, stats_ws, g.nparts);
+                       g.ppb, apply_silu, stats_ws);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

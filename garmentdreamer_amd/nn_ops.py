@@ -20,7 +20,6 @@ SIGNATURES = {
     "gd_nn_groupnorm_silu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "gd_nn_groupnorm_silu_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
-    "gd_nn_groupnorm_partials": (_i, [_i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_ws_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_forward_ws": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t]),
@@ -57,8 +56,6 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if os.environ.get("GD_GN_PARTIALS"):     # A/B toggle: 0 = fp64-atomic statistics everywhere, n > 1 = HW limit
-            L.gd_nn_groupnorm_partials(int(os.environ["GD_GN_PARTIALS"]))
         _lib = L
     return _lib
 
@@ -78,7 +75,7 @@ class _GroupNormSiLU(torch.autograd.Function):
         N, Cc, H, W = x.shape
         L = lib()
         y = torch.empty_like(x, memory_format=torch.channels_last)
-        ws = torch.empty(L.gd_nn_groupnorm_ws_bytes(N, groups) // 8, dtype=torch.float64, device=x.device)
+        ws = torch.empty(N * groups * 2, dtype=torch.float64, device=x.device)
         mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
         w, b = weight.contiguous(), bias.contiguous()
         with torch.cuda.device(x.device):
@@ -99,7 +96,7 @@ class _GroupNormSiLU(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
-        ws = torch.empty(lib().gd_nn_groupnorm_ws_bytes(N, ctx.groups) // 8, dtype=torch.float64, device=x.device)
+        ws = torch.empty(N * ctx.groups * 2, dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _check(L.gd_nn_groupnorm_silu_backward(stream, x.data_ptr(), dy.data_ptr(), w.data_ptr(), b.data_ptr(),
@@ -320,7 +317,7 @@ class _GNConv3x3(torch.autograd.Function):
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
         L = lib()
-        ws = torch.empty(L.gd_nn_groupnorm_ws_bytes(N, groups) // 8, dtype=torch.float64, device=x.device)
+        ws = torch.empty(N * groups * 2, dtype=torch.float64, device=x.device)
         mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
         y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
         gw, gb = gn_weight.contiguous(), gn_bias.contiguous()
@@ -354,7 +351,7 @@ class _GNConv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dact = _conv_launch(dy, _flipped(w), None, None, Cin)          # gradient w.r.t. act(GN(x))
             dx = torch.empty_like(x, memory_format=torch.channels_last)
-            ws = torch.empty(lib().gd_nn_groupnorm_ws_bytes(N, ctx.groups) // 8, dtype=torch.float64, device=x.device)
+            ws = torch.empty(N * ctx.groups * 2, dtype=torch.float64, device=x.device)
             L = lib()
             with torch.cuda.device(x.device):
                 stream = torch.cuda.current_stream(x.device).cuda_stream

@@ -25,9 +25,7 @@ extern "C" {
 
 /* y = act(GroupNorm_G(x) * gamma + beta), act = SiLU if apply_silu else identity.
  * x, y: bf16 [N, HW, C] (NHWC); gamma, beta: bf16 [C]; C % 8 == 0, C % G == 0.
- * stats_ws: gd_nn_groupnorm_ws_bytes(N, G) bytes of scratch (the call initialises what it uses: either
- * zeroed [N][G][2] sums for fp64 atomics, or -- maps of <= 4096 pixels, N >= 4 -- up to 32 per-workgroup partial slots
- * that need no zeroing and no atomics); mean_rstd: N*G*2 floats out
+ * stats_ws: N*G*2 doubles of scratch (zeroed by the call); mean_rstd: N*G*2 floats out
  * (saved for backward).  Replaces F.group_norm + F.silu (two kernels + two NCHW<->NHWC copies in
  * PyTorch-ROCm's native path). */
 int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
@@ -42,8 +40,6 @@ int gd_nn_groupnorm_silu_backward(void* stream, const void* x, const void* dy, c
                                   int apply_silu, double* stats_ws);
 
 size_t gd_nn_groupnorm_ws_bytes(int N, int G);
-/* tuning hook: 0 = fp64-atomic statistics everywhere (default 1: partial slots on small maps) */
-int gd_nn_groupnorm_partials(int on);
 
 /* y = conv3x3(x, w; stride 1, pad 1) [+ bias] [+ residual], NHWC bf16, as an MFMA implicit GEMM.
  * x: [N,H,W,Cin]; weight: [Cout][3][3][Cin] (PyTorch's channels_last weight storage); bias: [Cout]
