@@ -37,6 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import garmentdreamer_amd  # noqa: E402,F401  (first: sets a HIP runtime flag before the runtime starts, _runtime_env.py)
+
 import torch  # noqa: E402
 
 UNET_TFLOP_PER_SAMPLE = 0.80425746432     # FlopCounterMode on sd21.UNet2DConditionModel @64x64 latents

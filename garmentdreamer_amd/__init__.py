@@ -9,3 +9,7 @@ Layout (only what the path needs):
     sds_loop.py, dist.py           the iteration that drives the path, view-sharded over RCCL
 """
 __version__ = "0.1.0"
+
+from . import _runtime_env as _runtime_env  # noqa: E402
+
+_runtime_env.configure()   # before the first HIP call where possible (see the module docstring)

@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _runtime_env
 from . import sd21
 
 
@@ -114,6 +115,12 @@ class StableDiffusionGuidance(nn.Module):
         self.grad_clip_val: Optional[float] = None
         self._unet_graphs = {}
         self._vae_graphs = {}
+        if self.cfg.use_hip_graphs and not _runtime_env.graph_replay_safe():
+            import warnings
+            warnings.warn(f"{_runtime_env.FLAG}=0 was not in place before the HIP runtime started; hipGraph replay of "
+                          "the UNet / VAE is off for this process (eager launches). Import garmentdreamer_amd before "
+                          "the first torch.cuda call, or export the flag.")
+            self.cfg.use_hip_graphs = False
 
     def set_min_max_steps(self, min_step_percent=0.02, max_step_percent=0.98):
         self.min_step = int(self.num_train_timesteps * min_step_percent)
@@ -121,8 +128,10 @@ class StableDiffusionGuidance(nn.Module):
 
     def forward_unet(self, latents, t, encoder_hidden_states):
         input_dtype = latents.dtype
-        x, tt, ctx = latents.to(self.weights_dtype), t.to(self.weights_dtype), \
-            encoder_hidden_states.to(self.weights_dtype)
+        # the reference casts t to its fp16 weights dtype (:155), which holds every timestep < 2048 exactly; bf16
+        # would round t > 256 to a multiple of 2 or 4, so with bf16 weights the timestep stays fp32
+        t_dtype = torch.float32 if self.weights_dtype == torch.bfloat16 else self.weights_dtype
+        x, tt, ctx = latents.to(self.weights_dtype), t.to(t_dtype), encoder_hidden_states.to(self.weights_dtype)
         if self.cfg.use_hip_graphs and x.is_cuda and not torch.is_grad_enabled():
             try:
                 return self._graphed_unet(x, tt, ctx).to(input_dtype)
