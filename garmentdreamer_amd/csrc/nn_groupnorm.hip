@@ -7,6 +7,12 @@
 // accesses, thread <-> fixed channel vector so gamma/beta/mean/rstd live in registers, fp32 math,
 // fp64 global accumulation of the (few) per-workgroup partial sums.
 //
+// Statistics workspace (gd_nn_groupnorm_ws_bytes): [N*G*2 fp64 accumulators][1 u64 ticket].  It must be ZERO when
+// a call starts and is zero again when the call's kernels have run: the last statistics workgroup to finish
+// (ticket) turns the sums into fp32 results in a separate buffer (mean_rstd / group_sums) and clears what it
+// read with atomic exchanges -- no memset and no finalize launch per GroupNorm (105 GroupNorms per SDS step).
+// One zero-initialised workspace therefore serves any sequence of calls, of any shapes, on one stream.
+//
 // Layout: x[n][p][c], p = pixel (H*W), c fastest.  Workgroup = rows x vpp threads where
 // vpp = C/8 vectors per pixel and rows = max(1, 256 / vpp); blockIdx.x walks pixel chunks,
 // blockIdx.y = n.
@@ -37,9 +43,13 @@ constexpr int kMaxThreads = 320;  // C = 2560 -> 320 vectors per pixel
 
 // Sum over the workgroup of per-thread per-channel partials, folded to per-group totals and added
 // to ws[n][g][0..1] in fp64.  `a`, `b`: the thread's 8-channel partial sums of two quantities.
+// MODE 0: results = {mean, rstd} (forward statistics);  MODE 1: results = {s1 / M, s2 / M} (backward)
+template <int MODE>
 __device__ __forceinline__ void reduce_to_groups(const float (&a)[8], const float (&b)[8], int vpp, int rows, int tv,
-                                                 int tr, int C, int G, double* __restrict__ ws_n, float* lds)
+                                                 int tr, int C, int G, int N, int n, double M, float eps,
+                                                 double* __restrict__ ws, float* __restrict__ result, float* lds)
 {
+    double* ws_n = ws + (size_t)n * G * 2;
     // lds: [2][rows][C]
     float* la = lds;
     float* lb = lds + (size_t)rows * C;
@@ -67,13 +77,45 @@ __device__ __forceinline__ void reduce_to_groups(const float (&a)[8], const floa
             sa += la[c];
             sb += lb[c];
         }
-        atomicAdd(&ws_n[2 * g], (double)sa);
-        atomicAdd(&ws_n[2 * g + 1], (double)sb);
+        // returning atomics, results consumed: the wave waits until both were performed at the device-coherent
+        // point before it reaches the barrier below, which orders them before this workgroup's ticket.  (An
+        // agent-scope __threadfence() here costs an L2 write-back + invalidate per workgroup on this multi-XCD
+        // part: +9 ms per SDS step when tried.  Every cross-workgroup access below is itself an atomic.)
+        const double o1 = atomicAdd(&ws_n[2 * g], (double)sa);
+        const double o2 = atomicAdd(&ws_n[2 * g + 1], (double)sb);
+        asm volatile("" ::"v"(o1), "v"(o2));
     }
+    // last workgroup of the launch: sums -> results, and leave accumulators + ticket zero for the next call
+    __shared__ unsigned int s_last;
+    __syncthreads();
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws + (size_t)N * G * 2);
+    if (threadIdx.x == 0) {
+        const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+        s_last = atomicAdd(ticket, 1ULL) == total - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = threadIdx.x; i < N * G; i += blockDim.x) {
+        unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws + 2 * (size_t)i);
+        const double sa = __longlong_as_double((long long)atomicExch(acc, 0ULL));
+        const double sb = __longlong_as_double((long long)atomicExch(acc + 1, 0ULL));
+        if (MODE == 0) {
+            const double mean = sa / M;
+            double var = sb / M - mean * mean;
+            var = var < 0 ? 0 : var;
+            result[2 * i] = (float)mean;
+            result[2 * i + 1] = rsqrtf((float)var + eps);
+        } else {
+            const float invM = 1.f / (float)M;
+            result[2 * i] = (float)sa * invM;
+            result[2 * i + 1] = (float)sb * invM;
+        }
+    }
+    if (threadIdx.x == 0) atomicExch(ticket, 0ULL);
 }
 
 __global__ void gn_stats_kernel(const bf16x8* __restrict__ x, int HW, int C, int G, int vpp, int rows, int ppb,
-                                double* __restrict__ ws)
+                                float eps, double* __restrict__ ws, float* __restrict__ mean_rstd)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = blockIdx.y;
@@ -92,48 +134,28 @@ __global__ void gn_stats_kernel(const bf16x8* __restrict__ x, int HW, int C, int
             ss[k] += f * f;
         }
     }
-    reduce_to_groups(s, ss, vpp, rows, tv, tr, C, G, ws + (size_t)n * G * 2, lds);
-}
-
-// ws[n][g] = {sum, sum of squares} (fp64)  ->  mean_rstd[n][g] = {mean, rstd} (same arithmetic as gn_apply_kernel)
-__global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean_rstd, int NG, double M,
-                                   float eps)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NG) return;
-    const double mean = ws[2 * i] / M;
-    double var = ws[2 * i + 1] / M - mean * mean;
-    var = var < 0 ? 0 : var;
-    mean_rstd[2 * i] = (float)mean;
-    mean_rstd[2 * i + 1] = rsqrtf((float)var + eps);
+    reduce_to_groups<0>(s, ss, vpp, rows, tv, tr, C, G, gridDim.y, n, (double)HW * (C / G), eps, ws, mean_rstd, lds);
 }
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 
 __global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y,
                                 const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta, int HW, int C,
-                                int G, int vpp, int rows, int ppb, float eps, int apply_silu,
-                                const double* __restrict__ ws, float* __restrict__ mean_rstd)
+                                int G, int vpp, int rows, int ppb, int apply_silu,
+                                const float* __restrict__ mean_rstd)
 {
     const int n = blockIdx.y;
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
     const int cg = C / G;
-    const double M = (double)HW * cg;
     float a[8], b[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int c = tv * 8 + k, g = c / cg;
-        const double mean = ws[((size_t)n * G + g) * 2] / M;
-        double var = ws[((size_t)n * G + g) * 2 + 1] / M - mean * mean;
-        var = var < 0 ? 0 : var;
-        const float rstd = rsqrtf((float)var + eps);
+        const float mean = mean_rstd[((size_t)n * G + g) * 2];
+        const float rstd = mean_rstd[((size_t)n * G + g) * 2 + 1];
         a[k] = rstd * bf2f(gamma[c]);
-        b[k] = bf2f(beta[c]) - (float)mean * a[k];
-        if (blockIdx.x == 0 && tr == 0 && (c % cg) == 0) {
-            mean_rstd[((size_t)n * G + g) * 2] = (float)mean;
-            mean_rstd[((size_t)n * G + g) * 2 + 1] = rstd;
-        }
+        b[k] = bf2f(beta[c]) - mean * a[k];
     }
     const bf16x8* xn = x + (size_t)n * HW * vpp;
     bf16x8* yn = y + (size_t)n * HW * vpp;
@@ -154,7 +176,7 @@ __global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict
 __global__ void gn_bwd_stats_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy,
                                     const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                                     const float* __restrict__ mean_rstd, int HW, int C, int G, int vpp, int rows,
-                                    int ppb, int apply_silu, double* __restrict__ ws)
+                                    int ppb, int apply_silu, double* __restrict__ ws, float* __restrict__ m12)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = blockIdx.y;
@@ -190,19 +212,18 @@ __global__ void gn_bwd_stats_kernel(const bf16x8* __restrict__ x, const bf16x8* 
             s2[k] += t * xh;
         }
     }
-    reduce_to_groups(s1, s2, vpp, rows, tv, tr, C, G, ws + (size_t)n * G * 2, lds);
+    reduce_to_groups<1>(s1, s2, vpp, rows, tv, tr, C, G, gridDim.y, n, (double)HW * cg, 0.f, ws, m12, lds);
 }
 
 __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy,
                                     const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                                     const float* __restrict__ mean_rstd, bf16x8* __restrict__ dx, int HW, int C,
-                                    int G, int vpp, int rows, int ppb, int apply_silu, const double* __restrict__ ws)
+                                    int G, int vpp, int rows, int ppb, int apply_silu, const float* __restrict__ m12)
 {
     const int n = blockIdx.y;
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
     const int cg = C / G;
-    const float invM = 1.f / ((float)HW * cg);
     float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -211,8 +232,8 @@ __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* 
         rstd[k] = mean_rstd[((size_t)n * G + g) * 2 + 1];
         gm[k] = bf2f(gamma[c]);
         bt[k] = bf2f(beta[c]);
-        m1[k] = (float)ws[((size_t)n * G + g) * 2] * invM;
-        m2[k] = (float)ws[((size_t)n * G + g) * 2 + 1] * invM;
+        m1[k] = m12[((size_t)n * G + g) * 2];
+        m2[k] = m12[((size_t)n * G + g) * 2 + 1];
     }
     const bf16x8* xn = x + (size_t)n * HW * vpp;
     const bf16x8* dn = dy + (size_t)n * HW * vpp;
@@ -277,7 +298,10 @@ int fail(int code, const char* msg)
 
 extern "C" {
 
-size_t gd_nn_groupnorm_ws_bytes(int N, int G) { return (size_t)N * G * 2 * sizeof(double); }
+size_t gd_nn_groupnorm_ws_bytes(int N, int G)
+{
+    return (size_t)N * G * 2 * sizeof(double) + sizeof(unsigned long long);
+}
 
 int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
                                  int HW, int C, int G, float eps, int apply_silu, double* stats_ws, float* mean_rstd)
@@ -286,13 +310,11 @@ int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const voi
     if (!x || !y || !gamma || !beta || !stats_ws || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats_ws, 0, gd_nn_groupnorm_ws_bytes(N, G), s) != hipSuccess)
-        return fail(GD_NN_ERR_HIP, "hipMemsetAsync failed");
     dim3 grid(g.nchunks, N), block(g.threads), grid_s(g.nchunks_stats, N);
     hipLaunchKernelGGL(gn_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows,
-                       g.ppb_stats, stats_ws);
+                       g.ppb_stats, eps, stats_ws, mean_rstd);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (bf16x8*)y, (const uint16_t*)gamma,
-                       (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, eps, apply_silu, stats_ws, mean_rstd);
+                       (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, apply_silu, mean_rstd);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
@@ -305,13 +327,9 @@ int gd_nn_groupnorm_stats(void* stream, const void* x, int N, int HW, int C, int
     if (!x || !stats_ws || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats_ws, 0, gd_nn_groupnorm_ws_bytes(N, G), s) != hipSuccess)
-        return fail(GD_NN_ERR_HIP, "hipMemsetAsync failed");
     dim3 block(g.threads), grid_s(g.nchunks_stats, N);
     hipLaunchKernelGGL(gn_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows,
-                       g.ppb_stats, stats_ws);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * G + 255) / 256), dim3(256), 0, s, stats_ws, mean_rstd, N * G,
-                       (double)HW * (C / G), eps);
+                       g.ppb_stats, eps, stats_ws, mean_rstd);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
@@ -319,22 +337,21 @@ int gd_nn_groupnorm_stats(void* stream, const void* x, int N, int HW, int C, int
 
 int gd_nn_groupnorm_silu_backward(void* stream, const void* x, const void* dy, const void* gamma, const void* beta,
                                   const float* mean_rstd, void* dx, int N, int HW, int C, int G, int apply_silu,
-                                  double* stats_ws)
+                                  double* stats_ws, float* group_sums)
 {
     Geo g;
-    if (!x || !dy || !gamma || !beta || !stats_ws || !mean_rstd || !dx)
+    if (!x || !dy || !gamma || !beta || !stats_ws || !mean_rstd || !dx || !group_sums)
         return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats_ws, 0, gd_nn_groupnorm_ws_bytes(N, G), s) != hipSuccess)
-        return fail(GD_NN_ERR_HIP, "hipMemsetAsync failed");
+    float* m12 = group_sums;
     dim3 grid(g.nchunks, N), block(g.threads), grid_s(g.nchunks_stats, N);
     hipLaunchKernelGGL(gn_bwd_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, (const bf16x8*)dy,
                        (const uint16_t*)gamma, (const uint16_t*)beta, mean_rstd, HW, C, G, g.vpp, g.rows,
-                       g.ppb_stats, apply_silu, stats_ws);
+                       g.ppb_stats, apply_silu, stats_ws, m12);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (const bf16x8*)dy,
                        (const uint16_t*)gamma, (const uint16_t*)beta, mean_rstd, (bf16x8*)dx, HW, C, G, g.vpp, g.rows,
-                       g.ppb, apply_silu, stats_ws);
+                       g.ppb, apply_silu, m12);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

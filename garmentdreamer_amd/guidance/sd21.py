@@ -88,6 +88,18 @@ def _gn_conv3(norm: nn.GroupNorm, conv: nn.Conv2d, x, image_bias=None, residual=
 # ----------------------------------------------------------------------------------------------
 
 
+class TembProjections:
+    """``time_emb_proj(silu(temb)) + conv1.bias`` of every ResnetBlock2D of a frozen UNet from ONE GEMM over the
+    row-concatenated projection weights: the 22 blocks of SD-2.1 otherwise launch 22 x (silu, GEMM, add) on a
+    [B, 1280] tensor -- 64 launches of ~5 us that the 1-view-per-GPU step cannot hide.  ``image_bias[id(block)]``
+    is a [B, C_out] column slice (row stride = the total width); the conv kernels take the stride."""
+
+    __slots__ = ("temb", "image_bias")
+
+    def __init__(self, temb, image_bias):
+        self.temb, self.image_bias = temb, image_bias
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, in_ch: int, out_ch: int, temb_ch: Optional[int], eps: float = 1e-5, groups: int = 32):
         super().__init__()
@@ -100,7 +112,11 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb=None):
         image_bias = None
-        if self.time_emb_proj is not None:  # conv bias + time-embedding projection = one per-image bias
+        if isinstance(temb, TembProjections):   # projected for every block at once (UNet2DConditionModel.forward)
+            image_bias = temb.image_bias.get(id(self))
+            temb = temb.temb
+        if image_bias is None and self.time_emb_proj is not None:
+            # conv bias + time-embedding projection = one per-image bias
             image_bias = self.time_emb_proj(F.silu(temb)) + self.conv1.bias
         h = _gn_conv3(self.norm1, self.conv1, x, image_bias=image_bias)
         if self.conv_shortcut is not None:
@@ -374,6 +390,31 @@ class UNet2DConditionModel(nn.Module):
         """Hook for subclasses: an additive term for the time embedding (None here)."""
         return None
 
+    def _project_temb(self, temb):
+        """All blocks' per-image conv1 biases in one GEMM (``TembProjections``) when nothing on the way needs a
+        gradient; otherwise the time embedding itself (each block then projects it, with autograd)."""
+        if not temb.is_cuda or (torch.is_grad_enabled() and temb.requires_grad):
+            return temb
+        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+        if not blocks or any(b.time_emb_proj.weight.requires_grad or b.conv1.bias.requires_grad for b in blocks):
+            return temb
+        first = blocks[0].time_emb_proj.weight
+        key = (first.data_ptr(), first._version, blocks[0].conv1.bias._version, temb.dtype, len(blocks))
+        cache = getattr(self, "_temb_cat", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w = torch.cat([b.time_emb_proj.weight for b in blocks], dim=0).to(temb.dtype).contiguous()
+                bias = torch.cat([b.time_emb_proj.bias + b.conv1.bias for b in blocks], dim=0).to(temb.dtype)
+            cache = self._temb_cat = (key, w, bias)
+        with torch.no_grad():
+            allp = F.linear(F.silu(temb), cache[1], cache[2])
+        out, off = {}, 0
+        for b in blocks:
+            c = b.time_emb_proj.out_features
+            out[id(b)] = allp[:, off:off + c]
+            off += c
+        return TembProjections(temb, out)
+
     def forward(self, sample, timestep, encoder_hidden_states, **kwargs):
         dtype = self.conv_in.weight.dtype
         if timestep.dim() == 0:
@@ -382,6 +423,7 @@ class UNet2DConditionModel(nn.Module):
         extra = self.extra_embedding(sample.shape[0], **kwargs)
         if extra is not None:
             temb = temb + extra.to(dtype)
+        temb = self._project_temb(temb)
         x = conv3x3_small_cin(sample.to(dtype).contiguous(memory_format=torch.channels_last), self.conv_in.weight,
                               self.conv_in.bias)
         ctx = encoder_hidden_states.to(dtype)

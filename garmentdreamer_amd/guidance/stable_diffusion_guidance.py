@@ -147,6 +147,8 @@ class StableDiffusionGuidance(nn.Module):
         self._unet_graphs.clear()
         self._vae_graphs.clear()
         torch.cuda.synchronize()
+        from .. import nn_ops
+        nn_ops.reset_workspaces()      # an aborted capture may have left a statistics workspace mid-update
 
     # ---- hipGraph replay ----------------------------------------------------------------------
     def _graphed_unet(self, x, t, ctx):

@@ -18,7 +18,7 @@ _lib = None
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "gd_nn_groupnorm_silu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
-    "gd_nn_groupnorm_silu_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gd_nn_groupnorm_silu_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_ws_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
@@ -65,6 +65,28 @@ def _check(ret, what):
         raise RuntimeError(f"{what} failed ({ret}): {lib().gd_nn_last_error().decode()}")
 
 
+_gn_ws_cache = {}
+
+
+def _gn_workspace(x, N, groups):
+    """The zero-initialised GroupNorm statistics workspace of (device, current stream): every call leaves it zero
+    (include/gd_nn.h), so it is allocated once and never memset again.  Keyed by stream because two streams may
+    run GroupNorms concurrently; a workspace first needed during hipGraph capture is allocated (and kept alive
+    here) in that graph's pool."""
+    stream = torch.cuda.current_stream(x.device)
+    key = (x.device.index, stream.cuda_stream)
+    need = lib().gd_nn_groupnorm_ws_bytes(N, groups)
+    ws = _gn_ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _gn_ws_cache[key] = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=x.device)
+    return ws
+
+
+def reset_workspaces():
+    """Drop the cached workspaces (after an aborted hipGraph capture may have left one mid-update)."""
+    _gn_ws_cache.clear()
+
+
 def _is_nhwc_bf16(x):
     return x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
 
@@ -75,7 +97,7 @@ class _GroupNormSiLU(torch.autograd.Function):
         N, Cc, H, W = x.shape
         L = lib()
         y = torch.empty_like(x, memory_format=torch.channels_last)
-        ws = torch.empty(N * groups * 2, dtype=torch.float64, device=x.device)
+        ws = _gn_workspace(x, N, groups)
         mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
         w, b = weight.contiguous(), bias.contiguous()
         with torch.cuda.device(x.device):
@@ -96,12 +118,14 @@ class _GroupNormSiLU(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
-        ws = torch.empty(N * ctx.groups * 2, dtype=torch.float64, device=x.device)
+        ws = _gn_workspace(x, N, ctx.groups)
+        sums = torch.empty(N * ctx.groups * 2, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _check(L.gd_nn_groupnorm_silu_backward(stream, x.data_ptr(), dy.data_ptr(), w.data_ptr(), b.data_ptr(),
                                                    mr.data_ptr(), dx.data_ptr(), N, H * W, Cc, ctx.groups,
-                                                   int(ctx.silu), ws.data_ptr()), "gd_nn_groupnorm_silu_backward")
+                                                   int(ctx.silu), ws.data_ptr(), sums.data_ptr()),
+                   "gd_nn_groupnorm_silu_backward")
         return dx, None, None, None, None, None
 
 
@@ -123,15 +147,24 @@ def group_norm_silu(x, weight, bias, groups: int, eps: float, silu: bool = True)
 # 3x3 convolution (implicit GEMM on MFMA), fused bias / per-image bias / residual
 # ---------------------------------------------------------------------------------------------
 
+def _bias_and_stride(bias):
+    """[Cout] bias -> (bias, 0); per-image [N, Cout] bias -> (bias, elements between rows).  Column slices of a
+    wider matrix (sd21.TembProjections) are passed as they are -- the kernels take the row stride."""
+    if bias is None:
+        return None, 0
+    if bias.dim() == 1:
+        return bias.contiguous(), 0
+    if bias.stride(1) != 1 or bias.stride(0) % 8 or bias.storage_offset() % 8:
+        bias = bias.contiguous()
+    return bias, bias.stride(0)
+
+
 def _conv_launch(x, w_khwc, bias, residual, out_channels):
     N, Cin, H, W = x.shape
     L = lib()
     y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device,
                     memory_format=torch.channels_last)
-    stride = 0
-    if bias is not None:
-        bias = bias.contiguous()
-        stride = out_channels if bias.dim() == 2 else 0
+    bias, stride = _bias_and_stride(bias)
     # small-M layers run split over the taps and need fp32 scratch (torch's allocator: hipGraph-capture safe)
     ws_bytes = L.gd_nn_conv3x3_ws_bytes(N, H, W, Cin, out_channels)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
@@ -151,10 +184,7 @@ def _patch_launch(x, w_khwc, bias, residual, out_channels):
     N, Cin, H, W = x.shape
     L = lib()
     y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    stride = 0
-    if bias is not None:
-        bias = bias.contiguous()
-        stride = out_channels if bias.dim() == 2 else 0
+    bias, stride = _bias_and_stride(bias)
     with torch.cuda.device(x.device):
         ret = L.gd_nn_conv3x3_gn_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), None, None, None,
                                          0, 0, w_khwc.data_ptr(), None if bias is None else bias.data_ptr(), stride,
@@ -317,14 +347,11 @@ class _GNConv3x3(torch.autograd.Function):
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
         L = lib()
-        ws = torch.empty(N * groups * 2, dtype=torch.float64, device=x.device)
+        ws = _gn_workspace(x, N, groups)
         mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
         y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
         gw, gb = gn_weight.contiguous(), gn_bias.contiguous()
-        stride = 0
-        if bias is not None:
-            bias = bias.contiguous()
-            stride = Cout if bias.dim() == 2 else 0
+        bias, stride = _bias_and_stride(bias)
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _check(L.gd_nn_groupnorm_stats(stream, x.data_ptr(), N, H * W, Cin, groups, float(eps), ws.data_ptr(),
@@ -351,13 +378,14 @@ class _GNConv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dact = _conv_launch(dy, _flipped(w), None, None, Cin)          # gradient w.r.t. act(GN(x))
             dx = torch.empty_like(x, memory_format=torch.channels_last)
-            ws = torch.empty(N * ctx.groups * 2, dtype=torch.float64, device=x.device)
+            ws = _gn_workspace(x, N, ctx.groups)
+            sums = torch.empty(N * ctx.groups * 2, dtype=torch.float32, device=x.device)
             L = lib()
             with torch.cuda.device(x.device):
                 stream = torch.cuda.current_stream(x.device).cuda_stream
                 _check(L.gd_nn_groupnorm_silu_backward(stream, x.data_ptr(), dact.data_ptr(), gw.data_ptr(),
                                                        gb.data_ptr(), mr.data_ptr(), dx.data_ptr(), N, H * W, Cin,
-                                                       ctx.groups, int(ctx.silu), ws.data_ptr()),
+                                                       ctx.groups, int(ctx.silu), ws.data_ptr(), sums.data_ptr()),
                        "gd_nn_groupnorm_silu_backward")
         return dx, None, None, None, None, None, None, None, (dy if ctx.has_res else None)
 

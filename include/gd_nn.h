@@ -25,8 +25,9 @@ extern "C" {
 
 /* y = act(GroupNorm_G(x) * gamma + beta), act = SiLU if apply_silu else identity.
  * x, y: bf16 [N, HW, C] (NHWC); gamma, beta: bf16 [C]; C % 8 == 0, C % G == 0.
- * stats_ws: N*G*2 doubles of scratch (zeroed by the call); mean_rstd: N*G*2 floats out
- * (saved for backward).  Replaces F.group_norm + F.silu (two kernels + two NCHW<->NHWC copies in
+ * stats_ws: gd_nn_groupnorm_ws_bytes(N, G) bytes that are ZERO on entry (zero-initialise once; every call
+ * leaves them zero again, so one workspace serves all calls on a stream -- the last statistics workgroup
+ * finalises and clears, there is no memset / finalize launch); mean_rstd: N*G*2 floats out (saved for backward).  Replaces F.group_norm + F.silu (two kernels + two NCHW<->NHWC copies in
  * PyTorch-ROCm's native path). */
 int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
                                  int HW, int C, int G, float eps, int apply_silu, double* stats_ws,
@@ -37,7 +38,7 @@ int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const voi
  * stable_diffusion_guidance.py:99-102).  dy: gradient w.r.t. y. */
 int gd_nn_groupnorm_silu_backward(void* stream, const void* x, const void* dy, const void* gamma,
                                   const void* beta, const float* mean_rstd, void* dx, int N, int HW, int C, int G,
-                                  int apply_silu, double* stats_ws);
+                                  int apply_silu, double* stats_ws, float* group_sums /* N*G*2 floats scratch */);
 
 size_t gd_nn_groupnorm_ws_bytes(int N, int G);
 

@@ -34,6 +34,63 @@ def test_groupnorm_silu_matches_fp32_reference(N, C, H, W, silu):
     assert cos > 0.9995, cos
 
 
+def test_groupnorm_workspace_is_shared_and_left_zero():
+    """The statistics workspace is zero-initialised once per (device, stream) and every call must leave it zero
+    (last-workgroup finalize + clear, include/gd_nn.h): interleave shapes, forward and backward, on one workspace,
+    check each result against fp32 torch and the workspace bytes afterwards."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(5)
+    shapes = [(8, 128, 64, 64), (1, 320, 16, 16), (16, 1280, 8, 8), (2, 512, 128, 128), (3, 640, 7, 9), (8, 128, 64, 64)]
+    for rep in range(2):
+        for (N, C, H, W) in shapes:
+            x = (torch.randn(N, C, H, W, device=DEV, generator=g) * 1.3 - 0.2).to(torch.bfloat16) \
+                .contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            w = (torch.randn(C, device=DEV, generator=g) * 0.5 + 1.0).to(torch.bfloat16)
+            b = (torch.randn(C, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
+            y = nn_ops.group_norm_silu(x, w, b, 32, 1e-6, True)
+            gy = torch.randn(N, C, H, W, device=DEV, generator=g).to(torch.bfloat16)
+            y.backward(gy)
+            xr = x.detach().float().requires_grad_(True)
+            yr = F.silu(F.group_norm(xr, 32, w.float(), b.float(), 1e-6))
+            yr.backward(gy.float())
+            assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item() + 1e-2
+            assert F.cosine_similarity(x.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.9995
+    torch.cuda.synchronize()
+    assert len(nn_ops._gn_ws_cache) >= 1
+    for ws in nn_ops._gn_ws_cache.values():
+        assert int(ws.count_nonzero()) == 0
+
+
+def test_batched_time_embedding_projection_equals_per_block_projection():
+    """UNet2DConditionModel._project_temb: one GEMM over the concatenated time_emb_proj weights (strided per-image
+    bias handed to the conv kernels) vs every ResnetBlock2D projecting for itself -- same network output up to the
+    bf16 rounding of the two GEMM shapes; and the per-block path is what runs when the embedding needs a gradient."""
+    from garmentdreamer_amd.guidance import sd21
+    with torch.device(DEV):
+        unet = sd21.init_random_(sd21.UNet2DConditionModel(block_out_channels=(64, 128, 256, 256),
+                                                           attention_head_dim=(1, 2, 4, 4)))
+    unet = unet.to(torch.bfloat16).to(memory_format=torch.channels_last).eval()
+    for p_ in unet.parameters():
+        p_.requires_grad_(False)
+    g = torch.Generator(DEV).manual_seed(3)
+    x = torch.randn(3, 4, 32, 32, device=DEV, generator=g).to(torch.bfloat16)
+    ctx = torch.randn(3, 77, 1024, device=DEV, generator=g).to(torch.bfloat16)
+    t = torch.tensor([17.0, 480.0, 977.0], device=DEV)
+    with torch.no_grad():
+        y_batched = unet(x, t, encoder_hidden_states=ctx)
+        packed = unet._project_temb(torch.randn(3, 256, device=DEV).to(torch.bfloat16))
+        assert isinstance(packed, sd21.TembProjections) and len(packed.image_bias) == 22
+        orig = unet._project_temb
+        unet._project_temb = lambda temb: temb
+        y_blocks = unet(x, t, encoder_hidden_states=ctx)
+        unet._project_temb = orig
+    scale = y_blocks.float().abs().max().item()
+    assert (y_batched.float() - y_blocks.float()).abs().max().item() <= 3e-2 * scale
+    assert F.cosine_similarity(y_batched.float().flatten(), y_blocks.float().flatten(), dim=0).item() > 0.9995
+    temb = torch.randn(3, 256, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    assert unet._project_temb(temb) is temb      # gradient wanted (LoRA / camera embedding training): per block
+
+
 def test_unet_and_vae_bf16_hip_path_tracks_fp32_torch_path():
     """Whole small UNet / VAE: bf16 + HIP GroupNorm kernels vs the same weights in fp32 torch ops."""
     from garmentdreamer_amd.guidance import sd21
