@@ -100,6 +100,21 @@ class TembProjections:
         self.temb, self.image_bias = temb, image_bias
 
 
+class ContextProjections:
+    """``to_k(context)`` / ``to_v(context)`` of every cross-attention of a frozen UNet from ONE GEMM: the text
+    embeddings do not depend on the sample, so the 16 layers' 32 projections of the [B, 77, 1024] context are one
+    [B*77, 1024] x [1024, 24960] product whose column slices feed the attentions as strided views."""
+
+    __slots__ = ("context", "kv")
+
+    def __init__(self, context, kv):
+        self.context, self.kv = context, kv
+
+    @property
+    def shape(self):
+        return self.context.shape
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, in_ch: int, out_ch: int, temb_ch: Optional[int], eps: float = 1e-5, groups: int = 32):
         super().__init__()
@@ -165,8 +180,14 @@ class Attention(nn.Module):
 
     def forward(self, x, context=None):
         B, N, _ = x.shape
+        kv = None
+        if isinstance(context, ContextProjections):
+            kv = context.kv.get(id(self)) if self.lora is None else None
+            context = context.context
         ctx = x if context is None else context
-        if _FUSED_QKV and context is None and self.lora is None and x.is_cuda and self.to_q.bias is None and \
+        if kv is not None:
+            q, (k, v) = self.to_q(x), kv
+        elif _FUSED_QKV and context is None and self.lora is None and x.is_cuda and self.to_q.bias is None and \
                 not self.to_q.weight.requires_grad and not torch.is_grad_enabled():
             # frozen self-attention: ONE [C, 3C] projection; the attention kernel reads the three strided views
             src = (self.to_q.weight.data_ptr(), self.to_q.weight._version, x.dtype)
@@ -224,12 +245,16 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def forward(self, x, context):
+    def forward(self, x, context, defer_ff_bias: bool = False):
         # x = x + attn1(norm1(x)); x = x + attn2(norm2(x), ctx); x = x + ff(norm3(x)) with each residual add fused
         # into the LayerNorm that follows it (nn_ops.add_layer_norm; plain torch ops when gradients are needed)
         _, n = add_layer_norm(x, None, self.norm1)
         x, n = add_layer_norm(x, self.attn1(n), self.norm2)
         x, n = add_layer_norm(x, self.attn2(n, context), self.norm3)
+        if defer_ff_bias:
+            # last residual inside the GEMM (beta = 1): x + gelu-gated(n) @ W2^T; the caller owes the constant b2
+            g = self.ff.net[0](n)
+            return torch.addmm(x.reshape(-1, x.shape[-1]), g.reshape(-1, g.shape[-1]), self.ff.net[2].weight.t()).view_as(x)
         return x + self.ff(n)
 
 
@@ -241,14 +266,30 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(channels, heads, dim_head, cross_dim)])
         self.proj_out = nn.Linear(channels, channels)
 
+    def _folded_out_bias(self, dtype):
+        w, b2 = self.proj_out.weight, self.transformer_blocks[0].ff.net[2].bias
+        key = (w.data_ptr(), w._version, b2._version, self.proj_out.bias._version, dtype)
+        if getattr(self, "_fold_key", None) != key:
+            with torch.no_grad():
+                self._fold_bias = (self.proj_out.bias.float() + w.float() @ b2.float()).to(dtype)
+            self._fold_key = key
+        return self._fold_bias
+
     def forward(self, x, context):
         B, C, H, W = x.shape
         h = _gn(self.norm, x, False)
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)  # free for channels_last activations
         h = self.proj_in(h)
-        for blk in self.transformer_blocks:
-            h = blk(h, context)
-        h = self.proj_out(h)
+        if len(self.transformer_blocks) == 1 and h.is_cuda and not torch.is_grad_enabled() and \
+                not self.proj_out.weight.requires_grad:
+            # frozen inference: the block's feed-forward output bias b2 is a constant added right before proj_out,
+            # so it moves into proj_out's bias (W_out b2 + b_out) and the residual add moves into the GEMM
+            h = self.transformer_blocks[0](h, context, defer_ff_bias=True)
+            h = F.linear(h, self.proj_out.weight, self._folded_out_bias(h.dtype))
+        else:
+            for blk in self.transformer_blocks:
+                h = blk(h, context)
+            h = self.proj_out(h)
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
         return h + x
 
@@ -390,6 +431,30 @@ class UNet2DConditionModel(nn.Module):
         """Hook for subclasses: an additive term for the time embedding (None here)."""
         return None
 
+    def _project_context(self, ctx):
+        """Every cross-attention's K and V of the text embeddings in one GEMM (``ContextProjections``) for a frozen
+        UNet without gradients; otherwise the embeddings themselves."""
+        if not ctx.is_cuda or torch.is_grad_enabled():
+            return ctx
+        atts = [m.attn2 for m in self.modules() if isinstance(m, BasicTransformerBlock)]
+        if not atts or any(a.to_k.weight.requires_grad or a.to_k.bias is not None or a.lora is not None for a in atts):
+            return ctx
+        first = atts[0].to_k.weight
+        key = (first.data_ptr(), first._version, ctx.dtype, len(atts))
+        cache = getattr(self, "_ctx_cat", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w = torch.cat([t for a in atts for t in (a.to_k.weight, a.to_v.weight)], dim=0).to(ctx.dtype).contiguous()
+            cache = self._ctx_cat = (key, w)
+        with torch.no_grad():
+            allp = F.linear(ctx, cache[1])
+        kv, off = {}, 0
+        for a in atts:
+            c = a.to_k.out_features
+            kv[id(a)] = (allp[..., off:off + c], allp[..., off + c:off + 2 * c])
+            off += 2 * c
+        return ContextProjections(ctx, kv)
+
     def _project_temb(self, temb):
         """All blocks' per-image conv1 biases in one GEMM (``TembProjections``) when nothing on the way needs a
         gradient; otherwise the time embedding itself (each block then projects it, with autograd)."""
@@ -426,7 +491,7 @@ class UNet2DConditionModel(nn.Module):
         temb = self._project_temb(temb)
         x = conv3x3_small_cin(sample.to(dtype).contiguous(memory_format=torch.channels_last), self.conv_in.weight,
                               self.conv_in.bias)
-        ctx = encoder_hidden_states.to(dtype)
+        ctx = self._project_context(encoder_hidden_states.to(dtype))
         skips = [x]
         for blk in self.down_blocks:
             x = blk(x, temb, ctx, skips)

@@ -87,6 +87,19 @@ def test_batched_time_embedding_projection_equals_per_block_projection():
     scale = y_blocks.float().abs().max().item()
     assert (y_batched.float() - y_blocks.float()).abs().max().item() <= 3e-2 * scale
     assert F.cosine_similarity(y_batched.float().flatten(), y_blocks.float().flatten(), dim=0).item() > 0.9995
+    # the other launch-count reductions of the frozen no-grad path (cross-attention K/V of the text embeddings from
+    # one GEMM, feed-forward residual inside the GEMM with its bias folded into proj_out, fused QKV, own attention)
+    # against the plain per-layer path, which is what runs with autograd on
+    with torch.no_grad():
+        ctxp = unet._project_context(ctx)
+    assert isinstance(ctxp, sd21.ContextProjections) and len(ctxp.kv) == 16
+    assert unet._project_context(ctx) is ctx          # autograd on: every layer projects for itself
+    with torch.enable_grad():
+        unet._project_temb = lambda temb: temb
+        y_plain = unet(x, t, encoder_hidden_states=ctx).detach()
+        unet._project_temb = orig
+    assert (y_batched.float() - y_plain.float()).abs().max().item() <= 4e-2 * scale
+    assert F.cosine_similarity(y_batched.float().flatten(), y_plain.float().flatten(), dim=0).item() > 0.999
     temb = torch.randn(3, 256, device=DEV).to(torch.bfloat16).requires_grad_(True)
     assert unet._project_temb(temb) is temb      # gradient wanted (LoRA / camera embedding training): per block
 
