@@ -218,7 +218,8 @@ __global__ void gn_bwd_stats_kernel(const bf16x8* __restrict__ x, const bf16x8* 
 __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy,
                                     const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                                     const float* __restrict__ mean_rstd, bf16x8* __restrict__ dx, int HW, int C,
-                                    int G, int vpp, int rows, int ppb, int apply_silu, const float* __restrict__ m12)
+                                    int G, int vpp, int rows, int ppb, int apply_silu, const float* __restrict__ m12,
+                                    const bf16x8* __restrict__ add)
 {
     const int n = blockIdx.y;
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
@@ -238,9 +239,12 @@ __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* 
     const bf16x8* xn = x + (size_t)n * HW * vpp;
     const bf16x8* dn = dy + (size_t)n * HW * vpp;
     bf16x8* on = dx + (size_t)n * HW * vpp;
+    const bf16x8* an = add ? add + (size_t)n * HW * vpp : nullptr;
     for (int p = p0 + tr; p < p1; p += rows) {
         const bf16x8 v = xn[(size_t)p * vpp + tv];
         const bf16x8 d = dn[(size_t)p * vpp + tv];
+        bf16x8 a;
+        if (an) a = an[(size_t)p * vpp + tv];
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -251,7 +255,9 @@ __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* 
                 const float sg = 1.f / (1.f + __expf(-z));
                 dz *= sg * (1.f + z * (1.f - sg));
             }
-            o.v[k] = f2bf(rstd[k] * (dz * gm[k] - m1[k] - xh * m2[k]));
+            float r = rstd[k] * (dz * gm[k] - m1[k] - xh * m2[k]);
+            if (an) r += bf2f(a.v[k]);   // the other gradient arriving at this tensor (a ResnetBlock's skip path)
+            o.v[k] = f2bf(r);
         }
         on[(size_t)p * vpp + tv] = o;
     }
@@ -337,7 +343,7 @@ int gd_nn_groupnorm_stats(void* stream, const void* x, int N, int HW, int C, int
 
 int gd_nn_groupnorm_silu_backward(void* stream, const void* x, const void* dy, const void* gamma, const void* beta,
                                   const float* mean_rstd, void* dx, int N, int HW, int C, int G, int apply_silu,
-                                  double* stats_ws, float* group_sums)
+                                  double* stats_ws, float* group_sums, const void* add)
 {
     Geo g;
     if (!x || !dy || !gamma || !beta || !stats_ws || !mean_rstd || !dx || !group_sums)
@@ -351,7 +357,7 @@ int gd_nn_groupnorm_silu_backward(void* stream, const void* x, const void* dy, c
                        g.ppb_stats, apply_silu, stats_ws, m12);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (const bf16x8*)dy,
                        (const uint16_t*)gamma, (const uint16_t*)beta, mean_rstd, (bf16x8*)dx, HW, C, G, g.vpp, g.rows,
-                       g.ppb, apply_silu, m12);
+                       g.ppb, apply_silu, m12, (const bf16x8*)add);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

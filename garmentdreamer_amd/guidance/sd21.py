@@ -35,7 +35,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, conv1x1, conv3x3, conv3x3_s2, conv3x3_s2_supported, conv3x3_small_cin,
-                      conv3x3_supported, geglu, gn_conv3x3, gn_conv3x3_supported, group_norm_silu)
+                      conv3x3_supported, geglu, gn_conv3x3, gn_conv3x3_supported, gn_conv_prefers_fused, group_norm_silu,
+                      resnet_block_frozen, resnet_block_frozen_supported)
 
 
 import os as _os
@@ -70,13 +71,9 @@ def _gn_conv3(norm: nn.GroupNorm, conv: nn.Conv2d, x, image_bias=None, residual=
     as ONE patch-staged kernel that normalises in its activation loader (nn_ops.gn_conv3x3: 1.05-1.26x faster
     than GroupNorm kernel + convolution on MI355X, tools/gn_conv_bench.py); on 64^2 and smaller maps the
     GroupNorm kernel + plain convolution (LDS-DMA patch kernel or implicit GEMM, chosen by the library) is faster."""
-    # workgroups of the patch kernel: one per (image, 16x16 patch, 128/256-channel slab); below ~1.5 waves of
-    # the 256 CUs (small maps or one view per GPU) the implicit-GEMM kernel's finer tiles fill the chip better
-    bn = 256 if conv.out_channels % 256 == 0 else 128
-    wgs = x.shape[0] * -(-x.shape[2] // 16) * -(-x.shape[3] // 16) * -(-conv.out_channels // bn)
     frozen = not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
     frozen = frozen and (image_bias is None or not image_bias.requires_grad)
-    if x.is_cuda and frozen and x.shape[2] * x.shape[3] >= 128 * 128 and wgs >= 384 and \
+    if x.is_cuda and frozen and gn_conv_prefers_fused(x, conv.out_channels) and \
             gn_conv3x3_supported(x, norm.weight, conv.weight):
         return gn_conv3x3(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True, conv.weight,
                           conv.bias if image_bias is None else image_bias, residual)
@@ -126,6 +123,8 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
     def forward(self, x, temb=None):
+        if resnet_block_frozen_supported(x, self):   # VAE encoder inside the SDS graph: one autograd node per block
+            return resnet_block_frozen(x, self)
         image_bias = None
         if isinstance(temb, TembProjections):   # projected for every block at once (UNet2DConditionModel.forward)
             image_bias = temb.image_bias.get(id(self))

@@ -18,7 +18,7 @@ _lib = None
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "gd_nn_groupnorm_silu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
-    "gd_nn_groupnorm_silu_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "gd_nn_groupnorm_silu_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_ws_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
@@ -124,7 +124,7 @@ class _GroupNormSiLU(torch.autograd.Function):
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _check(L.gd_nn_groupnorm_silu_backward(stream, x.data_ptr(), dy.data_ptr(), w.data_ptr(), b.data_ptr(),
                                                    mr.data_ptr(), dx.data_ptr(), N, H * W, Cc, ctx.groups,
-                                                   int(ctx.silu), ws.data_ptr(), sums.data_ptr()),
+                                                   int(ctx.silu), ws.data_ptr(), sums.data_ptr(), None),
                    "gd_nn_groupnorm_silu_backward")
         return dx, None, None, None, None, None
 
@@ -385,7 +385,8 @@ class _GNConv3x3(torch.autograd.Function):
                 stream = torch.cuda.current_stream(x.device).cuda_stream
                 _check(L.gd_nn_groupnorm_silu_backward(stream, x.data_ptr(), dact.data_ptr(), gw.data_ptr(),
                                                        gb.data_ptr(), mr.data_ptr(), dx.data_ptr(), N, H * W, Cin,
-                                                       ctx.groups, int(ctx.silu), ws.data_ptr(), sums.data_ptr()),
+                                                       ctx.groups, int(ctx.silu), ws.data_ptr(), sums.data_ptr(),
+                                                       None),
                        "gd_nn_groupnorm_silu_backward")
         return dx, None, None, None, None, None, None, None, (dy if ctx.has_res else None)
 
@@ -407,6 +408,116 @@ def gn_conv3x3(x, norm_weight, norm_bias, groups: int, eps: float, silu: bool, w
     if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
         residual = residual.contiguous(memory_format=torch.channels_last)
     return _GNConv3x3.apply(x, norm_weight, norm_bias, groups, eps, silu, w, bias, residual)
+
+
+def gn_conv_prefers_fused(x, out_channels: int) -> bool:
+    """Large feature maps (the VAE encoder's 512^2 .. 128^2 levels) run GroupNorm + SiLU inside the patch-staged
+    convolution's activation loader (1.05-1.26x faster than GroupNorm kernel + convolution on MI355X,
+    tools/gn_conv_bench.py); on 64^2 and smaller maps, or below ~1.5 waves of workgroups (one per image, 16x16
+    patch, 128/256-channel slab), the GroupNorm kernel + plain convolution is faster."""
+    bn = 256 if out_channels % 256 == 0 else 128
+    wgs = x.shape[0] * -(-x.shape[2] // 16) * -(-x.shape[3] // 16) * -(-out_channels // bn)
+    return x.shape[2] * x.shape[3] >= 128 * 128 and wgs >= 384
+
+
+def _gn_bwd_launch(x, dy, gw, gb, mr, groups, silu, add=None):
+    N, Cc, H, W = x.shape
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    ws = _gn_workspace(x, N, groups)
+    sums = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().gd_nn_groupnorm_silu_backward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
+                                                   dy.data_ptr(), gw.data_ptr(), gb.data_ptr(), mr.data_ptr(),
+                                                   dx.data_ptr(), N, H * W, Cc, groups, int(silu), ws.data_ptr(),
+                                                   sums.data_ptr(), None if add is None else add.data_ptr()),
+               "gd_nn_groupnorm_silu_backward")
+    return dx
+
+
+def _gnconv_forward(x, gw, gb, groups, eps, w, bias, residual):
+    """``conv3x3(silu(group_norm(x))) + bias (+ residual)`` without autograd; returns (y, mean_rstd)."""
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    L = lib()
+    ws = _gn_workspace(x, N, groups)
+    mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        if gn_conv_prefers_fused(x, Cout):
+            y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+            bias_c, stride = _bias_and_stride(bias)
+            _check(L.gd_nn_groupnorm_stats(stream, x.data_ptr(), N, H * W, Cin, groups, float(eps), ws.data_ptr(),
+                                           mr.data_ptr()), "gd_nn_groupnorm_stats")
+            ret = L.gd_nn_conv3x3_gn_forward(stream, x.data_ptr(), mr.data_ptr(), gw.data_ptr(), gb.data_ptr(), groups,
+                                             1, w.data_ptr(), None if bias_c is None else bias_c.data_ptr(), stride,
+                                             None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W,
+                                             Cin, Cout)
+            if ret < 0:
+                raise RuntimeError(f"gd_nn_conv3x3_gn_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+            return y, mr
+        act = torch.empty_like(x, memory_format=torch.channels_last)
+        _check(L.gd_nn_groupnorm_silu_forward(stream, x.data_ptr(), act.data_ptr(), gw.data_ptr(), gb.data_ptr(), N,
+                                              H * W, Cin, groups, float(eps), 1, ws.data_ptr(), mr.data_ptr()),
+               "gd_nn_groupnorm_silu_forward")
+    return _conv_launch(act, w, bias, residual, Cout), mr
+
+
+class _ResnetBlockFrozen(torch.autograd.Function):
+    """diffusers ``ResnetBlock2D`` without time embedding (the VAE encoder's) as ONE autograd node:
+    ``conv2(silu(norm2(conv1(silu(norm1(x)))))) + shortcut(x)``.  As separate nodes, x receives two gradients (main
+    path and skip path) that autograd sums with an extra elementwise pass over the largest tensors of the step
+    (1.2 ms per SDS step at 8 views); here the skip gradient goes into the GroupNorm backward of norm1
+    (``add`` of gd_nn_groupnorm_silu_backward).  Saves x and conv1's output, as the separate nodes did."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, scw, scb, groups, eps):
+        h, mr1 = _gnconv_forward(x, n1w, n1b, groups, eps, c1w, c1b, None)
+        skip = x
+        if scw is not None:
+            skip = F.linear(x.permute(0, 2, 3, 1), scw.flatten(1), scb).permute(0, 3, 1, 2)
+        y, mr2 = _gnconv_forward(h, n2w, n2b, groups, eps, c2w, c2b, skip)
+        ctx.save_for_backward(x, h, mr1, mr2, n1w, n1b, n2w, n2b)
+        ctx.c1w, ctx.c2w, ctx.scw, ctx.groups = c1w, c2w, scw, groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, mr1, mr2, n1w, n1b, n2w, n2b = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dact2 = _conv_launch(dy, _flipped(ctx.c2w), None, None, ctx.c2w.shape[1])
+        dh = _gn_bwd_launch(h, dact2, n2w, n2b, mr2, ctx.groups, True)
+        dact1 = _conv_launch(dh, _flipped(ctx.c1w), None, None, ctx.c1w.shape[1])
+        g_skip = dy
+        if ctx.scw is not None:   # 1x1 shortcut: its input gradient is a plain GEMM on the NHWC view
+            g_skip = torch.matmul(dy.permute(0, 2, 3, 1), ctx.scw.flatten(1)).permute(0, 3, 1, 2)
+        dx = _gn_bwd_launch(x, dact1, n1w, n1b, mr1, ctx.groups, True, add=g_skip)
+        return (dx,) + (None,) * 12
+
+
+def resnet_block_frozen_supported(x, block) -> bool:
+    """``block``: an sd21.ResnetBlock2D without time embedding, all parameters frozen, bf16 on the GPU, and x needs
+    a gradient (without autograd the per-layer path has nothing to accumulate)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and torch.is_grad_enabled() and x.requires_grad):
+        return False
+    if block.time_emb_proj is not None or any(p.requires_grad for p in block.parameters()):
+        return False
+    c1, c2 = block.conv1.weight, block.conv2.weight
+    return (conv3x3_supported(x, c1) and c1.shape[0] % 64 == 0 and c2.shape[0] % 64 == 0 and c2.shape[1] % 64 == 0
+            and c2.is_contiguous(memory_format=torch.channels_last) and c1.shape[1] % block.norm1.num_groups == 0
+            and c1.shape[1] % 8 == 0 and block.norm1.num_groups == block.norm2.num_groups
+            and block.norm1.eps == block.norm2.eps)
+
+
+def resnet_block_frozen(x, block):
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    sc = block.conv_shortcut
+    return _ResnetBlockFrozen.apply(x, block.norm1.weight, block.norm1.bias, block.conv1.weight, block.conv1.bias,
+                                    block.norm2.weight, block.norm2.bias, block.conv2.weight, block.conv2.bias,
+                                    None if sc is None else sc.weight, None if sc is None else sc.bias,
+                                    block.norm1.num_groups, block.norm1.eps)
 
 
 class _Conv3x3S2(torch.autograd.Function):

@@ -35,10 +35,13 @@ int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const voi
 
 /* dx for the same op (weights frozen: no dgamma / dbeta, as in the guidance where
  * requires_grad_(False) is set on every VAE/UNet parameter,
- * stable_diffusion_guidance.py:99-102).  dy: gradient w.r.t. y. */
+ * stable_diffusion_guidance.py:99-102).  dy: gradient w.r.t. y.  add (optional, bf16, shape of dx): a second
+ * gradient arriving at x -- a ResnetBlock's skip path -- summed in fp32 before the one bf16 rounding, which saves the
+ * separate accumulation pass autograd would run (3 tensor passes -> 1 extra read). */
 int gd_nn_groupnorm_silu_backward(void* stream, const void* x, const void* dy, const void* gamma,
                                   const void* beta, const float* mean_rstd, void* dx, int N, int HW, int C, int G,
-                                  int apply_silu, double* stats_ws, float* group_sums /* N*G*2 floats scratch */);
+                                  int apply_silu, double* stats_ws, float* group_sums /* N*G*2 floats scratch */,
+                                  const void* add);
 
 size_t gd_nn_groupnorm_ws_bytes(int N, int G);
 

@@ -104,6 +104,43 @@ def test_batched_time_embedding_projection_equals_per_block_projection():
     assert unet._project_temb(temb) is temb      # gradient wanted (LoRA / camera embedding training): per block
 
 
+@pytest.mark.parametrize("N,cin,cout,H,W", [(8, 128, 128, 128, 128), (2, 128, 256, 32, 32), (1, 256, 256, 24, 40)])
+def test_vae_resnet_block_as_one_autograd_node_matches_fp32_reference(N, cin, cout, H, W):
+    """nn_ops._ResnetBlockFrozen (VAE ResnetBlock2D, skip gradient summed inside the GroupNorm backward) against
+    the same block in fp32 torch ops: output and input gradient; both the fused GN-conv maps and the small ones,
+    with and without the 1x1 shortcut."""
+    from garmentdreamer_amd import nn_ops
+    from garmentdreamer_amd.guidance import sd21
+    torch.manual_seed(cin + cout + H)
+    with torch.device(DEV):
+        blk32 = sd21.ResnetBlock2D(cin, cout, None, eps=1e-6)
+        for p_ in blk32.parameters():
+            p_.data.normal_(0.0, 0.05)
+        blk32.norm1.weight.data.add_(1.0)
+        blk32.norm2.weight.data.add_(1.0)
+    blk = sd21.ResnetBlock2D(cin, cout, None, eps=1e-6).to(DEV)
+    blk.load_state_dict(blk32.state_dict())
+    blk = blk.to(torch.bfloat16).to(memory_format=torch.channels_last)
+    for p_ in list(blk.parameters()) + list(blk32.parameters()):
+        p_.requires_grad_(False)
+    blk32.load_state_dict({k: v.float() for k, v in blk.state_dict().items()})     # identical (bf16-rounded) weights
+    g = torch.Generator(DEV).manual_seed(1)
+    x = torch.randn(N, cin, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, cout, H, W, device=DEV, generator=g).to(torch.bfloat16)
+    xb = x.clone().requires_grad_(True)
+    assert nn_ops.resnet_block_frozen_supported(xb, blk)
+    y = blk(xb)
+    assert y.grad_fn is not None and "ResnetBlockFrozen" in type(y.grad_fn).__name__
+    y.backward(gy)
+    xr = x.float().requires_grad_(True)
+    yr = blk32(xr)
+    yr.backward(gy.float())
+    assert (y.float() - yr).abs().max().item() <= 3e-2 * yr.abs().max().item() + 1e-2
+    assert F.cosine_similarity(y.float().flatten(), yr.flatten(), dim=0).item() > 0.9995
+    assert (xb.grad.float() - xr.grad).abs().max().item() <= 4e-2 * xr.grad.abs().max().item()
+    assert F.cosine_similarity(xb.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.999
+
+
 def test_unet_and_vae_bf16_hip_path_tracks_fp32_torch_path():
     """Whole small UNet / VAE: bf16 + HIP GroupNorm kernels vs the same weights in fp32 torch ops."""
     from garmentdreamer_amd.guidance import sd21
