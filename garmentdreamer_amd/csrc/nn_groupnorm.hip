@@ -7,7 +7,7 @@
 // accesses, thread <-> fixed channel vector so gamma/beta/mean/rstd live in registers, fp32 math,
 // fp64 global accumulation of the (few) per-workgroup partial sums.
 //
-// Statistics workspace (gd_nn_groupnorm_ws_bytes): [N*G*2 fp64 accumulators][1 u64 ticket].  It must be ZERO when
+// Statistics workspace (gd_nn_groupnorm_ws_bytes): [8 x N*G*2 fp64 accumulators][N u64 tickets].  It must be ZERO when
 // a call starts and is zero again when the call's kernels have run: the last statistics workgroup to finish
 // (ticket) turns the sums into fp32 results in a separate buffer (mean_rstd / group_sums) and clears what it
 // read with atomic exchanges -- no memset and no finalize launch per GroupNorm (105 GroupNorms per SDS step).
@@ -40,6 +40,7 @@ __device__ __forceinline__ uint16_t f2bf(float f)
 }
 
 constexpr int kMaxThreads = 320;  // C = 2560 -> 320 vectors per pixel
+constexpr int kSlots = 8;         // copies of the statistics accumulators (contention, see reduce_to_groups)
 
 // Sum over the workgroup of per-thread per-channel partials, folded to per-group totals and added
 // to ws[n][g][0..1] in fp64.  `a`, `b`: the thread's 8-channel partial sums of two quantities.
@@ -49,7 +50,9 @@ __device__ __forceinline__ void reduce_to_groups(const float (&a)[8], const floa
                                                  int tr, int C, int G, int N, int n, double M, float eps,
                                                  double* __restrict__ ws, float* __restrict__ result, float* lds)
 {
-    double* ws_n = ws + (size_t)n * G * 2;
+    // kSlots copies of the accumulators, picked by chunk index: with up to 256 chunks per image all adding to the
+    // same 2*G addresses, the (returning) atomics of one copy serialised for ~10 us per workgroup
+    double* ws_n = ws + ((size_t)(blockIdx.x % kSlots) * N + n) * G * 2;
     // lds: [2][rows][C]
     float* la = lds;
     float* lb = lds + (size_t)rows * C;
@@ -85,20 +88,22 @@ __device__ __forceinline__ void reduce_to_groups(const float (&a)[8], const floa
         const double o2 = atomicAdd(&ws_n[2 * g + 1], (double)sb);
         asm volatile("" ::"v"(o1), "v"(o2));
     }
-    // last workgroup of the launch: sums -> results, and leave accumulators + ticket zero for the next call
+    // last workgroup of this image: sums -> results, and leave accumulators + ticket zero for the next call
     __shared__ unsigned int s_last;
     __syncthreads();
-    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws + (size_t)N * G * 2);
-    if (threadIdx.x == 0) {
-        const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
-        s_last = atomicAdd(ticket, 1ULL) == total - 1 ? 1u : 0u;
-    }
+    // one ticket per image: the last workgroup of image n finalises that image's G groups
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ws + (size_t)kSlots * N * G * 2) + n;
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1ULL) == (unsigned long long)gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
-    for (int i = threadIdx.x; i < N * G; i += blockDim.x) {
-        unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws + 2 * (size_t)i);
-        const double sa = __longlong_as_double((long long)atomicExch(acc, 0ULL));
-        const double sb = __longlong_as_double((long long)atomicExch(acc + 1, 0ULL));
+    for (int i = n * G + threadIdx.x; i < (n + 1) * G; i += blockDim.x) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < kSlots; sl++) {
+            unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws + 2 * ((size_t)sl * N * G + i));
+            sa += __longlong_as_double((long long)atomicExch(acc, 0ULL));
+            sb += __longlong_as_double((long long)atomicExch(acc + 1, 0ULL));
+        }
         if (MODE == 0) {
             const double mean = sa / M;
             double var = sb / M - mean * mean;
@@ -306,7 +311,7 @@ extern "C" {
 
 size_t gd_nn_groupnorm_ws_bytes(int N, int G)
 {
-    return (size_t)N * G * 2 * sizeof(double) + sizeof(unsigned long long);
+    return (size_t)kSlots * N * G * 2 * sizeof(double) + (size_t)N * sizeof(unsigned long long);
 }
 
 int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
