@@ -1055,6 +1055,32 @@ int gd_nn_conv3x3_s2_dgrad(void* stream, const void* dy, const void* weight_flip
     return GD_NN_OK;
 }
 
+int gd_nn_conv3x3_up2_forward(void* stream, const void* x, const void* w_even_rows, const void* w_odd_rows,
+                              const void* bias, void* y, int N, int H, int W, int Cin, int Cout)
+{
+    if (!x || !w_even_rows || !w_odd_rows || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || H < 1 || W < 1 || Cin % BK || Cout % 4 || Cin <= 0 || Cout <= 0)
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3 up2: need Cin % 64 == 0, Cout % 4 == 0");
+    // y[2i+py, 2j+px] = sum over (ty, tx) in {0,1}^2 of x[i + ty + py - 1, j + tx + px - 1] . Wc[py][px][ty][tx]
+    // where Wc sums the 3x3 taps that land on the same source pixel of the nearest-neighbour upsampled image
+    // (rows: py = 0 -> {ky=0}, {ky=1,2};  py = 1 -> {ky=0,1}, {ky=2}; columns alike).  Tap (px, ty, tx) of row
+    // parity py is filter slot px*4 + ty*2 + tx of w_even_rows / w_odd_rows ([Cout][9][Cin], slot 8 unused).
+    for (int py = 0; py < 2; py++)
+        for (int px = 0; px < 2; px++) {
+            ConvGeom g = {};
+            g.Hin = H; g.Win = W;
+            g.Hg = H; g.Wg = W;
+            g.sy = g.sx = 1;
+            g.Hout = 2 * H; g.Wout = 2 * W;
+            g.osy = g.osx = 2; g.ooy = py; g.oox = px;
+            for (int ty = 0; ty < 2; ty++)
+                for (int tx = 0; tx < 2; tx++) add_tap(g, ty + py - 1, tx + px - 1, px * 4 + ty * 2 + tx);
+            const int r = launch_conv((hipStream_t)stream, x, py ? w_odd_rows : w_even_rows, bias, 0, nullptr, y, N, g, Cin, Cout);
+            if (r < 0) return r;
+        }
+    return GD_NN_OK;
+}
+
 int gd_nn_conv_force_variant(int v)
 {
     g_force_variant = v;

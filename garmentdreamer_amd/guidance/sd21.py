@@ -36,7 +36,8 @@ import torch.nn.functional as F
 
 from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, conv1x1, conv3x3, conv3x3_s2, conv3x3_s2_supported, conv3x3_small_cin,
                       conv3x3_supported, geglu, gn_conv3x3, gn_conv3x3_supported, gn_conv_prefers_fused, group_norm_silu,
-                      resnet_block_frozen, resnet_block_frozen_supported)
+                      resnet_block_frozen, resnet_block_frozen_supported, upsample2x_conv3x3,
+                      upsample2x_conv3x3_supported)
 
 
 import os as _os
@@ -314,6 +315,8 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x):
+        if upsample2x_conv3x3_supported(x, self.conv.weight) and not self.conv.bias.requires_grad:
+            return upsample2x_conv3x3(x, self.conv.weight, self.conv.bias)   # no upsampled tensor, 16 taps not 36
         return _conv3(self.conv, F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 

@@ -106,6 +106,15 @@ int gd_nn_conv3x3_first_forward(void* stream, const void* x, const void* weight,
 int gd_nn_conv3x3_s2_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int Hin,
                              int Win, int Cin, int Cout, int pad_lo);
 
+/* y = conv3x3_s1_p1( nearest_upsample_2x(x) ) + bias, diffusers Upsample2D (F.interpolate(scale_factor=2, "nearest")
+ * followed by the 3x3 convolution; UNet up blocks) without the upsampled tensor: each output-pixel parity class
+ * (py, px) is a 2x2-tap convolution of x with pre-summed filters -- 16 tap GEMMs instead of 36, and no 4x larger
+ * intermediate.  x: [N,H,W,Cin], y: [N,2H,2W,Cout], bias [Cout] or NULL.  w_even_rows / w_odd_rows: [Cout][9][Cin]
+ * bf16, slot px*4 + ty*2 + tx = sum of the original taps (ky, kx) with ky in R(py, ty), kx in R(px, tx),
+ * R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}; slot 8 unused. */
+int gd_nn_conv3x3_up2_forward(void* stream, const void* x, const void* w_even_rows, const void* w_odd_rows,
+                              const void* bias, void* y, int N, int H, int W, int Cin, int Cout);
+
 /* Input gradient of gd_nn_conv3x3_s2_forward: dx[N,Hin,Win,Cin] from dy[N,Ho,Wo,Cout] and
  * weight_flipped = gd_nn_conv3x3_flip_weights(weight) ([Cin][3][3][Cout]).  Four launches, one per parity
  * class of the input pixel, each walking only the taps that reach it (9 taps in total: no zero-insertion

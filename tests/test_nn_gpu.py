@@ -443,6 +443,31 @@ def test_plain_conv_on_patch_kernel_matches_fp32_reference(N, Cin, Cout, H, W, p
         assert F.cosine_similarity(y.float().flatten(), yr.flatten(), dim=0).item() > 0.9999
 
 
+@pytest.mark.parametrize("N,C,Cout,H,W", [(2, 128, 128, 16, 16), (1, 320, 320, 9, 13), (3, 64, 192, 5, 4), (2, 1280, 1280, 8, 8)])
+def test_upsample_fused_conv_matches_fp32_reference(N, C, Cout, H, W):
+    """gd_nn_conv3x3_up2_forward (four 2x2-tap convolutions with pre-summed filters) against
+    conv2d(interpolate(x, 2, nearest)) in fp32 with the same bf16 weights; odd sizes exercise the borders."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(H * 31 + W)
+    x = torch.randn(N, C, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, C, 3, 3, device=DEV, generator=g) * (1.0 / (3 * C ** 0.5))).to(torch.bfloat16) \
+        .contiguous(memory_format=torch.channels_last)
+    b = (torch.randn(Cout, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    with torch.no_grad():
+        y = nn_ops.upsample2x_conv3x3(x, w, b)
+        ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    scale = ref.abs().max().item()
+    assert (y.float() - ref).abs().max().item() <= 2e-2 * scale
+    assert F.cosine_similarity(y.float().flatten(), ref.flatten(), dim=0).item() > 0.9998
+    w2 = w.clone()                       # the pre-summed filters follow weight updates
+    w2.mul_(0.5)
+    with torch.no_grad():
+        y2 = nn_ops.upsample2x_conv3x3(x, w2, None)
+        ref2 = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w2.float(), None, padding=1)
+    assert (y2.float() - ref2).abs().max().item() <= 2e-2 * ref2.abs().max().item()
+
+
 def test_flipped_weight_cache_follows_weight_updates():
     """The dgrad weights are cached per weight tensor; loading new values in place (load_state_dict) must refresh them."""
     from garmentdreamer_amd.nn_ops import conv3x3
