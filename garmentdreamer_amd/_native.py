@@ -70,6 +70,8 @@ SCENE_SIGNATURES = {
     "gd_scene_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _I64P, C.POINTER(C.c_double), C.c_double,
                                 C.c_double, C.c_double, _i]),
     "gd_scene_densify_stats": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gd_scene_activate_forward": (_i, [_vp, _i, _i] + [_vp] * 9),
+    "gd_scene_activate_backward": (_i, [_vp, _i, _i] + [_vp] * 12),
     "gd_scene_last_error": (C.c_char_p, []),
 }
 

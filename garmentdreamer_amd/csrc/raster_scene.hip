@@ -252,6 +252,71 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const int* __
     }
 }
 
+// Parameter activations of GaussianModel (scene/gaussian_model.py:95-115): one thread per Gaussian instead of
+// exp / sigmoid / normalize (norm, clamp, div) / cat kernels and their autograd nodes.
+__global__ __launch_bounds__(256) void activate_forward_kernel(int P, int M, const float* __restrict__ f_dc,
+                                                               const float* __restrict__ f_rest,
+                                                               const float* __restrict__ opacity_raw,
+                                                               const float* __restrict__ scaling_raw,
+                                                               const float* __restrict__ rotation_raw,
+                                                               float* __restrict__ shs, float* __restrict__ opacity,
+                                                               float* __restrict__ scales, float* __restrict__ rotations)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float* sh = shs + (size_t)i * M * 3;
+    for (int k = 0; k < 3; k++) sh[k] = f_dc[(size_t)i * 3 + k];
+    for (int k = 0; k < 3 * (M - 1); k++) sh[3 + k] = f_rest[(size_t)i * 3 * (M - 1) + k];
+    opacity[i] = 1.0f / (1.0f + expf(-opacity_raw[i]));
+    for (int k = 0; k < 3; k++) scales[(size_t)i * 3 + k] = expf(scaling_raw[(size_t)i * 3 + k]);
+    const float4 q = *reinterpret_cast<const float4*>(rotation_raw + (size_t)i * 4);
+    const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);   // F.normalize eps
+    *reinterpret_cast<float4*>(rotations + (size_t)i * 4) = make_float4(q.x / nrm, q.y / nrm, q.z / nrm, q.w / nrm);
+}
+
+// g_* += d(activated)/d(raw)^T . d_*  (accumulating, like AccumulateGrad on a zeroed .grad)
+__global__ __launch_bounds__(256) void activate_backward_kernel(int P, int M, const float* __restrict__ opacity,
+                                                                const float* __restrict__ scales,
+                                                                const float* __restrict__ rotation_raw,
+                                                                const float* __restrict__ d_shs,
+                                                                const float* __restrict__ d_opacity,
+                                                                const float* __restrict__ d_scales,
+                                                                const float* __restrict__ d_rot, float* __restrict__ g_f_dc,
+                                                                float* __restrict__ g_f_rest, float* __restrict__ g_opacity,
+                                                                float* __restrict__ g_scaling, float* __restrict__ g_rotation)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    if (d_shs) {
+        const float* ds = d_shs + (size_t)i * M * 3;
+        for (int k = 0; k < 3; k++) g_f_dc[(size_t)i * 3 + k] += ds[k];
+        for (int k = 0; k < 3 * (M - 1); k++) g_f_rest[(size_t)i * 3 * (M - 1) + k] += ds[3 + k];
+    }
+    if (d_opacity) {
+        const float o = opacity[i];
+        g_opacity[i] += d_opacity[i] * o * (1.0f - o);
+    }
+    if (d_scales)
+        for (int k = 0; k < 3; k++) g_scaling[(size_t)i * 3 + k] += d_scales[(size_t)i * 3 + k] * scales[(size_t)i * 3 + k];
+    if (d_rot) {
+        const float4 q = *reinterpret_cast<const float4*>(rotation_raw + (size_t)i * 4);
+        const float4 g = *reinterpret_cast<const float4*>(d_rot + (size_t)i * 4);
+        const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        float4 r;
+        if (len > 1e-12f) {   // d(q/|q|) = (g - n (n.g)) / |q|
+            const float inv = 1.0f / len;
+            const float4 n = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+            const float ng = n.x * g.x + n.y * g.y + n.z * g.z + n.w * g.w;
+            r = make_float4((g.x - n.x * ng) * inv, (g.y - n.y * ng) * inv, (g.z - n.z * ng) * inv, (g.w - n.w * ng) * inv);
+        } else {              // clamped denominator: q / 1e-12
+            r = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+        }
+        float4* out = reinterpret_cast<float4*>(g_rotation + (size_t)i * 4);
+        const float4 acc = *out;
+        *out = make_float4(acc.x + r.x, acc.y + r.y, acc.z + r.z, acc.w + r.w);
+    }
+}
+
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct KnnScratch {
@@ -359,6 +424,40 @@ int gd_scene_densify_stats(void* stream, int P, const int* radii, const float* v
         return sfail(-1, "densify_stats: null pointer");
     hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, radii,
                        viewspace_grad, max_radii2D, xyz_gradient_accum, denom);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sfail(-2, hipGetErrorString(e));
+    return 0;
+}
+
+int gd_scene_activate_forward(void* stream, int P, int M, const float* f_dc, const float* f_rest, const float* opacity_raw,
+                              const float* scaling_raw, const float* rotation_raw, float* shs, float* opacity,
+                              float* scales, float* rotations)
+{
+    using namespace gd;
+    if (P <= 0) return 0;
+    if (M < 1 || !f_dc || (M > 1 && !f_rest) || !opacity_raw || !scaling_raw || !rotation_raw || !shs || !opacity ||
+        !scales || !rotations)
+        return sfail(-1, "activate_forward: null pointer or M < 1");
+    hipLaunchKernelGGL(activate_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, M, f_dc,
+                       f_rest, opacity_raw, scaling_raw, rotation_raw, shs, opacity, scales, rotations);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sfail(-2, hipGetErrorString(e));
+    return 0;
+}
+
+int gd_scene_activate_backward(void* stream, int P, int M, const float* opacity, const float* scales,
+                               const float* rotation_raw, const float* d_shs, const float* d_opacity,
+                               const float* d_scales, const float* d_rotations, float* g_f_dc, float* g_f_rest,
+                               float* g_opacity, float* g_scaling, float* g_rotation)
+{
+    using namespace gd;
+    if (P <= 0) return 0;
+    if (M < 1 || !opacity || !scales || !rotation_raw || !g_f_dc || (M > 1 && !g_f_rest) || !g_opacity || !g_scaling ||
+        !g_rotation)
+        return sfail(-1, "activate_backward: null pointer or M < 1");
+    hipLaunchKernelGGL(activate_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, M, opacity,
+                       scales, rotation_raw, d_shs, d_opacity, d_scales, d_rotations, g_f_dc, g_f_rest, g_opacity,
+                       g_scaling, g_rotation);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sfail(-2, hipGetErrorString(e));
     return 0;

@@ -88,6 +88,57 @@ class OptimizationParams:
     percent_dense = 0.01
 
 
+class _ActivateScene(torch.autograd.Function):
+    """``get_features / get_opacity / get_scaling / get_rotation`` (scene/gaussian_model.py:95-115) as one HIP launch
+    forward and one backward (gd_scene_activate_*, include/gd_scene.h) instead of exp / sigmoid / normalize / cat
+    kernels and their autograd nodes.  With ``grad_views`` (the five slices of the scene's flat gradient buffer)
+    the backward accumulates straight into them and returns no gradients: no AccumulateGrad kernels either."""
+
+    @staticmethod
+    def forward(ctx, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, grad_views):
+        P, M = f_dc.shape[0], 1 + f_rest.shape[1]
+        dev = f_dc.device
+        shs = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
+        opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
+        scales = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        rots = torch.empty((P, 4), dtype=torch.float32, device=dev)
+        L = _native.lib()
+        with torch.cuda.device(dev):
+            _native.check_scene(L.gd_scene_activate_forward(
+                torch.cuda.current_stream(dev).cuda_stream, P, M, f_dc.data_ptr(),
+                f_rest.data_ptr() if M > 1 else None, opacity_raw.data_ptr(), scaling_raw.data_ptr(),
+                rotation_raw.data_ptr(), shs.data_ptr(), opac.data_ptr(), scales.data_ptr(), rots.data_ptr()),
+                "gd_scene_activate_forward")
+        ctx.save_for_backward(opac, scales, rotation_raw)
+        ctx.grad_views, ctx.M, ctx.rest_shape = grad_views, M, f_rest.shape
+        ctx.set_materialize_grads(False)
+        return shs, opac, scales, rots
+
+    @staticmethod
+    def backward(ctx, d_shs, d_opac, d_scales, d_rots):
+        opac, scales, rotation_raw = ctx.saved_tensors
+        P, M, dev = opac.shape[0], ctx.M, opac.device
+        direct = ctx.grad_views is not None
+        if direct:
+            g = ctx.grad_views
+        else:
+            g = (torch.zeros((P, 1, 3), device=dev), torch.zeros(ctx.rest_shape, device=dev),
+                 torch.zeros((P, 1), device=dev), torch.zeros((P, 3), device=dev), torch.zeros((P, 4), device=dev))
+        c = lambda t: None if t is None else t.contiguous()                       # noqa: E731
+        d_shs, d_opac, d_scales, d_rots = c(d_shs), c(d_opac), c(d_scales), c(d_rots)
+        p = lambda t: None if t is None else t.data_ptr()                         # noqa: E731
+        L = _native.lib()
+        with torch.cuda.device(dev):
+            _native.check_scene(L.gd_scene_activate_backward(
+                torch.cuda.current_stream(dev).cuda_stream, P, M, opac.data_ptr(), scales.data_ptr(),
+                rotation_raw.data_ptr(), p(d_shs), p(d_opac), p(d_scales), p(d_rots), g[0].data_ptr(),
+                g[1].data_ptr() if M > 1 else None, g[2].data_ptr(), g[3].data_ptr(), g[4].data_ptr()),
+                "gd_scene_activate_backward")
+        if direct:
+            return (None,) * 6
+        return g[0], g[1], g[2], g[3], g[4], None
+
+
 class GaussianModel(GaussianParams):
     """Flat-buffer Gaussian scene with the reference's optimisation / densification surface."""
 
@@ -201,6 +252,17 @@ class GaussianModel(GaussianParams):
 
     def zero_grad(self):
         self._grad.zero_()
+
+    def activated(self):
+        """(shs [P,M,3], opacity [P,1], scales [P,3], rotations [P,4]) -- the activated accessors in one launch
+        (``_ActivateScene``); gradients go straight into the flat gradient buffer.  CPU tensors: the torch ops."""
+        if not self._flat.is_cuda:
+            return self.get_features, self.get_opacity, self.get_scaling, self.get_rotation
+        raw = (self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation)
+        views = None
+        if torch.is_grad_enabled() and all(p.grad is not None and p.grad.is_contiguous() for p in raw):
+            views = tuple(p.grad for p in raw)
+        return _ActivateScene.apply(*raw, views)
 
     def step(self, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15):
         """``torch.optim.Adam(l, lr=0.0, eps=1e-15).step()`` (:166) as one HIP launch over the flat buffer."""

@@ -82,10 +82,14 @@ def render_batch(cameras, pc, bg_color: torch.Tensor, scaling_modifier=1.0, over
         bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=cb.viewmatrix, projmatrix=cb.projmatrix,
         sh_degree=pc.active_sh_degree, campos=cb.campos, prefiltered=False, debug=False)
     rasterizer = GaussianRasterizer(raster_settings=rs)
-    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+    if hasattr(pc, "activated"):     # flat-buffer GaussianModel: all activations in one launch
+        feats, opacities, scales, rotations = pc.activated()
+    else:
+        feats, opacities, scales, rotations = pc.get_features, pc.get_opacity, pc.get_scaling, pc.get_rotation
+    shs, colors_precomp = (feats, None) if override_color is None else (None, override_color)
     rendered, radii, depth, alpha = rasterizer(
         means3D=xyz.float(), means2D=screenspace_points.float(), shs=None if shs is None else shs.float(),
-        colors_precomp=colors_precomp, opacities=pc.get_opacity.float(), scales=pc.get_scaling.float(),
-        rotations=pc.get_rotation.float(), cov3D_precomp=None)
+        colors_precomp=colors_precomp, opacities=opacities.float(), scales=scales.float(),
+        rotations=rotations.float(), cov3D_precomp=None)
     return {"render": rendered, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "depth_3dgs": depth, "alpha": alpha}

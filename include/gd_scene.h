@@ -10,6 +10,8 @@
  *                            (scene/gaussian_model.py:156-167): ONE launch over a flat fp32 parameter buffer with a
  *                            per-group learning rate (the flat gradient buffer is also what the view-sharded
  *                            all-reduce sends, garmentdreamer_amd/dist.py).
+ *   gd_scene_activate_*   <- get_features / get_opacity / get_scaling / get_rotation (scene/gaussian_model.py:95-115)
+ *                            and their autograd nodes: one launch forward, one backward.
  *   gd_scene_densify_stats <- on_before_optimizer_step + add_densification_stats
  *                            (Garment_3DGS/threestudio/systems/GaussianDreamer.py:268-279,
  *                             scene/gaussian_model.py:415-419): max_radii2D / xyz_gradient_accum / denom update.
@@ -53,6 +55,21 @@ int gd_scene_adam_step(void* stream, float* param, const float* grad, float* exp
  * radii: int32 [P]; viewspace_grad: float [P][3]; the three accumulators: float [P]. */
 int gd_scene_densify_stats(void* stream, int P, const int* radii, const float* viewspace_grad, float* max_radii2D,
                            float* xyz_gradient_accum, float* denom);
+
+/* Parameter activations of GaussianModel (get_features / get_opacity / get_scaling / get_rotation,
+ * scene/gaussian_model.py:95-115) in one launch: shs = cat(f_dc, f_rest) [P][M][3], opacity = sigmoid,
+ * scales = exp, rotations = q / max(|q|, 1e-12) (torch.nn.functional.normalize).  M = (sh_degree + 1)^2;
+ * f_rest may be NULL when M == 1. */
+int gd_scene_activate_forward(void* stream, int P, int M, const float* f_dc, const float* f_rest, const float* opacity_raw,
+                              const float* scaling_raw, const float* rotation_raw, float* shs, float* opacity,
+                              float* scales, float* rotations);
+
+/* Its input gradients, ACCUMULATED into g_* (the flat gradient buffer of the scene, zeroed once per step):
+ * opacity / scales are the activated outputs of the forward, d_* the gradients w.r.t. them (any may be NULL). */
+int gd_scene_activate_backward(void* stream, int P, int M, const float* opacity, const float* scales,
+                               const float* rotation_raw, const float* d_shs, const float* d_opacity,
+                               const float* d_scales, const float* d_rotations, float* g_f_dc, float* g_f_rest,
+                               float* g_opacity, float* g_scaling, float* g_rotation);
 
 const char* gd_scene_last_error(void);
 

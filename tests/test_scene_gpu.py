@@ -147,3 +147,38 @@ def test_simple_knn_import_path_is_served_by_the_hip_kernel():
     D.fill_diagonal_(float("inf"))
     ref = D.topk(3, largest=False).values.mean(dim=1)
     assert d.shape == (500,) and torch.allclose(d.double(), ref, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("sh_degree", [0, 2])
+def test_fused_activations_match_torch_accessors_and_their_gradients(sh_degree):
+    """GaussianModel.activated() (gd_scene_activate_forward / _backward, one launch each, gradients accumulated
+    straight into the flat gradient buffer) vs get_features / get_opacity / get_scaling / get_rotation through
+    torch autograd (scene/gaussian_model.py:95-115)."""
+    from garmentdreamer_amd.gaussian_model import GaussianModel
+    from garmentdreamer_amd.scene import synthetic_gaussians
+    gm = GaussianModel.from_activated(synthetic_gaussians(5000, seed=3, sh_degree=sh_degree), sh_degree=sh_degree, device=DEV)
+    with torch.no_grad():
+        gm._rotation[:7] *= 3.7                  # un-normalised quaternions exercise the normalize Jacobian
+        gm._rotation[7] = 0.0                    # and the clamped denominator
+    outs = gm.activated()
+    refs = (gm.get_features, gm.get_opacity, gm.get_scaling, gm.get_rotation)
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape
+        torch.testing.assert_close(o, r, rtol=2e-6, atol=1e-7)
+    g = torch.Generator(DEV).manual_seed(1)
+    ws = [torch.randn(o.shape, device=DEV, generator=g) for o in outs]
+    gm.zero_grad()
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    fused = gm.flat_grad.clone()
+    assert fused.abs().sum().item() > 0
+    gm.zero_grad()
+    sum((r * w).sum() for r, w in zip(refs, ws)).backward()
+    ref = gm.flat_grad.clone()
+    ok = torch.isfinite(ref)
+    torch.testing.assert_close(fused[ok], ref[ok], rtol=1e-5, atol=1e-6)
+    # twice through the same buffer accumulates, like AccumulateGrad on an existing .grad
+    gm.zero_grad()
+    for _ in range(2):
+        o2 = gm.activated()
+        sum((o * w).sum() for o, w in zip(o2, ws)).backward()
+    torch.testing.assert_close(gm.flat_grad[ok], 2 * fused[ok], rtol=1e-5, atol=1e-6)
