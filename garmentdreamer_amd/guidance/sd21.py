@@ -563,17 +563,32 @@ class _VAEAttention(nn.Module):
         self.to_v = nn.Linear(ch, ch)
         self.to_out = nn.ModuleList([nn.Linear(ch, ch)])
 
+    def _qkv_scaled(self, dtype, scale):
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_q.bias, self.to_k.bias, self.to_v.bias)
+        key = (ws[0].data_ptr(), dtype) + tuple(t._version for t in ws)
+        if getattr(self, "_qkv_key", None) != key:
+            with torch.no_grad():
+                w = torch.cat([ws[0].float() * scale, ws[1].float(), ws[2].float()], dim=0).to(dtype).contiguous()
+                b = torch.cat([ws[3].float() * scale, ws[4].float(), ws[5].float()], dim=0).to(dtype)
+            self._qkv_cache, self._qkv_key = (w, b), key
+        return self._qkv_cache
+
     def forward(self, x):
         B, C, H, W = x.shape
         h = _gn(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
-        q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
         if x.is_cuda:
-            # one head of dim 512: three plain GEMMs + a softmax (hipBLASLt) beat the fused kernel, whose
-            # backward for head_dim 512 runs at ~180 TFLOP/s; the [B,N,N] bf16 score matrix (34 MB per
-            # image at N = 4096) is cheap on a 288 GB part
-            p = torch.softmax(torch.bmm(q * (C ** -0.5), k.transpose(1, 2)), dim=-1)   # scale q (N x C), not the N x N scores
+            # one head of dim 512: plain GEMMs + a softmax (hipBLASLt) beat the fused kernel, whose backward for
+            # head_dim 512 runs at ~180 TFLOP/s; the [B,N,N] bf16 score matrix (34 MB per image at N = 4096) is
+            # cheap on a 288 GB part.  Frozen weights: one [C, 3C] projection with the softmax scale folded into its
+            # q rows (no N x C scaling pass forward or backward); the bmm's read the strided q / k / v views.
+            if _FUSED_QKV and not (self.to_q.weight.requires_grad or self.to_k.weight.requires_grad or self.to_v.weight.requires_grad):
+                q, k, v = F.linear(h, *self._qkv_scaled(h.dtype, C ** -0.5)).chunk(3, dim=-1)
+            else:
+                q, k, v = self.to_q(h) * (C ** -0.5), self.to_k(h), self.to_v(h)
+            p = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
             o = torch.bmm(p, v)
         else:
+            q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
             o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
         o = self.to_out[0](o).reshape(B, H, W, C).permute(0, 3, 1, 2)
         return x + o
