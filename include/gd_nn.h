@@ -47,8 +47,9 @@ size_t gd_nn_groupnorm_ws_bytes(int N, int G);
 
 /* y = conv3x3(x, w; stride 1, pad 1) [+ bias] [+ residual], NHWC bf16, as an MFMA implicit GEMM.
  * x: [N,H,W,Cin]; weight: [Cout][3][3][Cin] (PyTorch's channels_last weight storage); bias: [Cout]
- * (bias_img_stride = 0) or [N][Cout] (bias_img_stride = Cout: per-image bias, e.g. conv bias +
- * time-embedding projection of diffusers' ResnetBlock2D); residual: [N,H,W,Cout] or NULL;
+ * (bias_img_stride = 0) or [N][Cout] (bias_img_stride = elements between rows, >= Cout and a multiple of 8:
+ * per-image bias, e.g. conv bias + time-embedding projection of diffusers' ResnetBlock2D; a column slice of a
+ * wider matrix is passed with that matrix's row stride); residual: [N,H,W,Cout] or NULL;
  * Cin % 64 == 0, Cout % 4 == 0.  Replaces F.conv2d (+ bias kernel + residual add kernel). */
 int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const void* bias, int bias_img_stride,
                           const void* residual, void* y, int N, int H, int W, int Cin, int Cout);
