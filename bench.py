@@ -327,7 +327,7 @@ def main():
         ach = conv_flops / (conv_ms * 1e-3) / 1e12
         roofline_conv = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "conv3x3_nhwc_bf16_kernel + conv3x3_gn_patch_kernel",
+                         "kernel": "conv3x3_nhwc_bf16_kernel + conv3x3_gn_patch_kernel + conv3x3_patch_stream_kernel",
                          "avg_launch_us": conv_ms / conv_n * 1e3, "launches": conv_n,
                          "flops_per_launch": conv_flops / conv_n, "ms_per_step": conv_ms / max(conv_steps, 1),
                          "timing": conv_note,

@@ -588,6 +588,306 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_gn_patch_kernel(
     }
 }
 
+// The same patch-staged convolution as a PERSISTENT kernel for the plain (GN = false) case; the GroupNorm variants
+// above keep one tile per workgroup (their register-staged transform leaves no registers for the cross-tile
+// prefetch: restructured the same way they ran 2-3 % slower).
+template <int BN, int WN, int WM, bool GN>
+__global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
+    const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
+    int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, int H, int W,
+    int Cin, int Cout, const float* __restrict__ mean_rstd, const uint16_t* __restrict__ gamma,
+    const uint16_t* __restrict__ beta, int G, int apply_silu, int tiles_n, int tiles_x, int tiles_y, int nwg)
+{
+    constexpr int BM = 256;
+    constexpr int THREADS = 64 * WN * WM;
+    constexpr int NB = BN * 8 / THREADS;                       // 16-B chunks of the weight tile per thread per step
+    constexpr int NA = (kPatchPix * 8 + THREADS - 1) / THREADS;  // ... of the activation patch per K chunk
+    constexpr int FA = BN / WN / 32, FB = BM / WM / 32;
+    static_assert(FB == 2 && THREADS % 8 == 0, "wave pixel block = 4 patch rows x 16");
+    constexpr int kAStage = (kPatchPix + 4) * BK * 2;          // 41984 B: 324 pixels + 4 of padding so that the last
+                                                               // (half-filled) LDS-DMA piece of wave 0 stays inside
+    constexpr int kBStage = BN * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                    // 2 stages
+    char* sB = smem + 2 * kAStage;      // 2 stages
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // PERSISTENT workgroups (plain variant, GN = false): workgroup b runs tiles b, b + gridDim.x, ... as one
+    // continuous stream of (chunk, tap) steps -- the patch of the next tile's first chunk and its first weight slice
+    // are fetched during the last chunk of the current tile, so the load prologue (half of all patch traffic when
+    // Cin = 128) and the epilogue stores overlap with MFMA work instead of standing at the head and tail of every
+    // workgroup: +3...5 % on the plain convolutions (tools/patch_conv_bench.py).
+    const int tpi = tiles_x * tiles_y;
+    const bool remap = (nwg & 7) == 0 && (GN || (gridDim.x & 7) == 0);   // XCD-contiguous tile order
+    struct Tile { int nimg, tyi, txi, n0; };
+    auto decode = [&](int vb) {
+        int bid = vb;
+        if (remap) bid = (vb & 7) * (nwg >> 3) + (vb >> 3);
+        const int tn = bid % tiles_n, tm = bid / tiles_n;
+        Tile t;
+        t.nimg = tm / tpi;
+        const int trem = tm - t.nimg * tpi;
+        t.tyi = trem / tiles_x;
+        t.txi = trem - t.tyi * tiles_x;
+        t.n0 = tn * BN;
+        return t;
+    };
+
+    const uint32_t row_bytes = (uint32_t)Cin * 2u;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)in, 0, (int)((uint32_t)Nimg * (uint32_t)(H * W) * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)wt, 0, (int)((uint32_t)Cout * 9u * row_bytes), 0x00020000);
+
+    // ---- activation loader: thread <-> fixed channel octet (tid & 7), NA patch pixels
+    const int a_chunk = tid & 7;
+    uint32_t a_goff[NA];      // byte offset of (pixel, octet) in `in`, or kOOB (outside image / beyond the patch)
+    uint32_t a_lds[NA];       // byte offset inside a patch stage
+    uint32_t a_keep = 0;      // bit i: slot i is a real patch pixel inside the image (else it must stay zero)
+    uint32_t a_slot = 0;      // bit i: slot i exists (pix < 324)
+    int ld_nimg = 0;          // image of the tile whose patch is being loaded (its GroupNorm statistics row)
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int pix = (tid + THREADS * i) >> 3;
+        a_lds[i] = (uint32_t)pix * 128u + (uint32_t)((a_chunk ^ ((pix >> 1) & 7)) << 4);
+        if (pix < kPatchPix) a_slot |= 1u << i;
+    }
+    // loader state of the tile whose patch chunks are fetched next
+    auto setupA = [&](const Tile& t) {
+        const int y0 = t.tyi * 16 - 1, x0 = t.txi * 16 - 1;   // image coords of patch pixel (0, 0)
+        a_keep = 0;
+        ld_nimg = t.nimg;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int pix = (tid + THREADS * i) >> 3;
+            const int py = pix / kPatch, px = pix - py * kPatch;
+            const int gy = y0 + py, gx = x0 + px;
+            const bool inimg = pix < kPatchPix && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            // GN: this thread always handles channel octet tid & 7 and swizzles the LDS address; DMA: the LDS slot
+            // is lane-linear, so the swizzle picks WHICH octet the lane fetches
+            const int oct = GN ? a_chunk : (a_chunk ^ ((pix >> 1) & 7));
+            a_goff[i] = inimg ? (uint32_t)((t.nimg * H + gy) * W + gx) * row_bytes + (uint32_t)oct * 16u : kOOB;
+            if (inimg) a_keep |= 1u << i;
+        }
+    };
+    uint4 a_reg[NA];
+    auto loadA = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)a_goff[i], (int)(c * (BK * 2)), 0);
+            a_reg[i] = __builtin_bit_cast(uint4, v);
+        }
+    };
+    const int cg = mean_rstd ? Cin / G : 1;
+    auto storeA = [&](int buf, int c) {
+        char* dst = sA + buf * kAStage;
+        float sc[8], sh[8];
+        if (mean_rstd) {
+            const int ch0 = c * BK + a_chunk * 8;
+            const uint4 gq = *(const uint4*)(gamma + ch0), bq = *(const uint4*)(beta + ch0);
+            const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int g = (ch0 + k) / cg;
+                const float2 mr = *(const float2*)(mean_rstd + ((size_t)ld_nimg * G + g) * 2);
+                const float gm = bf2f((uint16_t)(gw[k >> 1] >> ((k & 1) * 16)));
+                const float bt = bf2f((uint16_t)(bw[k >> 1] >> ((k & 1) * 16)));
+                sc[k] = gm * mr.y;
+                sh[k] = bt - mr.x * sc[k];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            if (!((a_slot >> i) & 1u)) continue;
+            uint4 v = a_reg[i];
+            if (mean_rstd) {
+                uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                const bool keep = (a_keep >> i) & 1u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float lo = __uint_as_float(w4[k] << 16), hi = __uint_as_float(w4[k] & 0xffff0000u);
+                    lo = lo * sc[2 * k] + sh[2 * k];
+                    hi = hi * sc[2 * k + 1] + sh[2 * k + 1];
+                    if (apply_silu) { lo = silu_fast(lo); hi = silu_fast(hi); }
+                    w4[k] = keep ? pack_bf16(lo, hi) : 0u;
+                }
+                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+            *(uint4*)(dst + a_lds[i]) = v;
+        }
+    };
+
+    // ---- weight loader (LDS-DMA, swizzled on the source side; as in the implicit-GEMM kernel)
+    uint32_t b_off[NB];
+    auto setupB = [&](const Tile& t) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int q = tid + THREADS * i;
+            const int line = q >> 4, cc = (q & 15) ^ (line & 15);
+            const int r = 2 * line + (cc >> 3);
+            const int co = t.n0 + r;
+            b_off[i] = co < Cout ? (uint32_t)co * 9u * row_bytes + (uint32_t)(cc & 7) * 16u : kOOB;
+        }
+    };
+    auto issueB = [&](int buf, int tap, int c) {
+        char* dst = sB + buf * kBStage;
+        const uint32_t soff = (uint32_t)tap * row_bytes + (uint32_t)c * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < NB; i++) bload_lds16(rs_w, b_off[i], soff, dst + (wave * 64 + THREADS * i) * 16);
+    };
+
+    f32x16 acc[FA][FB];
+
+    const int wc = wave % WN, wp = wave / WN;   // wave's channel block / pixel block (4 patch rows)
+    const int fk = lane >> 5, fn = lane & 31;
+    // MFMA pixel column fn -> (row rr in {0,1}, x) such that each 16-lane LDS service group is one row
+    int rr, fx;
+    if (fn < 4) { rr = 0; fx = fn; }
+    else if (fn < 12) { rr = 1; fx = fn - 4; }
+    else if (fn < 16) { rr = 0; fx = fn - 8; }
+    else if (fn < 20) { rr = 1; fx = fn - 8; }
+    else if (fn < 28) { rr = 0; fx = fn - 12; }
+    else { rr = 1; fx = fn - 16; }
+    uint32_t w_rd[FA];
+    int p_base[FB];           // patch pixel index of the lane's pixel for tap (0, 0)
+#pragma unroll
+    for (int a = 0; a < FA; a++) w_rd[a] = (uint32_t)swz(wc * (BN / WN) + a * 32 + fn, fk);
+#pragma unroll
+    for (int b = 0; b < FB; b++) p_base[b] = (4 * wp + 2 * b + rr) * kPatch + fx;
+
+    const int kc = Cin / BK;
+    // prologue: patch of chunk 0 and weights of step 0
+    auto issueA = [&](int buf, int c) {     // GN = false: LDS-DMA of the patch; piece NA-1 only has pixels in wave 0
+        char* dst = sA + buf * kAStage;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            if (i == NA - 1 && wave * 64 + THREADS * i >= kPatchPix * 8) continue;
+            bload_lds16(rs_in, a_goff[i], (uint32_t)c * (BK * 2), dst + (wave * 64 + THREADS * i) * 16);
+        }
+    };
+    int vb = blockIdx.x;
+    Tile cur = decode(vb);
+    setupB(cur);
+    setupA(cur);
+#pragma unroll
+    for (int a = 0; a < FA; a++)
+#pragma unroll
+        for (int b = 0; b < FB; b++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+    if (GN) {
+        loadA(0);
+        issueB(0, 0, 0);
+        storeA(0, 0);
+    } else {
+        issueA(0, 0);
+        issueB(0, 0, 0);
+    }
+    int s = 0;    // running (chunk, tap) step count: weight buffer parity
+    int ga = 0;   // running chunk count: patch stage parity
+    for (;;) {
+        const int vnext = vb + (int)gridDim.x;
+        // the GroupNorm variants keep one tile per workgroup: with the register-staged transform the cross-tile
+        // prefetch costs more registers (spills in the 256-channel variant) than the hidden prologue returns
+        const bool has_next = !GN && vnext < nwg;
+        const Tile nxt = GN ? cur : decode(has_next ? vnext : vb);
+        for (int c = 0; c < kc; c++, ga++) {
+            const char* pa = sA + (ga & 1) * kAStage;
+            const bool last_chunk = c + 1 == kc;
+            // every patch chunk of the current tile is on its way or in LDS: the loader moves on to the next tile
+            if (last_chunk && has_next) setupA(nxt);
+            for (int tap = 0; tap < 9; tap++, s++) {
+                const int bufB = s & 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (!(last_chunk && tap == 8)) {
+                    issueB(bufB ^ 1, tap == 8 ? 0 : tap + 1, tap == 8 ? c + 1 : c);
+                } else if (has_next) {
+                    setupB(nxt);
+                    issueB(bufB ^ 1, 0, 0);
+                }
+                if (!last_chunk || has_next) {
+                    const int nc = last_chunk ? 0 : c + 1;
+                    const int st = (ga + 1) & 1;   // that patch stage was last read one chunk ago
+                    if (GN) {
+                        if (tap == 0) loadA(nc);
+                        else if (tap == 1) storeA(st, nc);   // (staggering the store per wave pair: slower, tried)
+                    } else if (tap == 0) {
+                        issueA(st, nc);
+                    }
+                }
+                const char* pb = sB + bufB * kBStage;
+                const int tapoff = (tap / 3) * kPatch + (tap % 3);
+                uint32_t p_rd[FB], p_sw[FB];
+#pragma unroll
+                for (int b = 0; b < FB; b++) {
+                    const int p = p_base[b] + tapoff;
+                    p_rd[b] = (uint32_t)p * 128u;
+                    p_sw[b] = (uint32_t)((p >> 1) & 7);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    bf16x8_t wf[FA], pf[FB];
+#pragma unroll
+                    for (int a = 0; a < FA; a++) wf[a] = *(const bf16x8_t*)(pb + (w_rd[a] ^ (uint32_t)(kk << 5)));
+#pragma unroll
+                    for (int b = 0; b < FB; b++)
+                        pf[b] = *(const bf16x8_t*)(pa + p_rd[b] + ((((uint32_t)(2 * kk + fk)) ^ p_sw[b]) << 4));
+#pragma unroll
+                    for (int a = 0; a < FA; a++)
+#pragma unroll
+                        for (int b = 0; b < FB; b++)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue of the current tile (the next tile's first patch chunk and weights are already in flight)
+#pragma unroll
+        for (int b = 0; b < FB; b++) {
+            const int oy = cur.tyi * 16 + 4 * wp + 2 * b + rr, ox = cur.txi * 16 + fx;
+            if (oy >= H || ox >= W) continue;
+            const size_t opix = ((size_t)cur.nimg * H + oy) * W + ox;
+            const uint16_t* bias_n = bias ? bias + (size_t)cur.nimg * bias_img_stride : nullptr;
+#pragma unroll
+            for (int a = 0; a < FA; a++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int co = cur.n0 + wc * (BN / WN) + a * 32 + 8 * q + 4 * fk;
+                    if (co >= Cout) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = acc[a][b][4 * q + e];
+                    if (bias_n) {
+                        const uint2 bb = *(const uint2*)(bias_n + co);
+                        v[0] += bf2f((uint16_t)(bb.x & 0xffff)); v[1] += bf2f((uint16_t)(bb.x >> 16));
+                        v[2] += bf2f((uint16_t)(bb.y & 0xffff)); v[3] += bf2f((uint16_t)(bb.y >> 16));
+                    }
+                    if (residual) {
+                        const uint2 rv = *(const uint2*)(residual + opix * Cout + co);
+                        v[0] += bf2f((uint16_t)(rv.x & 0xffff)); v[1] += bf2f((uint16_t)(rv.x >> 16));
+                        v[2] += bf2f((uint16_t)(rv.y & 0xffff)); v[3] += bf2f((uint16_t)(rv.y >> 16));
+                    }
+                    uint2 o;
+                    o.x = pack_bf16(v[0], v[1]);
+                    o.y = pack_bf16(v[2], v[3]);
+                    *(uint2*)(out + opix * Cout + co) = o;
+                }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        vb = vnext;
+#pragma unroll
+        for (int a = 0; a < FA; a++)
+#pragma unroll
+            for (int b = 0; b < FB; b++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+    }
+}
+
 // out = bf16( sum_s partial[s] + bias + residual ): second half of the split-K path; 8 channels per thread
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ partial, int S, size_t MC,
                                                                  int Cout, size_t pix_per_img,
@@ -716,6 +1016,8 @@ __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint
 }
 
 int g_first_grid = 2048;   // persistent workgroups of the first-conv kernel (GD_NN_FIRST_GRID overrides, tuning)
+int g_num_cus = 256;       // MI355X; refreshed from the device properties at the first patch launch
+int g_patch_persistent = -1;   // GD_NN_PATCH_PERSISTENT=0: one workgroup per tile (A/B)
 int g_force_split = -1;    // tuning hook: -1 heuristic, 1 = never split, 3 / 9 = force
 int g_force_variant = -1;  // tuning hook: 0 = 128x128, 1 = 128x256, 2 = 256x256, -1 = heuristic
 
@@ -924,6 +1226,12 @@ static int launch_patch(void* stream, const void* x, const float* mean_rstd, con
         return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_gn: activation / weight tensor must be < 2 GiB (32-bit buffer offsets)");
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
+    if (g_patch_persistent < 0) {
+        const char* e = getenv("GD_NN_PATCH_PERSISTENT");
+        g_patch_persistent = (e && atoi(e) == 0) ? 0 : 1;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_num_cus = cus;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     const int64_t M = (int64_t)N * H * W;
@@ -935,7 +1243,7 @@ static int launch_patch(void* stream, const void* x, const float* mean_rstd, con
     }
 #define GD_LAUNCH_P(BN_, GN_)                                                                                         \
     do {                                                                                                           \
-        auto kern = conv3x3_gn_patch_kernel<BN_, 2, 4, GN_>;                                                       \
+        auto kern = GN_ ? conv3x3_gn_patch_kernel<BN_, 2, 4, true> : conv3x3_patch_stream_kernel<BN_, 2, 4, false>; \
         constexpr int lds = 2 * (kPatchPix + 4) * BK * 2 + 2 * BN_ * BK * 2;                                       \
         static bool attr_set[16] = {false};                                                                        \
         if (!attr_set[dev]) {                                                                                      \
@@ -944,7 +1252,11 @@ static int launch_patch(void* stream, const void* x, const float* mean_rstd, con
         }                                                                                                          \
         const int tiles_n = (Cout + BN_ - 1) / BN_;                                                                \
         const int nwg = N * tiles_x * tiles_y * tiles_n;                                                           \
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, s, (const uint16_t*)x, (const uint16_t*)weight,        \
+        /* persistent workgroups: one per CU (the LDS footprint allows no more), each walking tiles b, b + grid, */ \
+        /* ...; a multiple of 8 keeps the XCD-contiguous tile order */                                             \
+        int grid = nwg;                                                                                            \
+        if (g_patch_persistent && !(GN_) && nwg > g_num_cus) grid = (nwg & 7) == 0 ? (g_num_cus & ~7) : g_num_cus; \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const uint16_t*)x, (const uint16_t*)weight,       \
                            (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y, N, H,  \
                            W, Cin, Cout, mean_rstd, (const uint16_t*)gamma, (const uint16_t*)beta, groups,         \
                            apply_silu, tiles_n, tiles_x, tiles_y, nwg);                                            \

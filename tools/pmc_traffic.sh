@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(float); cnt = collections.Counter()
     for row in csv.DictReader(open(f[0])):
         k = row["Kernel_Name"]
-        key = "conv3x3_nhwc_bf16_kernel" if ("conv3x3_nhwc" in k or "conv3x3_gn_patch" in k) else ("render_backward_kernel" if "render_backward" in k else None)
+        key = "conv3x3_nhwc_bf16_kernel" if ("conv3x3_nhwc" in k or "conv3x3_gn_patch" in k or "conv3x3_patch_stream" in k) else ("render_backward_kernel" if "render_backward" in k else None)
         if key is None or row["Counter_Name"] != c: continue
         agg[key] += float(row["Counter_Value"]); cnt[key] += 1
     for k in agg:
