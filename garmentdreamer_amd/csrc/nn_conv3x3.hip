@@ -1152,14 +1152,17 @@ static int launch_patch(void* stream, const void* x, const float* mean_rstd, con
                         int groups, int apply_silu, const void* weight, const void* bias, int bias_img_stride,
                         const void* residual, void* y, int N, int H, int W, int Cin, int Cout);
 
-// Plain stride-1 convolutions whose Cout is not a multiple of 256 (128-channel slabs) run 1.1-1.4x faster on the
-// patch-staged kernel with an LDS-DMA patch once its (image, 16x16 patch, slab) grid fills the chip
-// (tools/patch_conv_bench.py); Cout % 256 == 0 shapes tie with the 256x256 implicit-GEMM tile and stay there.
+// Plain stride-1 convolutions run on the persistent patch-staged kernel (LDS-DMA patch) once its (image, 16x16
+// patch, 128- or 256-channel slab) grid has >= 256 workgroups: 1.08-1.24x faster than the implicit-GEMM tiles on
+// every such shape of the workload, Cout % 256 == 0 included (tools/patch_conv_bench.py: 256->256@256^2 622 -> 537 us,
+// 512->512@128^2 534 -> 487 us, 1280->1280@32^2 549 -> 510 us); below that (16^2 maps, one view per GPU) the
+// implicit-GEMM kernel's finer tiles and split-K win by 1.3-3x.
 static bool prefer_patch(int N, int H, int W, int Cout)
 {
     if (g_force_variant >= 0 || g_force_split >= 0) return g_force_variant == 3;
-    if (Cout % 256 == 0 || Cout < 64 || H < 16 || W < 16) return false;
-    const int64_t wgs = (int64_t)N * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + 127) / 128);
+    if (Cout < 64 || H < 16 || W < 16) return false;
+    const int bn = Cout % 256 == 0 ? 256 : 128;
+    const int64_t wgs = (int64_t)N * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
     return wgs >= 256;
 }
 

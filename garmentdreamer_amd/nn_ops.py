@@ -412,13 +412,13 @@ def gn_conv3x3(x, norm_weight, norm_bias, groups: int, eps: float, silu: bool, w
 
 
 def gn_conv_prefers_fused(x, out_channels: int) -> bool:
-    """Large feature maps (the VAE encoder's 512^2 .. 128^2 levels) run GroupNorm + SiLU inside the patch-staged
-    convolution's activation loader (1.05-1.26x faster than GroupNorm kernel + convolution on MI355X,
-    tools/gn_conv_bench.py); on 64^2 and smaller maps, or below ~1.5 waves of workgroups (one per image, 16x16
-    patch, 128/256-channel slab), the GroupNorm kernel + plain convolution is faster."""
+    """The largest feature maps (the VAE encoder's 512^2 and 256^2 levels) run GroupNorm + SiLU inside the
+    patch-staged convolution's activation loader (1.07-1.17x faster than GroupNorm kernel + convolution on MI355X,
+    tools/gn_conv_bench.py); on 128^2 and smaller maps, or below ~1.5 waves of workgroups (one per image, 16x16
+    patch, 128/256-channel slab), the GroupNorm kernel + the persistent plain convolution is faster (0.95x)."""
     bn = 256 if out_channels % 256 == 0 else 128
     wgs = x.shape[0] * -(-x.shape[2] // 16) * -(-x.shape[3] // 16) * -(-out_channels // bn)
-    return x.shape[2] * x.shape[3] >= 128 * 128 and wgs >= 384
+    return x.shape[2] * x.shape[3] >= 256 * 256 and wgs >= 384
 
 
 def _gn_bwd_launch(x, dy, gw, gb, mr, groups, silu, add=None):

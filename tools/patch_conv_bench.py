@@ -8,7 +8,8 @@ from garmentdreamer_amd import nn_ops
 
 SH = [(8, 128, 128, 512), (8, 128, 256, 256), (8, 256, 128, 256), (8, 256, 256, 256), (8, 256, 512, 128), (8, 512, 256, 128),
       (8, 512, 512, 128), (8, 512, 512, 64), (16, 320, 320, 64), (16, 640, 320, 64), (16, 960, 320, 64), (16, 640, 640, 64),
-      (16, 640, 640, 32), (16, 1280, 1280, 32), (1, 128, 128, 512), (1, 256, 256, 256)]
+      (16, 640, 640, 32), (16, 1280, 1280, 32), (16, 1280, 1280, 16), (16, 2560, 1280, 16), (16, 1920, 1280, 32), (16, 640, 1280, 16), (1, 128, 128, 512), (1, 256, 256, 256),
+      (1, 512, 512, 128), (2, 1280, 1280, 32)]
 
 
 def timeit(fn, n=10):
