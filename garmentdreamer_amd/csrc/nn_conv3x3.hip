@@ -1095,6 +1095,7 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
         const int64_t t256 = ((M + 255) / 256) * ((Cout + 255) / 256);
         const int64_t t128x256 = ((M + 255) / 256) * ((Cout + 127) / 128);
         if (Cout % 256 == 0 && t256 >= 192) variant = 2;
+        else if (Cout <= 32 && M >= (1 << 18)) variant = 4;   // few output channels (first conv's dgrad, Cout = 4)
         else if (t128x256 >= 512 && (Cin >= 512 || M >= (1 << 20))) variant = 1;
         else variant = 0;
     }
@@ -1120,6 +1121,7 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
                            (const uint16_t*)residual, (uint16_t*)y, N, g, Cin, Cout, tiles_n, nwg, partial, tps);  \
     } while (0)
     if (variant == 2) GD_LAUNCH(256, 256, 2, 4);
+    else if (variant == 4) GD_LAUNCH(32, 256, 1, 4);   // 32 channels x 256 pixels, 4 waves: 1/4 of the padded MFMA work
     else if (variant == 1) GD_LAUNCH(128, 256, 2, 4);
     else GD_LAUNCH(128, 128, 2, 2);
 #undef GD_LAUNCH

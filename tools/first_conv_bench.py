@@ -13,3 +13,14 @@ def timeit(fn, n=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 with torch.no_grad():
     print("own", timeit(lambda: nn_ops.conv3x3_small_cin(x, w, b)) * 1e6, "us; torch", timeit(lambda: F.conv2d(x, w, b, padding=1)) * 1e6, "us")
+# input gradient of the first conv: MFMA kernel on the flipped weights padded to 4 output channels
+xg = x.clone().requires_grad_(True)
+y = nn_ops.conv3x3_small_cin(xg, w, b)
+gy = torch.randn_like(y)
+def bwd():
+    xg.grad = None
+    y.backward(gy, retain_graph=True)
+print("dgrad (incl. autograd overhead)", timeit(bwd) * 1e6, "us")
+ref = torch.nn.grad.conv2d_input(x.shape, w.float(), gy.float(), padding=1)
+bwd()
+print("dgrad max err vs fp32", (xg.grad.float() - ref).abs().max().item(), "scale", ref.abs().max().item())
