@@ -791,7 +791,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
         // the GroupNorm variants keep one tile per workgroup: with the register-staged transform the cross-tile
         // prefetch costs more registers (spills in the 256-channel variant) than the hidden prologue returns
         const bool has_next = !GN && vnext < nwg;
-        const Tile nxt = GN ? cur : decode(has_next ? vnext : vb);
+        const Tile nxt = decode(has_next ? vnext : vb);
         for (int c = 0; c < kc; c++, ga++) {
             const char* pa = sA + (ga & 1) * kAStage;
             const bool last_chunk = c + 1 == kc;
