@@ -448,6 +448,11 @@ __global__ __launch_bounds__(kGaussBlock) void preprocess_backward_kernel(
         dmean[0] += e0; dmean[1] += e1; dmean[2] += e2;
         if (shs) {
             float sm[3];
+            if (sh_first) {
+                // bands above the active degree receive no gradient: exact zeros, as the reference's
+                // torch::zeros output has (rasterize_points.cu:160); the output buffer is NOT pre-zeroed
+                for (int i = 3 * (D + 1) * (D + 1); i < 3 * M; i++) dL_dsh[(size_t)g * M * 3 + i] = 0.f;
+            }
             sh_backward(g, vp, D, M, means3D, campos + 3 * v, shs, clamped, dcol, sm, dL_dsh + (size_t)g * M * 3,
                         sh_first);
             sh_first = false;

@@ -116,6 +116,9 @@ class GradBucket:
         dev = tensors[0].device
         self.flat = torch.zeros(sum(self.numels), dtype=torch.float32, device=dev)
 
+    def matches(self, tensors: Sequence[torch.Tensor]) -> bool:
+        return [t.numel() for t in tensors] == self.numels and tensors[0].device == self.flat.device
+
     def all_reduce_mean_(self, tensors: Sequence[torch.Tensor]) -> None:
         ws = world_size()
         if ws == 1:
@@ -125,6 +128,15 @@ class GradBucket:
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / ws)
         torch._foreach_copy_([t.reshape(-1) for t in tensors], list(views))
+
+
+def all_reduce_mean_(flat: torch.Tensor) -> torch.Tensor:
+    """In-place all-reduce(sum) x 1/N of an already flat, contiguous buffer (``GaussianModel.grad_bucket``)."""
+    ws = world_size()
+    if ws > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / ws)
+    return flat
 
 
 def all_reduce_max_(t: torch.Tensor) -> torch.Tensor:

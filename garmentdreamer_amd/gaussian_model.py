@@ -76,16 +76,22 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
 
 
 class OptimizationParams:
-    """Defaults of arguments/__init__.py:73-90 (the keys training_setup / densification read)."""
-    position_lr_init = 0.00016
-    position_lr_final = 0.0000016
-    position_lr_delay_mult = 0.01
+    """Defaults of this fork's arguments/__init__.py:70-90 (they differ from vanilla 3DGS: slower xyz, 5x faster
+    features, 5x slower opacity); pinned by tests/golden/scene_helpers (``optimization_params``)."""
+    position_lr_init = 0.00005
+    position_lr_final = 0.000025
+    position_lr_delay_mult = 0.5
     position_lr_max_steps = 30_000
-    feature_lr = 0.0025
-    opacity_lr = 0.05
+    feature_lr = 0.0125
+    opacity_lr = 0.01
     scaling_lr = 0.005
     rotation_lr = 0.001
     percent_dense = 0.01
+    densification_interval = 100
+    opacity_reset_interval = 3000
+    densify_from_iter = 500
+    densify_until_iter = 15_000
+    densify_grad_threshold = 0.0002
 
 
 class _ActivateScene(torch.autograd.Function):
@@ -184,7 +190,11 @@ class GaussianModel(GaussianParams):
         dev = self.device
         flat = torch.cat([tensors[n].reshape(-1).to(dev, torch.float32) for n in GROUPS])
         self._flat = flat
-        self._grad = torch.zeros_like(flat)
+        # [parameter gradients | viewspace gradient summed over views (3 P)]: ONE buffer, so the view-sharded
+        # all-reduce (dist.all_reduce_mean_) sends it in place -- no staging copy
+        self._bucket = torch.zeros(flat.numel() + 3 * P, dtype=torch.float32, device=dev)
+        self._grad = self._bucket[:flat.numel()]
+        self.viewspace_grad = self._bucket[flat.numel():].view(P, 3)
         self._exp_avg = torch.zeros_like(flat) if exp_avg is None else torch.cat([exp_avg[n].reshape(-1) for n in GROUPS])
         self._exp_avg_sq = torch.zeros_like(flat) if exp_avg_sq is None else \
             torch.cat([exp_avg_sq[n].reshape(-1) for n in GROUPS])
@@ -252,6 +262,16 @@ class GaussianModel(GaussianParams):
 
     def zero_grad(self):
         self._grad.zero_()
+
+    @property
+    def grad_bucket(self) -> torch.Tensor:
+        """[flat parameter gradient | ``viewspace_grad``] as one contiguous fp32 tensor."""
+        return self._bucket
+
+    def oneupSHdegree(self):
+        """gaussian_model.py:120-122."""
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
 
     def activated(self):
         """(shs [P,M,3], opacity [P,1], scales [P,3], rotations [P,4]) -- the activated accessors in one launch

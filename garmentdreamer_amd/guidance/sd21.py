@@ -190,7 +190,8 @@ class Attention(nn.Module):
         elif _FUSED_QKV and context is None and self.lora is None and x.is_cuda and self.to_q.bias is None and \
                 not self.to_q.weight.requires_grad and not torch.is_grad_enabled():
             # frozen self-attention: ONE [C, 3C] projection; the attention kernel reads the three strided views
-            src = (self.to_q.weight.data_ptr(), self.to_q.weight._version, x.dtype)
+            src = (self.to_q.weight.data_ptr(), self.to_q.weight._version, self.to_k.weight._version,
+                   self.to_v.weight._version, x.dtype)
             if getattr(self, "_wqkv_src", None) != src:
                 self._wqkv = torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], dim=0).detach().contiguous()
                 self._wqkv_src = src
@@ -442,7 +443,7 @@ class UNet2DConditionModel(nn.Module):
         if not atts or any(a.to_k.weight.requires_grad or a.to_k.bias is not None or a.lora is not None for a in atts):
             return ctx
         first = atts[0].to_k.weight
-        key = (first.data_ptr(), first._version, ctx.dtype, len(atts))
+        key = (first.data_ptr(), ctx.dtype, len(atts)) + tuple(t._version for a in atts for t in (a.to_k.weight, a.to_v.weight))
         cache = getattr(self, "_ctx_cat", None)
         if cache is None or cache[0] != key:
             with torch.no_grad():
@@ -466,7 +467,8 @@ class UNet2DConditionModel(nn.Module):
         if not blocks or any(b.time_emb_proj.weight.requires_grad or b.conv1.bias.requires_grad for b in blocks):
             return temb
         first = blocks[0].time_emb_proj.weight
-        key = (first.data_ptr(), first._version, blocks[0].conv1.bias._version, temb.dtype, len(blocks))
+        key = (first.data_ptr(), temb.dtype, len(blocks)) + tuple(
+            t._version for b in blocks for t in (b.time_emb_proj.weight, b.time_emb_proj.bias, b.conv1.bias))
         cache = getattr(self, "_temb_cat", None)
         if cache is None or cache[0] != key:
             with torch.no_grad():

@@ -80,7 +80,7 @@ class GaussianParams(nn.Module):
     def get_opacity(self):
         return torch.sigmoid(self._opacity)
 
-    def param_groups(self, lr_xyz=0.00016, lr_f_dc=0.0025, lr_f_rest=0.0025 / 20.0, lr_opacity=0.05,
+    def param_groups(self, lr_xyz=0.00005, lr_f_dc=0.0125, lr_f_rest=0.0125 / 20.0, lr_opacity=0.01,
                      lr_scaling=0.005, lr_rotation=0.001):
         """The six Adam groups of ``training_setup`` (gaussian_model.py:156-165; default rates from
         Garment_3DGS/gaussiansplatting/arguments/__init__.py:73-80)."""

@@ -12,9 +12,11 @@ on_before_optimizer_step`` (Garment_3DGS/threestudio/systems/GaussianDreamer.py:
 
 Differences, all MI355X-side: the V views go through ONE batched rasterizer launch set
 (``render_batch``) instead of a Python loop of V launch sets + V host syncs; with N ranks each
-rank renders V/N views and ONE flat all-reduce carries every gradient (``dist.GradBucket``).
-Lightning, OmegaConf, the prompt processor's CLIP encoder, densify/prune and PLY export are out
-of scope.
+rank renders V/N views and ONE flat all-reduce carries every gradient (the scene's own
+``grad_bucket``, reduced in place).  The densify / prune schedule of ``on_before_optimizer_step``
+(:279-283: every 100 steps in (300, 900), screen-size pruning after step 500) runs with a seeded
+generator so that replicas stay identical.  Lightning, OmegaConf and the prompt processor's CLIP
+encoder are out of scope.
 """
 from __future__ import annotations
 
@@ -29,7 +31,8 @@ from .cameras import Camera, CameraBatch
 class SDSLoop:
     def __init__(self, gaussians, guidance, prompt_utils, bg_color: torch.Tensor,
                  render_batch_fn: Optional[Callable] = None, lambda_sds: float = 1.0, lambda_sparsity: float = 1.0,
-                 lr_scale: float = 1.0, fused_adam: Optional[bool] = None):
+                 lr_scale: float = 1.0, fused_adam: Optional[bool] = None, densify: bool = True,
+                 cameras_extent: float = 4.0, densify_seed: int = 0):
         self.gaussians = gaussians
         self.guidance = guidance
         self.prompt_utils = prompt_utils
@@ -58,6 +61,16 @@ class SDSLoop:
             self.max_radii2D = torch.zeros((P,), device=dev)
         self.global_step = 0
         self._bucket = None
+        # densify_and_prune(0.0002, 0.05, cameras_extent, size_threshold), GaussianDreamer.py:279-283,426
+        self.densify = densify and self.native_scene
+        self.cameras_extent = cameras_extent
+        self._densify_gen = torch.Generator(device=dev).manual_seed(densify_seed) if self.densify else None
+        if not self.native_scene:
+            from .gaussian_model import OptimizationParams as a, get_expon_lr_func
+            self._xyz_lr = get_expon_lr_func(lr_init=a.position_lr_init * lr_scale,
+                                             lr_final=a.position_lr_final * lr_scale,
+                                             lr_delay_mult=a.position_lr_delay_mult,
+                                             max_steps=a.position_lr_max_steps)
 
     # -- forward (GaussianDreamer.forward, :180-219) --------------------------------------------
     def render_views(self, batch: Dict):
@@ -77,6 +90,13 @@ class SDSLoop:
         """``batch``: this rank's shard of the camera batch (keys as uncond.py:395-408)."""
         if hasattr(self.guidance, "update_step"):  # Updateable hook, systems/base.py:148-152
             self.guidance.update_step(0, self.global_step)
+        # gaussian.update_learning_rate(true_global_step): exponential xyz schedule, GaussianDreamer.py:231,236
+        if self.native_scene:
+            self.gaussians.update_learning_rate(self.global_step)
+        else:
+            for g in self.optimizer.param_groups:
+                if g.get("name") == "xyz":
+                    g["lr"] = self._xyz_lr(self.global_step)
         if self.global_step > 500:  # GaussianDreamer.py:233-234
             self.guidance.set_min_max_steps(min_step_percent=0.02, max_step_percent=0.55)
         out = self.render_views(batch)
@@ -92,33 +112,48 @@ class SDSLoop:
             self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
 
+        densified = False
         with torch.no_grad():
-            vs_grad = out["viewspace_points"].grad.sum(0)  # sum over this rank's views
             radii = out["radii"].max(dim=0).values
             if self.native_scene:
-                grads = [self.gaussians.flat_grad]   # every parameter's .grad is a view into this buffer
+                # every parameter's .grad is a view into the scene's bucket; the view-summed viewspace gradient
+                # lands in its tail, so ONE in-place all-reduce carries everything (no staging copies)
+                vs_grad = self.gaussians.viewspace_grad
+                torch.sum(out["viewspace_points"].grad, dim=0, out=vs_grad)
+                if gdist.world_size() > 1:
+                    gdist.all_reduce_mean_(self.gaussians.grad_bucket)
+                    gdist.all_reduce_max_(radii)
+                if self.global_step < 900:
+                    self.gaussians.add_densification_stats(vs_grad, radii)
+                    if self.densify and self.global_step > 300 and self.global_step % 100 == 0:
+                        size_threshold = 20 if self.global_step > 500 else None
+                        self.gaussians.densify_and_prune(0.0002, 0.05, self.cameras_extent, size_threshold,
+                                                         generator=self._densify_gen)
+                        densified = True
             else:
+                vs_grad = out["viewspace_points"].grad.sum(0)  # sum over this rank's views
                 grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
                 for p, g in zip(self.params, grads):
                     p.grad = g
-            if gdist.world_size() > 1:
-                tensors = grads + [vs_grad]
-                if self._bucket is None:
-                    self._bucket = gdist.GradBucket(tensors)
-                self._bucket.all_reduce_mean_(tensors)
-                gdist.all_reduce_max_(radii)
-            if self.native_scene:
-                if self.global_step < 900:
-                    self.gaussians.add_densification_stats(vs_grad, radii)
-            else:
+                if gdist.world_size() > 1:
+                    tensors = grads + [vs_grad]
+                    if self._bucket is None or not self._bucket.matches(tensors):
+                        self._bucket = gdist.GradBucket(tensors)
+                    self._bucket.all_reduce_mean_(tensors)
+                    gdist.all_reduce_max_(radii)
                 self._densification_stats(vs_grad, radii)
         if self.native_scene:
-            self.gaussians.step()
+            # after densify_and_prune the gradient buffer is fresh (zeros) and the Adam moments of the surviving
+            # points were carried over: the optimizer step that follows is the reference's (Lightning calls
+            # optimizer.step() right after on_before_optimizer_step; the re-created parameters have no .grad, so
+            # Adam skips them, gaussian_model.py:296-340) -- a no-op
+            if not densified:
+                self.gaussians.step()
         else:
             self.optimizer.step()
         self.global_step += 1
         return {"loss": loss.detach(), "loss_sds": loss_sds.detach(), "loss_sparsity": loss_sparsity.detach(),
-                "grad_norm": g_out["grad_norm"], "num_visible": (radii > 0).sum()}
+                "grad_norm": g_out["grad_norm"], "num_visible": (radii > 0).sum(), "densified": densified}
 
     def _densification_stats(self, viewspace_grad, radii):
         """on_before_optimizer_step (:268-279) + add_densification_stats (gaussian_model.py:415-419)."""

@@ -1,0 +1,258 @@
+"""GPU tests at the shapes BASELINE.json's configs name (round-1 verdict: configs[2], [3] and [4] had no test).
+
+configs[2]  100 000 Gaussians x 4 views @512^2 with the full-size SD-2.1 UNet/VAE: one graphed step vs the eager
+            step (loss, parameter gradients, per-view viewspace gradients), and the rasterizer gradients of one of
+            its views against the CPU oracle given the step's own dL/dimage.
+configs[3]  the view-sharded loop on the REAL HIP rasterizer: 2 ranks (gloo, sharing this one GPU) x 2 views ==
+            1 rank x 4 views; replicas stay bit-identical through a densify/prune event.  (RCCL itself needs two
+            GPUs; the driver's multi-GPU bench runs it.)
+configs[4]  the NeTF VSD iteration at full size (SD-2.1 UNet + LoRA UNet + VAE, 512^2), and the same step at reduced
+            width against eager fp32 PyTorch.
+"""
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import helpers as h
+from tests import parity_report
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cos(a, b):
+    return F.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+
+
+def _one_gradient_step(loop, batch, noise, t, vae_noise):
+    """render -> guidance -> loss -> backward (no Adam): what SDSLoop.step does up to the optimizer."""
+    gm = loop.gaussians
+    out = loop.render_views(batch)
+    for k in ("render", "depth_3dgs", "alpha"):
+        out[k].retain_grad()
+    g_out = loop.guidance(out["comp_rgb"], loop.prompt_utils, batch["elevation"], batch["azimuth"],
+                          batch["camera_distances"], rgb_as_latents=False, guidance_eval=False, noise=noise,
+                          timesteps=t, vae_noise=vae_noise)
+    loss = g_out["loss_sds"] + (out["opacity"] ** 2 + 0.01).sqrt().mean()
+    gm.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    return {"loss_sds": g_out["loss_sds"].detach().clone(), "flat_grad": gm.flat_grad.detach().clone(),
+            "viewspace": out["viewspace_points"].grad.detach().clone(), "radii": out["radii"].clone(),
+            "d_render": out["render"].grad.detach().clone(), "d_depth": out["depth_3dgs"].grad.detach().clone(),
+            "d_alpha": None if out["alpha"].grad is None else out["alpha"].grad.detach().clone()}
+
+
+def test_config2_100k_gaussians_4_views_full_nets_graph_vs_eager_and_oracle():
+    import argparse
+    import bench
+    from garmentdreamer_amd.cameras import Camera, CameraBatch
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    from garmentdreamer_amd.gaussian_model import GaussianModel
+    from garmentdreamer_amd.guidance.stable_diffusion_guidance import PromptEmbeddings, StableDiffusionGuidance
+    from garmentdreamer_amd.scene import synthetic_gaussians
+    from garmentdreamer_amd.sds_loop import SDSLoop
+    from oracle import gd_oracle
+    dev = torch.device(DEV)
+    V, P, HW = 4, 100000, 512
+    args = argparse.Namespace(views=V, gaussians=P, res=HW)
+    gm = GaussianModel.from_activated(synthetic_gaussians(P, seed=0), device=dev)
+    cfg = {"guidance_scale": 100.0, "grad_clip": [0, 1.5, 2.0, 1000]}
+    g_graph = StableDiffusionGuidance({**cfg, "use_hip_graphs": True}, device=dev)
+    g_eager = StableDiffusionGuidance({**cfg, "use_hip_graphs": False}, device=dev, unet=g_graph.unet, vae=g_graph.vae)
+    prompt, bg = PromptEmbeddings.random(dev), torch.ones(3, device=dev)
+    batch = bench.camera_batch(args, 0, list(range(V)))
+    gen = torch.Generator(device=dev).manual_seed(5)
+    noise = torch.randn(V, 4, 64, 64, device=dev, generator=gen)
+    vn = torch.randn(V, 4, 64, 64, device=dev, generator=gen)
+    t = torch.randint(20, 981, (V,), device=dev, generator=gen)
+    res = {}
+    for name, guid in (("eager", g_eager), ("graph", g_graph)):
+        loop = SDSLoop(gm, guid, prompt, bg)
+        guid.update_step(0, 0)
+        for _ in range(2 if name == "graph" else 1):    # the second graphed call is a pure replay
+            res[name] = _one_gradient_step(loop, batch, noise, t, vn)
+    assert g_graph.cfg.use_hip_graphs, "hipGraph replay was switched off (capture failed or runtime flag missing)"
+    e, g = res["eager"], res["graph"]
+    # same kernels, same inputs: what differs is the order of the fp32 atomics in the rasterizer backward and of
+    # the fp64 GroupNorm partial sums, amplified by guidance_scale = 100 on bf16 noise predictions
+    d_loss = abs(float(e["loss_sds"]) - float(g["loss_sds"])) / abs(float(e["loss_sds"]))
+    cos_flat, cos_vs = _cos(e["flat_grad"], g["flat_grad"]), _cos(e["viewspace"], g["viewspace"])
+    cos_img = _cos(e["d_render"], g["d_render"])
+    parity_report.record("configs[2] graph vs eager, 100k x 4 views, full SD-2.1", "step",
+                         rel_dloss=d_loss, cos_flat_grad=cos_flat, cos_viewspace=cos_vs, cos_dL_dimage=cos_img)
+    assert torch.equal(e["radii"], g["radii"])
+    assert d_loss < 1e-3, d_loss
+    assert cos_img > 0.9999 and cos_flat > 0.9999 and cos_vs > 0.9999, (cos_img, cos_flat, cos_vs)
+    assert torch.isfinite(g["flat_grad"]).all() and float(g["flat_grad"].abs().max()) > 0
+
+    # ---- rasterizer gradients of view 0 inside this step vs the CPU oracle, given the step's own dL/dimage ----
+    cams = [Camera(batch["c2w_3dgs"][i], batch["fovy"][i], HW, HW, data_device="cpu") for i in range(V)]
+    cb = CameraBatch(cams, dev)
+    with torch.no_grad():
+        shs, opac, scales, rots = gm.activated()
+    n = lambda x: x.detach().cpu().numpy()
+    inp = dict(bg=n(bg), means3D=n(gm.get_xyz), colors_precomp=None, opacities=n(opac), scales=n(scales),
+               rotations=n(rots), scale_modifier=1.0, cov3D_precomp=None, viewmatrix=n(cb.viewmatrix[0]),
+               projmatrix=n(cb.projmatrix[0]), tanfovx=float(cb.tanfovx[0]), tanfovy=float(cb.tanfovy[0]),
+               image_height=HW, image_width=HW, sh=n(shs), degree=0, campos=n(cb.campos[0]))
+    st = h.oracle_forward(inp)
+    gc, gd = n(g["d_render"][0]), n(g["d_depth"][0])
+    ga = np.zeros((1, HW, HW), np.float32) if g["d_alpha"] is None else n(g["d_alpha"][0])
+    ref = gd_oracle.backward(st, gc, gd, ga)
+    a = h.to_torch(inp, DEV)
+    out = _C.rasterize_gaussians(*a)
+    R, color, depth, alpha, radii, geom, binning, img = out
+    assert R == st.num_rendered and torch.equal(radii, g["radii"][0])
+    tt = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=DEV)
+    (bg_, means3D, colors, op_, sc_, ro_, smod, cov, vm, pm, tx, ty, H, W, sh_, degree, campos, _, _) = a
+    grads = _C.rasterize_gaussians_backward(bg_, means3D, radii, colors, sc_, ro_, smod, cov, vm, pm, tx, ty, tt(gc),
+                                            tt(gd), tt(ga), sh_, degree, campos, geom, R, binning, img, alpha, False)
+    torch.cuda.synchronize()
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations")
+    from tests.test_raster_gpu import _check_grads
+    for nm, gr in zip(names, grads):
+        _check_grads(nm, gr, ref[nm], rtol=5e-3, atol_scale=5e-4,
+                     case="configs[2] view 0 of the step vs oracle (GPU alpha, SDS dL/dimage)")
+    # ... and the gradient the LOOP saw for that view (batched launch) is the single-view one
+    vs0 = g["viewspace"][0]
+    s = float(grads[0].abs().max())
+    assert float((vs0 - grads[0]).abs().max()) <= 2e-4 * s
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_workers(world, out_dir, extra_env=None, timeout=900):
+    port = _free_port()
+    procs = []
+    for rk in range(world):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"),
+                                       os.path.join(out_dir, f"w{world}_r{rk}.pt")], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-4000:]
+    return [torch.load(os.path.join(out_dir, f"w{world}_r{rk}.pt"), map_location="cpu") for rk in range(world)]
+
+
+def test_config3_two_ranks_share_one_gpu_real_rasterizer_matches_single_rank(tmp_path):
+    """2 ranks x 2 views == 1 rank x 4 views through the HIP rasterizer, the guidance and the HIP Adam, with the
+    flat in-place all-reduce (GaussianDreamer.py:189-191,268-279 is the coupling being reproduced); steps 399-402
+    cross the densify_and_prune event at step 400 (:279-283) with the seeded generator."""
+    single = _run_workers(1, str(tmp_path))[0]
+    r0, r1 = _run_workers(2, str(tmp_path))
+    # replicas: bit-identical state on both ranks after every step, densification included
+    for k in ("flat", "exp_avg", "exp_avg_sq", "max_radii2D", "xyz_gradient_accum", "denom"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert r0["P"] == r1["P"] and r0["P_history"] == r1["P_history"]
+    assert r0["P_history"][0] != r0["P_history"][-1], "densify_and_prune did not change P"
+    assert any(r0["densified"])
+    # sharded == single rank, before the densify event (after it a borderline threshold may legitimately flip)
+    for s in range(len(single["grads"])):
+        a, b = single["grads"][s], r0["grads"][s]
+        assert a.shape == b.shape
+        cos = _cos(a, b)
+        rel = float((a - b).abs().max() / a.abs().max())
+        parity_report.record("configs[3] 2 ranks x 2 views vs 1 rank x 4 views (gloo, one GPU)", f"step {s} grad bucket",
+                             cos=cos, max_err_over_scale=rel)
+        assert cos > 0.9995, (s, cos)
+        assert torch.equal(single["radii"][s], r0["radii"][s])
+    assert abs(single["P_history"][-1] - r0["P_history"][-1]) <= 0.02 * single["P_history"][-1]
+    assert float((single["flat_before_densify"] - r0["flat_before_densify"]).abs().max()) < 1e-3
+
+
+def _vsd_objects(kw_unet, kw_vae, dtype):
+    from garmentdreamer_amd.guidance import sd21
+    from garmentdreamer_amd.guidance.sd_vsd import LoraUnet, StableDiffusionVSD
+    with torch.device(DEV):
+        unet = sd21.init_random_(sd21.UNet2DConditionModel(**kw_unet))
+        vae = sd21.init_random_(sd21.AutoencoderKLEncoder(**kw_vae), 1)
+        lora = sd21.init_random_(sd21.LoraUNet2DConditionModel(**kw_unet), 2)
+    gd = StableDiffusionVSD(DEV, fp16=dtype == torch.bfloat16, unet=unet, vae=vae)
+    lora = lora.to(dtype).to(memory_format=torch.channels_last)
+    train = lora.freeze_base()
+    return gd, lora, train, LoraUnet(lora)
+
+
+def _vsd_step(gd, q, train, seed):
+    g = torch.Generator(DEV).manual_seed(seed)
+    gd.set_text_embeds(torch.randn(1, 77, 1024, device=DEV, generator=g), torch.randn(1, 77, 1024, device=DEV, generator=g))
+    img = torch.rand(1, 3, 512, 512, device=DEV, generator=g).requires_grad_(True)
+    pose = torch.randn(1, 16, device=DEV, generator=g)
+    noise = torch.randn(1, 4, 64, 64, device=DEV, generator=g)
+    vn = torch.randn(1, 4, 64, 64, device=DEV, generator=g)
+    t = torch.tensor([317], device=DEV)
+    loss, pseudo, latents = gd.train_step(img, guidance_scale=7.5, q_unet=q, pose=pose, shading="albedo", noise=noise,
+                                          timesteps=t, vae_noise=vn)
+    loss.backward()
+    n2 = torch.randn(1, 4, 64, 64, device=DEV, generator=g)
+    lu = gd.lora_train_loss(q, latents, pose, shading="albedo", unet_bs=1, timesteps=torch.tensor([611], device=DEV),
+                            noise=n2, drop_pose=False)
+    for p in train:
+        p.grad = None
+    lu.backward()
+    torch.cuda.synchronize()
+    return img.grad.detach().float(), latents.detach().float(), float(lu), \
+        {i: p.grad.detach().float().clone() for i, p in enumerate(train) if p.grad is not None}
+
+
+def test_config4_vsd_iteration_full_size():
+    """BASELINE configs[4] at its stated shape: the NeTF VSD iteration (trainer.py:158-262) with the full-size SD-2.1
+    UNet, the full-size LoRA UNet (rank-4 adapters, camera + shading embeddings) and the VAE encoder on a 512^2 render,
+    through the HIP kernels in bf16: the image gradient and every trainable gradient finite and non-zero."""
+    gd, lora, train, q = _vsd_objects({}, {}, torch.bfloat16)
+    assert sum(p.numel() for p in gd.unet.parameters()) == 865910724
+    dimg, lat, lu, grads = _vsd_step(gd, q, train, seed=3)
+    assert torch.isfinite(dimg).all() and float(dimg.abs().sum()) > 0
+    assert math.isfinite(lu) and lu > 0
+    assert len(grads) > 0.9 * len(train)
+    assert all(torch.isfinite(v).all() for v in grads.values())
+    names = [n for n, p in lora.named_parameters() if p.requires_grad]
+    assert any("lora" in n for n in names) and any(n.startswith("camera_emb") for n in names)
+    assert sum(float(v.abs().sum()) > 0 for v in grads.values()) > 0.5 * len(grads)
+
+
+def test_config4_vsd_step_reduced_width_matches_eager_fp32():
+    """The same iteration at reduced width: bf16 through the HIP kernels vs the fp32 PyTorch ops on identical weights
+    (the reference runs fp32, sd_vsd_utils.py:35).  Latents, the image gradient and the LoRA loss agree to bf16 level."""
+    kw_u = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4))
+    kw_v = dict(block_out_channels=(64, 64, 128, 128))
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        gd, lora, train, q = _vsd_objects(kw_u, kw_v, dt)
+        out[dt] = _vsd_step(gd, q, train, seed=9)
+    (di32, lat32, lu32, g32), (di16, lat16, lu16, g16) = out[torch.float32], out[torch.bfloat16]
+    c_lat, c_img = _cos(lat32, lat16), _cos(di32, di16)
+    c_lora = min(_cos(g32[i], g16[i]) for i in g32 if float(g32[i].abs().max()) > 0)
+    parity_report.record("configs[4] VSD step, reduced width: bf16 HIP vs fp32 eager", "step", cos_latents=c_lat,
+                         cos_dL_dimage=c_img, rel_dlora_loss=abs(lu32 - lu16) / abs(lu32), min_cos_lora_grads=c_lora)
+    assert c_lat > 0.999 and c_img > 0.98, (c_lat, c_img)
+    assert abs(lu32 - lu16) <= 2e-2 * abs(lu32)
+    assert c_lora > 0.9, c_lora

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from tests import helpers as h
+from tests import parity_report
 
 pytestmark = pytest.mark.gpu
 
@@ -53,20 +54,29 @@ def _check_forward(inp, st, out, exact_ncontrib=True):
     if exact_ncontrib:
         assert mism <= max(1, int(1e-4 * nc.size)), f"n_contrib mismatches: {mism}"
     ok = nc == st.n_contrib
+    case = f"forward P={P} {W}x{H}"
+    parity_report.record(case, "n_contrib", max_mismatches=mism, pixels=nc.size)
     for name, g, o in (("color", color, st.color), ("depth", depth, st.depth), ("alpha", alpha, st.alpha)):
         g = g.cpu().numpy()
         err = np.abs(g - o)
         tol = 1e-5 + 1e-4 * np.abs(o)
         bad = (err > tol) & ok[None]
+        parity_report.record(case, name, max_abs_err=(err * ok[None]).max(), max_err_over_tol=(err / tol * ok[None]).max())
         assert not bad.any(), f"{name}: {bad.sum()} pixels beyond tolerance, max err {err.max()}"
     return sc
 
 
-def _check_grads(name, g, o, rtol=1e-3, atol_scale=2e-5):
+def _check_grads(name, g, o, rtol=1e-3, atol_scale=2e-5, case=None):
     g = g.detach().cpu().numpy().reshape(o.shape)
     scale = np.abs(o).max() + 1e-20
     err = np.abs(g - o)
     tol = rtol * np.abs(o) + atol_scale * scale
+    if case is not None:
+        # max |err| / max|ref|, and the worst relative error among the entries that carry >= 1e-3 of the scale
+        big = np.abs(o) >= 1e-3 * scale
+        parity_report.record(case, name, max_err_over_scale=err.max() / scale,
+                             max_rel_err_significant=(err[big] / np.abs(o[big])).max() if big.any() else 0.0,
+                             max_err_over_tol=(err / tol).max())
     assert (err <= tol).all(), f"{name}: max err {err.max():.3e} at scale {scale:.3e}, {(err > tol).sum()} bad"
 
 
@@ -114,7 +124,7 @@ def test_backward_parity(P, HW, deg):
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
              "dL_drotations")
     for n, g in zip(names, grads):
-        _check_grads(n, g, ref[n])
+        _check_grads(n, g, ref[n], case=f"backward P={P} {HW}^2 SH{deg} (GPU alpha)")
 
 
 def _needle_inputs(P, HW, seed):
@@ -322,13 +332,15 @@ def _check_backward_dense(st, args, out, seed):
     (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, _, _) = args
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
              "dL_drotations")
-    for alpha_img, rtol, atol in ((t(st.alpha).reshape(alpha.shape), 1e-3, 2e-5), (alpha, 5e-3, 5e-4)):
+    P_ = means3D.shape[0]
+    for label, alpha_img, rtol, atol in (("oracle alpha", t(st.alpha).reshape(alpha.shape), 1e-3, 2e-5),
+                                         ("GPU alpha", alpha, 5e-3, 5e-4)):
         grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
                                                 t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img,
                                                 alpha_img, False)
         torch.cuda.synchronize()
         for n, g in zip(names, grads):
-            _check_grads(n, g, ref[n], rtol=rtol, atol_scale=atol)
+            _check_grads(n, g, ref[n], rtol=rtol, atol_scale=atol, case=f"backward P={P_} {HW_w}^2 dense ({label})")
 
 
 def test_reference_config_1024_square_sh3_forward_and_backward():
@@ -358,3 +370,40 @@ def test_full_benchmark_size_parity_100k_gaussians_512():
     assert int((sc["n_contrib"][0] != st.n_contrib).sum()) == 0
     assert int(sc["pair_counts"][0, :, :, 1].sum()) == st.pairs_blended_fwd
     _check_backward_dense(st, args, out, seed=8)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_inactive_sh_bands_get_exact_zero_gradient(deg):
+    """SH storage of degree 3 (M = 16) rendered at a LOWER active degree (the reference starts at
+    active_sh_degree 0 and steps it up, gaussian_model.py:45,120-122): bands above the active degree receive no
+    gradient -- exact zeros like the reference's torch::zeros output (rasterize_points.cu:160), although this
+    library's outputs are not pre-zeroed -- and everything is finite, for visible and invisible Gaussians."""
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    from oracle import gd_oracle
+    HW, P = 96, 3000
+    inp = h.raster_inputs(P=P, H=HW, W=HW, sh_degree=3, seed=40 + deg)
+    inp["degree"] = deg
+    st = h.oracle_forward(inp)
+    gc, gd, ga = h.random_image_grads(HW, HW, seed=deg)
+    ref = gd_oracle.backward(st, gc, gd, ga)
+    args, out = _run_gpu_forward(inp)
+    _check_forward(inp, st, out)
+    R, color, depth, alpha, radii, geom, binning, img = out
+    t = lambda a: torch.as_tensor(a, device=DEV)
+    (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, _, _) = args
+    # poison the caching allocator's free list so that a missing write shows up as NaN, not as stale zeros
+    junk = torch.full((P * 16 * 3 * 4,), float("nan"), device=DEV)
+    del junk
+    grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
+                                            t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha,
+                                            False)
+    torch.cuda.synchronize()
+    dsh = grads[5]
+    assert dsh.shape == (P, 16, 3) and torch.isfinite(dsh).all()
+    n_active = (deg + 1) ** 2
+    assert float(dsh[:, n_active:, :].abs().max()) == 0.0
+    assert float(dsh[:, :n_active, :].abs().max()) > 0.0
+    assert (radii == 0).any() and float(dsh[radii == 0].abs().max()) == 0.0
+    for g in grads:
+        assert torch.isfinite(g).all()
+    _check_grads("dL_dsh", dsh, ref["dL_dsh"])

@@ -54,6 +54,28 @@ def test_expon_lr_func_matches_reference_golden():
     steps = GOLD["lr_steps"]
     np.testing.assert_array_equal(np.array([f1(int(s)) for s in steps]), GOLD["lr_xyz"])
     np.testing.assert_array_equal(np.array([f2(int(s)) for s in steps]), GOLD["lr_delay"])
+    a = gm.OptimizationParams
+    f3 = gm.get_expon_lr_func(lr_init=a.position_lr_init, lr_final=a.position_lr_final,
+                              lr_delay_mult=a.position_lr_delay_mult, max_steps=a.position_lr_max_steps)
+    np.testing.assert_array_equal(np.array([f3(int(s)) for s in steps]), GOLD["lr_fork"])
+
+
+def test_optimization_params_match_reference_golden():
+    """arguments/__init__.py:63-90 of THIS fork (not vanilla 3DGS), captured by tests/golden/make_golden_scene.py."""
+    import json
+    import os
+    from garmentdreamer_amd.scene import GaussianParams
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "optimization_params.json")))["optimization"]
+    for k in ("position_lr_init", "position_lr_final", "position_lr_delay_mult", "position_lr_max_steps", "feature_lr",
+              "opacity_lr", "scaling_lr", "rotation_lr", "percent_dense", "densification_interval",
+              "opacity_reset_interval", "densify_from_iter", "densify_until_iter", "densify_grad_threshold"):
+        assert getattr(gm.OptimizationParams, k) == ref[k], k
+    g = GaussianParams({"means3D": np.zeros((2, 3), np.float32), "shs": np.zeros((2, 1, 3), np.float32),
+                        "scales": np.ones((2, 3), np.float32), "rotations": np.ones((2, 4), np.float32),
+                        "opacities": np.full((2, 1), 0.5, np.float32)}, device="cpu")
+    lrs = {d["name"]: d["lr"] for d in g.param_groups()}
+    assert lrs == {"xyz": ref["position_lr_init"], "f_dc": ref["feature_lr"], "f_rest": ref["feature_lr"] / 20.0,
+                   "opacity": ref["opacity_lr"], "scaling": ref["scaling_lr"], "rotation": ref["rotation_lr"]}
 
 
 def test_build_rotation_and_rgb2sh_match_reference_golden():
@@ -139,7 +161,7 @@ def test_reset_opacity_and_lr_schedule():
     lr0 = m.update_learning_rate(0)
     lr1 = m.update_learning_rate(30000)
     # lr_delay_steps = 0: the delay multiplier is inactive (general_utils.py:51-57)
-    assert abs(lr0 - 0.00016) < 1e-12 and abs(lr1 - 0.0000016) < 1e-12 and m.lrs["xyz"] == lr1
+    assert abs(lr0 - 0.00005) < 1e-12 and abs(lr1 - 0.000025) < 1e-12 and m.lrs["xyz"] == lr1
 
 
 def test_ply_round_trip_and_header_layout(tmp_path):
