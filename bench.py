@@ -106,20 +106,38 @@ def count_pairs(loop, batch, device):
                 views=V)
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
-    """CPU oracle rasterizer (1 thread) + fp32 PyTorch-CPU VAE/UNet for ONE view, scaled to the 8-view
-    iteration.  Test infrastructure used as the reported baseline only (never as the product path)."""
+    """CPU oracle rasterizer (1 thread, and tiles over all host cores with OpenMP) + fp32 PyTorch-CPU VAE/UNet for
+    ONE view, scaled to the whole iteration.  Test infrastructure used as the reported baseline only (never as the
+    product path).  ``value`` uses the multi-core rasterizer time; the single-thread time is reported beside it."""
     from garmentdreamer_amd.guidance import sd21
     from oracle import gd_oracle
     from tests import helpers as h
     nthreads = torch.get_num_threads()
+    ncores = os.cpu_count() or nthreads
     inp = h.raster_inputs(P=args.gaussians, H=args.res, W=args.res, seed=0, azimuth=-157.5, elevation=15.0,
                           distance=2.75, fovy_deg=55.0)
-    t0 = time.perf_counter()
-    st = h.oracle_forward(inp)
     gc, gd, ga = h.random_image_grads(args.res, args.res)
-    gd_oracle.backward(st, gc, gd, ga)
-    t_raster = time.perf_counter() - t0
+    t_raster = {}
+    for omp in (False, True):
+        os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+        t0 = time.perf_counter()
+        st = gd_oracle.forward(inp["bg"], inp["means3D"], inp["colors_precomp"], inp["opacities"], inp["scales"],
+                               inp["rotations"], inp["scale_modifier"], inp["cov3D_precomp"], inp["viewmatrix"],
+                               inp["projmatrix"], inp["tanfovx"], inp["tanfovy"], inp["image_height"],
+                               inp["image_width"], inp["sh"], inp["degree"], inp["campos"], omp=omp)
+        gd_oracle.backward(st, gc, gd, ga)
+        t_raster[omp] = time.perf_counter() - t0
     torch.manual_seed(0)
     vae = sd21.init_random_(sd21.AutoencoderKLEncoder()).float().eval()
     unet = sd21.init_random_(sd21.UNet2DConditionModel()).float().eval()
@@ -132,11 +150,16 @@ def cpu_baseline(args):
         eps = unet(torch.cat([lat.detach()] * 2), torch.tensor([500, 500]), torch.randn(2, 77, 1024))
     (lat * eps[:1].detach()).sum().backward()
     t_dense = time.perf_counter() - t0
-    t_view = t_raster + t_dense
+    t_view = t_raster[True] + t_dense
     return {"value": 1.0 / (args.views * t_view), "unit": "iters/s", "cores": nthreads, "kind": "port",
+            "cpu_model": _cpu_model(), "host_cores": ncores,
+            "raster_1thread_s_per_view": t_raster[False], "raster_openmp_s_per_view": t_raster[True],
+            "dense_fp32_s_per_view": t_dense,
+            "value_1thread_raster": 1.0 / (args.views * (t_raster[False] + t_dense)),
             "sample": (f"1 of {args.views} views: oracle rasterizer fwd+bwd {args.gaussians} Gaussians @{args.res}^2 "
-                       f"(1 thread, {t_raster:.2f} s) + fp32 torch-CPU VAE fwd/dgrad + UNet x2 fwd ({nthreads} threads, "
-                       f"{t_dense:.2f} s); scaled x{args.views}")}
+                       f"(1 thread {t_raster[False]:.2f} s; OpenMP over tiles, {ncores} cores, {t_raster[True]:.2f} s) + "
+                       f"fp32 torch-CPU VAE fwd/dgrad + UNet x2 fwd ({nthreads} threads, {t_dense:.2f} s); "
+                       f"scaled x{args.views}")}
 
 
 def vsd_main(args):
@@ -289,8 +312,10 @@ def main():
     _native.profile_enable(False)
     prof = _native.profile_read()
     conv_ms, conv_n, conv_flops = nn_ops.conv_profile(enable=False) if not args.raster_only else (0.0, 0, 0.0)
+    conv_bytes = nn_ops.conv_profile_bytes() if not args.raster_only else 0.0
     conv_steps = args.steps
     conv_note = "HIP events around every launch inside the timed region"
+    graphs_active = bool(guidance is not None and guidance.cfg.use_hip_graphs)   # False if capture failed / was refused
     if not args.raster_only and conv_n == 0:
         # The timed region replays the UNet / VAE as hipGraphs; launches inside a graph cannot be bracketed by
         # events, so the same kernels are timed in an eager pass of the same workload right after the timed region.
@@ -301,7 +326,8 @@ def main():
             one_step(args.warmup + args.steps + s)
         torch.cuda.synchronize()
         conv_ms, conv_n, conv_flops = nn_ops.conv_profile(enable=False)
-        guidance.cfg.use_hip_graphs = not args.no_graphs
+        conv_bytes = nn_ops.conv_profile_bytes()
+        guidance.cfg.use_hip_graphs = graphs_active
         conv_note = ("HIP events around every launch in an eager (non-graph) pass of the same workload run right after "
                      "the timed region, whose UNet/VAE launches are replayed from hipGraphs")
     if ws > 1:
@@ -330,6 +356,7 @@ def main():
                          "kernel": "conv3x3_nhwc_bf16_kernel + conv3x3_gn_patch_kernel + conv3x3_patch_stream_kernel",
                          "avg_launch_us": conv_ms / conv_n * 1e3, "launches": conv_n,
                          "flops_per_launch": conv_flops / conv_n, "ms_per_step": conv_ms / max(conv_steps, 1),
+                         "algorithmic_bytes_per_launch": conv_bytes / conv_n,
                          "timing": conv_note,
                          "note": ("dominant kernel family of the step (largest share of GPU time): the bf16 MFMA 3x3 "
                                   "convolution of the VAE encoder / UNet -- implicit-GEMM kernel (stride 1 / 2, dgrad, "
@@ -341,22 +368,43 @@ def main():
     if bwd_n > 0:
         avg_s = bwd_ms / bwd_n * 1e-3
         ach = flops_launch / avg_s / 1e12
-        roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+        V_ = counts["views"]
+        alg_bytes = 44.0 * counts["num_rendered"] + 20.0 * V_ * args.res * args.res + 40.0 * V_ * args.gaussians
+        roofline = {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
                     "kernel": "render_backward_kernel", "avg_launch_us": avg_s * 1e6, "launches": bwd_n,
-                    "flops_per_launch": flops_launch,
-                    "note": ("fp32 compute roof: 157.3 TF/s vector rate == f32-input MFMA rate on gfx950; the kernel is "
-                             "VALU-bound (no MFMA issued). Algorithmic HBM bytes ~28 MB per view; the PMC traffic figure "
-                             "is dominated by L2 atomic read-modify-writes of the per-Gaussian accumulators")}
+                    "flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": ("fp32 VALU roof: 157.3 TF/s (4 SIMD-32 per CU, v_fma_f32 every 2 cycles) == the f32-input "
+                             "MFMA rate on gfx950; no MFMA is issued. Algorithmic HBM bytes = 44 B per instance + 20 B "
+                             "per pixel + 40 B per (view, Gaussian) accumulator row")}
 
-    traffic_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(traffic_file):   # HBM bytes per launch from rocprofv3 PMC passes of this same command
+    # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/pmc_all.sh -> profiles/):
+    # bench.py cannot read hardware counters itself, so `traffic` quotes the committed counter file
+    kernels_per_step = None
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if os.path.exists(pmc_file):
         try:
-            tr = json.load(open(traffic_file))
-            if roofline_conv is not None and "conv3x3_nhwc_bf16_kernel" in tr:
-                roofline_conv["traffic"] = tr["conv3x3_nhwc_bf16_kernel"]["hbm_bytes_per_launch"]
-            if roofline is not None and "render_backward_kernel" in tr:
-                roofline["traffic"] = tr["render_backward_kernel"]["hbm_bytes_per_launch"]
+            ks = json.load(open(pmc_file))["kernels"]
+            if roofline_conv is not None:
+                fam = {k: v for k, v in ks.items() if k.startswith("conv3x3_") and "hbm_bytes_per_launch" in v
+                       and "first" not in k and "flip" not in k}
+                n = sum(v["launches_sampled"] for v in fam.values())
+                if n:
+                    roofline_conv["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in fam.values()) / n
+                    roofline_conv["traffic_per_kernel"] = {k: v["hbm_bytes_per_launch"] for k, v in fam.items()}
+                    roofline_conv["traffic_source"] = "profiles/r02_pmc.json (launch-weighted mean over the family)"
+            if roofline is not None:
+                for k, v in ks.items():
+                    if k.startswith("render_backward") and "hbm_bytes_per_launch" in v:
+                        roofline["traffic"] = v["hbm_bytes_per_launch"]
+                        roofline["traffic_source"] = "profiles/r02_pmc.json"
+        except Exception:
+            pass
+    steady = os.path.join(ROOT, "profiles", "r02_bench_N1_kernel_stats_steady.csv")
+    if os.path.exists(steady) and args.views == 8 and ws == 1:
+        try:
+            import csv
+            kernels_per_step = sum(float(r["CallsPerStep"]) for r in csv.DictReader(open(steady)))
         except Exception:
             pass
     if rk == 0:
@@ -370,7 +418,8 @@ def main():
                        "gaussians": args.gaussians, "views": args.views, "resolution": args.res,
                        "views_per_gpu": V, "parallelism": f"view-sharded dp{ws}",
                        "raster": "per-view loop" if args.per_view_raster else "batched",
-                       "raster_only": bool(args.raster_only)},
+                       "raster_only": bool(args.raster_only), "hip_graphs": graphs_active,
+                       "kernels_per_step": kernels_per_step},
             "roofline": roofline_conv if roofline_conv is not None else roofline,
             "roofline_raster_bwd": roofline,
             "raster_kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},

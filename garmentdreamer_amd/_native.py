@@ -34,7 +34,7 @@ SIGNATURES = {
     "gd_raster_geom_bytes": (C.c_size_t, [_i, _i]),
     "gd_raster_image_bytes": (C.c_size_t, [_i, _i, _i]),
     "gd_raster_binning_bytes": (C.c_size_t, [C.c_int64]),
-    "gd_raster_backward_scratch_bytes": (C.c_size_t, [_i, _i]),
+    "gd_raster_backward_scratch_bytes": (C.c_size_t, [_i, _i, C.c_int64]),
     "gd_raster_forward": (_i, [_vp] + [ALLOC_FN, _vp] * 3      # stream, 3 x (allocator, user)
                           + [_i] * 3 + [_vp] + [_i] * 2          # P D M, background, width height
                           + [_vp] * 5 + [_f] + [_vp] * 5         # means3D shs colors opac scales | mod | rot cov view proj campos

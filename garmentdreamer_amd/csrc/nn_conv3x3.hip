@@ -1028,7 +1028,7 @@ struct ConvProf {
     struct Rec { hipEvent_t a, b; };
     std::vector<Rec> pending;
     std::vector<hipEvent_t> pool;
-    double total_ms = 0, total_flops = 0;
+    double total_ms = 0, total_flops = 0, total_bytes = 0;
     int64_t launches = 0;
     hipEvent_t get()
     {
@@ -1136,6 +1136,9 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
         std::lock_guard<std::mutex> lk(g_cprof.mu);
         g_cprof.pending.push_back({ea, eb});
         g_cprof.total_flops += 2.0 * (double)M * Cout * (double)g.ntaps * Cin;
+        // algorithmic HBM bytes: every input element once, the taps' weights once, every output element once
+        g_cprof.total_bytes += 2.0 * ((double)N * g.Hin * g.Win * Cin + (double)g.ntaps * Cin * Cout + (double)M * Cout +
+                                      (residual ? (double)M * Cout : 0.0));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
@@ -1282,6 +1285,8 @@ static int launch_patch(void* stream, const void* x, const float* mean_rstd, con
         std::lock_guard<std::mutex> lk(g_cprof.mu);
         g_cprof.pending.push_back({ea, eb});
         g_cprof.total_flops += 2.0 * (double)M * Cout * 9.0 * Cin;
+        g_cprof.total_bytes += 2.0 * ((double)M * Cin + 9.0 * Cin * Cout + (double)M * Cout +
+                                      (residual ? (double)M * Cout : 0.0));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
@@ -1414,7 +1419,7 @@ int gd_nn_conv_profile_enable(int on)
 int gd_nn_conv_profile_reset(void)
 {
     std::lock_guard<std::mutex> lk(g_cprof.mu);
-    g_cprof.total_ms = g_cprof.total_flops = 0;
+    g_cprof.total_ms = g_cprof.total_flops = g_cprof.total_bytes = 0;
     g_cprof.launches = 0;
     return GD_NN_OK;
 }
@@ -1437,6 +1442,14 @@ int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_f
     if (total_ms) *total_ms = g_cprof.total_ms;
     if (launches) *launches = g_cprof.launches;
     if (total_flops) *total_flops = g_cprof.total_flops;
+    return GD_NN_OK;
+}
+
+/* Algorithmic HBM bytes (activations in + weights + activations out, each once) summed like total_flops. */
+int gd_nn_conv_profile_read_bytes(double* total_bytes)
+{
+    std::lock_guard<std::mutex> lk(g_cprof.mu);
+    if (total_bytes) *total_bytes = g_cprof.total_bytes;
     return GD_NN_OK;
 }
 

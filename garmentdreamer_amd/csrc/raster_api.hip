@@ -132,6 +132,7 @@ BinningState carve_binning(char* chunk, size_t R, size_t* used)
     obtain(p, b.keys_alt, R);
     const size_t nblk = (R + kSortTile - 1) / kSortTile;
     obtain(p, b.sort_hist, ((size_t)1 << kMaxDigitBits) * (nblk + 1));
+    obtain(p, b.ballots, 4 * R);
     if (used) *used = (size_t)(p - chunk);
     return b;
 }
@@ -237,7 +238,7 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     if (int e = check_debug(stream, debug, "ranges")) return e;
     { ProfScope ps(stream, GD_K_RENDER_FWD);
     launch_render_forward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
-                          out_color, out_depth, out_alpha, img.n_contrib, img.pair_counts); }
+                          out_color, out_depth, out_alpha, img.n_contrib, img.pair_counts, bin.ballots, num_rendered); }
     if (int e = check_debug(stream, debug, "render")) return e;
     GD_HIP(hipGetLastError());
     return (int)num_rendered;
@@ -268,16 +269,20 @@ int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const f
     ImageState img = carve_image(image_buffer, dm.tiles_total, dm.pixels_total, nullptr);
     if (radii == nullptr) radii = geom.radii;
 
-    float* acc = nullptr;
+    // backward scratch: one 10-float row per list position (written, never accumulated) + the inverse permutation
+    float* inst = nullptr;
+    uint32_t* inv = nullptr;
     {
         char* p = bwd_scratch;
-        obtain(p, acc, VP * 10);
+        obtain(p, inst, (size_t)R * 10);
+        obtain(p, inv, (size_t)R);
     }
-    GD_HIP(hipMemsetAsync(acc, 0, sizeof(float) * VP * 10, stream));
     if (R > 0) {
-        ProfScope ps(stream, GD_K_RENDER_BWD);
+        { ProfScope ps(stream, GD_K_RENDER_BWD);
         launch_render_backward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
-                               alphas, img.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc);
+                               alphas, img.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, inst, bin.ballots, (uint32_t)R); }
+        ProfScope ps(stream, GD_K_PREPROCESS_BWD);
+        launch_instance_slots(stream, (uint32_t)R, P, bin.keys, bin.point_list, radii, geom, dm.tiles_x, dm.tiles_y, inv);
     }
     if (int e = check_debug(stream, debug, "render backward")) return e;
 
@@ -285,8 +290,8 @@ int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const f
     const size_t cov_stride = cov3D_precomp ? 0 : (size_t)P * 6;
     { ProfScope ps(stream, GD_K_PREPROCESS_BWD);
     launch_preprocess_backward(stream, P, D, M, V, means3D, radii, shs, geom.clamped, scales, rotations,
-                               scale_modifier, cov3D, cov_stride, viewmatrix, projmatrix, campos, vs, acc,
-                               colors_precomp != nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth,
+                               scale_modifier, cov3D, cov_stride, viewmatrix, projmatrix, campos, vs, inst, inv,
+                               geom.point_offsets, geom.tiles_touched, colors_precomp != nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth,
                                dL_dmean3D, dL_dcov3D, shs ? dL_dsh : nullptr, scales ? dL_dscale : nullptr,
                                scales ? dL_drot : nullptr, nullptr); }
     if (int e = check_debug(stream, debug, "preprocess backward")) return e;
@@ -321,7 +326,12 @@ size_t gd_raster_binning_bytes(int64_t R)
     carve_binning(nullptr, (size_t)(R < 0 ? 0 : R), &used);
     return used + 128;
 }
-size_t gd_raster_backward_scratch_bytes(int P, int V) { return (size_t)P * (size_t)(V < 1 ? 1 : V) * 10 * sizeof(float) + 128; }
+size_t gd_raster_backward_scratch_bytes(int P, int V, int64_t R)
+{
+    (void)P; (void)V;
+    const size_t r = (size_t)(R < 0 ? 0 : R);
+    return r * 10 * sizeof(float) + r * sizeof(uint32_t) + 384;
+}
 
 int gd_raster_forward(void* stream, gd_alloc_fn geom_alloc, void* geom_user, gd_alloc_fn binning_alloc,
                       void* binning_user, gd_alloc_fn image_alloc, void* image_user, int P, int D, int M,

@@ -115,6 +115,28 @@ __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, c
     }
 }
 
+// Sorted position -> the slot duplicate_kernel gave the instance (its Gaussian's offset + the tile's index inside the
+// Gaussian's tile rectangle), inverted: inv[slot] = sorted position.  With it the backward pass needs no atomics: the
+// blend kernel stores one row per list position and preprocess_backward_kernel gathers each Gaussian's rows in a fixed
+// order (deterministic gradients; the reference's 10 atomicAdd per pair, backward.cu:555-598, become 0).
+__global__ __launch_bounds__(256) void instance_slots_kernel(uint32_t R, int P, const uint64_t* __restrict__ keys,
+                                                             const uint32_t* __restrict__ point_list,
+                                                             const int* __restrict__ radii, GeomState gs, uint32_t gx,
+                                                             uint32_t gy, uint32_t* __restrict__ inv)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= R) return;
+    const uint32_t vp = point_list[s];
+    const uint32_t tile = (uint32_t)(keys[s] >> 32);
+    const uint32_t lt = tile - (vp / (uint32_t)P) * gx * gy;
+    const uint32_t ty = lt / gx, tx = lt - ty * gx;
+    const float2 xy = gs.means2D[vp];
+    uint32_t x0, y0, x1, y1;
+    tile_rect(xy.x, xy.y, radii[vp], gx, gy, x0, y0, x1, y1);
+    const uint32_t first = gs.point_offsets[vp] - gs.tiles_touched[vp];
+    inv[first + (ty - y0) * (x1 - x0) + (tx - x0)] = s;
+}
+
 // ---------------- radix sort ----------------
 // Element i of a workgroup tile belongs to wave i / (64*kSortItems); inside the wave the order
 // is (step, lane).  Stability follows from ranking in exactly that order.
@@ -336,6 +358,14 @@ void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* 
 {
     (void)hipMemsetAsync(ranges, 0, (size_t)tiles_total * sizeof(uint2), s);
     if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges);
+}
+
+void launch_instance_slots(hipStream_t s, uint32_t R, int P, const uint64_t* keys, const uint32_t* point_list,
+                           const int* radii, const GeomState& g, int tiles_x, int tiles_y, uint32_t* inv)
+{
+    if (R == 0) return;
+    hipLaunchKernelGGL(instance_slots_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, R, P, keys, point_list, radii, g,
+                       (uint32_t)tiles_x, (uint32_t)tiles_y, inv);
 }
 
 }  // namespace gd

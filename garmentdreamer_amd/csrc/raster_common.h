@@ -45,6 +45,9 @@ struct BinningState {
     uint64_t* keys;            // [R] sorted keys
     uint64_t* keys_alt;        // [R]
     uint32_t* sort_hist;       // [bins * nblk + bins]
+    uint64_t* ballots;         // [4][R] per (16x4 strip of the tile, list position): which of the strip's 64 pixels
+                               // BLENDED the entry in the forward pass (written by render_forward, read by the
+                               // backward blend: the reverse pass never repeats the contribution test)
 };
 
 GeomState carve_geom(char* chunk, size_t VP, size_t* used);
@@ -79,7 +82,8 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
                                 const float* shs, const uint8_t* clamped, const float* scales,
                                 const float* rotations, float scale_modifier, const float* cov3D,
                                 size_t cov3D_view_stride, const float* viewmatrix, const float* projmatrix,
-                                const float* campos, const ViewScalars& vs, const float* acc /*[VP][10]*/,
+                                const float* campos, const ViewScalars& vs, const float* inst /*[R][10]*/,
+                                const uint32_t* inv /*[R]*/, const uint32_t* point_offsets, const uint32_t* tiles_touched,
                                 bool colors_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                                 float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
                                 float* dL_dsh, float* dL_dscale, float* dL_drot, float* view_partials);
@@ -92,10 +96,16 @@ void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* 
 
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
-                           float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts);
+                           float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts,
+                           uint64_t* ballots, uint32_t R);
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const uint32_t* point_list, const GeomState& g, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                            const float* dL_dalphas, float* acc /*[VP][10], zeroed*/);
+                            const float* dL_dalphas, float* inst /*[R][10]: one row per list position, all written*/,
+                            const uint64_t* ballots, uint32_t R);
+// inv[o] = sorted list position of instance o (o = the slot duplicate_kernel wrote it to: instances of Gaussian vp are
+// point_offsets[vp] - tiles_touched[vp] ... point_offsets[vp] - 1): lets a per-Gaussian thread GATHER its rows.
+void launch_instance_slots(hipStream_t s, uint32_t R, int P, const uint64_t* keys, const uint32_t* point_list,
+                           const int* radii, const GeomState& g, int tiles_x, int tiles_y, uint32_t* inv);
 
 }  // namespace gd

@@ -328,14 +328,17 @@ __device__ void sh_backward(int g, size_t vp, int deg, int M, const float* __res
 
 // One thread per Gaussian; loops over the V views so that every output element is written
 // exactly once, in a fixed order (deterministic, no pre-zeroing, no atomics).
-// acc[vp][10] = {dL_dcolor.rgb, dL_ddepth, dL_dmean2D.xy, dL_dconic.x/.y/.w, dL_dopacity}
-// as accumulated by the backward render kernel.
+// {dL_dcolor.rgb, dL_ddepth, dL_dmean2D.xy, dL_dconic.x/.y/.w, dL_dopacity} of (view, Gaussian) = the sum of the
+// rows inst[s][10] the backward render kernel stored for the Gaussian's list positions s = inv[slot], gathered here
+// in slot order (the reference accumulates the same terms with atomicAdd, backward.cu:555-598).
 __global__ __launch_bounds__(kGaussBlock) void preprocess_backward_kernel(
     int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
     const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
     const float* __restrict__ rotations, float scale_modifier, const float* __restrict__ cov3D,
     size_t cov3D_view_stride, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
-    const float* __restrict__ campos, ViewScalars vs, const float* __restrict__ acc, bool has_colors_precomp,
+    const float* __restrict__ campos, ViewScalars vs, const float* __restrict__ inst,
+    const uint32_t* __restrict__ inv, const uint32_t* __restrict__ point_offsets,
+    const uint32_t* __restrict__ tiles_touched, bool has_colors_precomp,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth, float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
@@ -349,8 +352,19 @@ __global__ __launch_bounds__(kGaussBlock) void preprocess_backward_kernel(
     bool sh_first = true;
     for (int v = 0; v < vs.V; v++) {
         const size_t vp = (size_t)v * P + g;
-        const float* a = acc + 10 * vp;
         const bool vis = radii[vp] > 0;
+        float a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (vis) {
+            const uint32_t end = point_offsets[vp], first = end - tiles_touched[vp];
+            for (uint32_t o = first; o < end; o++) {
+                const float2* row = reinterpret_cast<const float2*>(inst + 10 * (size_t)inv[o]);
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const float2 t = row[k];
+                    a[2 * k] += t.x; a[2 * k + 1] += t.y;
+                }
+            }
+        }
         // per-view outputs (exist for parity with the reference's intermediates)
         if (dL_dmean2D) {
             dL_dmean2D[3 * vp] = vis ? a[4] : 0.f; dL_dmean2D[3 * vp + 1] = vis ? a[5] : 0.f;
@@ -537,7 +551,8 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
                                 const float* shs, const uint8_t* clamped, const float* scales,
                                 const float* rotations, float scale_modifier, const float* cov3D,
                                 size_t cov3D_view_stride, const float* viewmatrix, const float* projmatrix,
-                                const float* campos, const ViewScalars& vs, const float* acc, bool colors_precomp,
+                                const float* campos, const ViewScalars& vs, const float* inst, const uint32_t* inv,
+                                const uint32_t* point_offsets, const uint32_t* tiles_touched, bool colors_precomp,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                                 float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                                 float* dL_dscale, float* dL_drot, float* /*unused*/)
@@ -545,7 +560,8 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
     (void)V;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + kGaussBlock - 1) / kGaussBlock), dim3(kGaussBlock), 0,
                        s, P, D, M, means3D, radii, shs, clamped, scales, rotations, scale_modifier, cov3D,
-                       cov3D_view_stride, viewmatrix, projmatrix, campos, vs, acc, colors_precomp, dL_dmean2D,
+                       cov3D_view_stride, viewmatrix, projmatrix, campos, vs, inst, inv, point_offsets, tiles_touched,
+                       colors_precomp, dL_dmean2D,
                        dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                        dL_drot);
 }

@@ -29,6 +29,10 @@
 
 #include "raster_common.h"
 
+#ifndef GD_BWD_ROUND
+#define GD_BWD_ROUND 128
+#define GD_BWD_CAP 512
+#endif
 #ifndef GD_ABLATE
 #define GD_ABLATE 0   // 1: skip the cross-lane reduction + LDS atomics (timing ablation only; wrong results)
 #endif
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
     const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-    uint32_t* __restrict__ n_contrib, uint2* __restrict__ pair_counts)
+    uint32_t* __restrict__ n_contrib, uint2* __restrict__ pair_counts, uint64_t* __restrict__ ballots, uint32_t R)
 {
     __shared__ float2 s_xy[kTilePix];
     __shared__ float4 s_co[kTilePix];
@@ -266,9 +270,15 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
         for (int c = 0; wave_live && c < n; c += 64) {
             // 64 entries' strip bits -> one scalar bitmap of the entries this wave must look at
             uint64_t bits = __builtin_amdgcn_ballot_w64(((s_mask[c + lane] >> wave) & 1u) != 0);
+            // lane l collects, for list entry c + l, the ballot of the strip's pixels that BLEND it: the backward pass
+            // walks exactly these (pixel, entry) pairs (ballots[strip][list position]; zero = nobody, also for the
+            // entries the strip culling or an early exit never looked at)
+            uint32_t wb_lo = 0, wb_hi = 0;
             while (bits) {
-                const int j = c + (int)__builtin_ctzll(bits);
+                const int jl = (int)__builtin_ctzll(bits);
+                const int j = c + jl;
                 bits &= bits - 1;
+                bool blend = false;
                 if (!done) {
                     const float2 xy = s_xy[j];
                     const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
@@ -294,15 +304,22 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
                                 T = test_T;
                                 last_contributor = cbase + (uint32_t)j + 1u;
                                 blended++;
+                                blend = true;
                             }
                         }
                     }
                 }
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(blend);
+                const bool mine = (int)lane == jl;
+                wb_lo = mine ? (uint32_t)bal : wb_lo;
+                wb_hi = mine ? (uint32_t)(bal >> 32) : wb_hi;
                 if (__builtin_amdgcn_ballot_w64(!done) == 0) {
                     wave_live = false;
                     break;
                 }
             }
+            if (c + (int)lane < n)
+                ballots[(size_t)wave * R + (range.x + cbase + (uint32_t)c + lane)] = ((uint64_t)wb_hi << 32) | wb_lo;
         }
     }
     if (inside) {
@@ -318,6 +335,17 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
 }
 
 constexpr int kAcc = 10;  // colour rgb, depth, mean2D xy, conic x/y/w, opacity
+
+// The backward blend kernels write ONE row of kAcc floats per list position (inst[position][kAcc], position =
+// range.x ... range.y - 1 of the tile) and never accumulate across workgroups: every row of every tile is stored
+// exactly once -- zeros for the entries no pixel reaches -- and preprocess_backward_kernel gathers the rows of a
+// Gaussian.  zero_rows: rows [first, first + count) <- 0 by the whole workgroup.
+__device__ __forceinline__ void zero_rows(float* __restrict__ inst, uint32_t first, uint32_t count, uint32_t tid,
+                                          uint32_t threads)
+{
+    float2* p = reinterpret_cast<float2*>(inst + (size_t)first * kAcc);
+    for (uint32_t i = tid; i < count * (kAcc / 2); i += threads) p[i] = make_float2(0.f, 0.f);
+}
 
 // Per-pixel state of the reverse walk (backward.cu:461-487).
 struct PixState {
@@ -409,10 +437,14 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
     uint32_t bmax = s_wmax[0];
 #pragma unroll
     for (int w = 1; w < WAVES; w++) bmax = max(bmax, s_wmax[w]);
-    if (bmax == 0) return;
     const int first_p_block = total - (int)bmax;  // first reverse position any pixel uses
     const int first_p_wave = total - (int)wmax;
     const int rounds = (total + ROUND - 1) / ROUND;
+    {   // rows of the list entries behind every pixel's last contributor (whole skipped rounds): zeros
+        const uint32_t skipped = bmax == 0 ? (uint32_t)total : (uint32_t)((first_p_block / ROUND) * ROUND);
+        zero_rows(acc, range.y - skipped, skipped, tid, THREADS);
+        if (bmax == 0) return;
+    }
 
     for (int i = first_p_block / ROUND; i < rounds; i++) {
         const int round_base = i * ROUND;
@@ -527,16 +559,295 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
             }
         }
         __syncthreads();
-        // flush this round: one global atomic per touched (entry, component)
+        // flush this round: the row of list position range.y - 1 - (round_base + e) (no atomics: one writer per row)
         for (int e = tid; e < n; e += THREADS) {
-            float* dst = acc + (size_t)s_id[e] * kAcc;
+            float2* dst = reinterpret_cast<float2*>(acc + (size_t)(range.y - 1u - (uint32_t)(round_base + e)) * kAcc);
 #pragma unroll
-            for (int k = 0; k < kAcc; k++) {
-                const float val = s_acc[e * kAcc + k];
-                if (val != 0.f) {
-                    atomicAdd(dst + k, val);
-                    s_acc[e * kAcc + k] = 0.f;
+            for (int k = 0; k < kAcc; k += 2) {
+                float2* src = reinterpret_cast<float2*>(&s_acc[e * kAcc + k]);
+                dst[k / 2] = *src;
+                *src = make_float2(0.f, 0.f);
+            }
+        }
+    }
+}
+
+
+// =================================================================================================================
+// render_backward_lists_kernel -- the reverse-order gradient pass re-organised around PER-PIXEL LISTS.
+//
+// The wave-uniform walk above executes its ~60-instruction body for all 64 lanes of a strip although on the
+// benchmark scene only a third of the 64 pixels blend a given (strip, entry) pair -- and for half of the pairs the
+// strip culling lets through, none does -- and then pays a 38-instruction cross-lane reduction per pair: VALU-issue
+// bound at 7 % of the fp32 roof.  Here nothing is evaluated for a pair that does not contribute:
+//
+//   *  the forward pass leaves, per (strip, list position), the 64-bit ballot of the pixels that blended the entry
+//      (render_forward_kernel, `ballots`): exactly the pairs backward.cu:517-533 lets through, so the reverse pass
+//      needs neither the contribution test nor the strip culling;
+//   A  per group of 64 list entries a wave loads its 64 ballots (lane = entry), turns their popcounts into record
+//      offsets with one DPP scan and transposes the non-zero ones into a per-PIXEL list (lane = pixel, bit = entry);
+//   B  (lane = pixel, each lane walks ITS OWN list)  the sequential part of backward.cu:517-578 -- exp, alpha,
+//      T /= (1 - alpha), the accumulated-colour recurrence, dL/dalpha.  Lanes advance independently, so a step keeps
+//      about half of the lanes busy instead of a third, and the five recurrences of the reference (3 colours, depth,
+//      alpha) collapse into ONE because only their dot product with the pixel's (dL/dC, dL/ddepth, dL/dalpha) is ever
+//      used.  Output: a record {alpha T, G dL/dalpha, pixel} per contributing pair at slot base[entry] +
+//      rank-of-the-pixel-in-the-entry's-ballot (v_mbcnt), i.e. grouped by entry;
+//   C  (lane = quarter of an entry's records)  gathers the records and accumulates the ten sums of
+//      backward.cu:555-598 in registers -- colour / depth gradients and the moments sum w, sum w d, sum w d d^T of
+//      the pixel offsets d, from which dL/dmean2D, dL/dconic and dL/dopacity follow by one multiplication per entry.
+//      No cross-lane reduction; LDS atomics combine the quarters and the tile's four strips; the flush to
+//      acc[vp][10] is unchanged.
+// =================================================================================================================
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
+{
+    // Hillis-Steele inside each row of 16 lanes (row_shr with zero fill), then the row totals (row_bcast 15 / 31)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+template <int ROUND, int CAP>
+__global__ __launch_bounds__(kTilePix) void render_backward_lists_kernel(
+    int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
+    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
+    const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+    const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ acc,
+    const uint64_t* __restrict__ ballots, uint32_t R, int ablate)
+{
+    static_assert(ROUND % 64 == 0 && CAP >= 64, "round = whole 64-entry groups; one entry has up to 64 records");
+    constexpr int THREADS = kTilePix;
+    __shared__ float2 s_xy[ROUND];
+    __shared__ float4 s_co[ROUND];
+    __shared__ float4 s_fd[ROUND];
+    __shared__ uint32_t s_id[ROUND];
+    __shared__ float s_acc[4][ROUND * kAcc];   // PER WAVE (strip): every (strip, entry) row has exactly one writer -> plain stores
+    __shared__ uint4 s_tab[4][64];          // per wave, per entry of the current group: {ballot lo, hi, record base, count}
+    __shared__ uint8_t s_nz[4][64];         // per wave: the entries of the group that have records, compacted
+    __shared__ float2 s_rec[4][CAP];        // per wave: {alpha T, G dL/dalpha} per contributing pair, grouped by entry
+    __shared__ uint8_t s_rid[4][CAP];       //           ... and the pixel (lane) it belongs to
+    __shared__ float4 s_pix[kTilePix];      // per pixel: dL/dC rgb, dL/ddepth
+    __shared__ uint32_t s_wmax[4];
+
+    const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
+    const uint32_t tpv = gx * gy;
+    const uint32_t view = tile / tpv;
+    const uint32_t lt = tile - view * tpv;
+    const uint32_t ty = lt / gx, tx = lt - ty * gx;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + (tid >> 4);
+    const float pixf_x = (float)px, pixf_y = (float)py;
+    const size_t HW = (size_t)H * W;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
+    const uint64_t* my_ballots = ballots + (size_t)wave * R;
+
+    // ---- per-pixel constants and the state of the reverse walk (backward.cu:461-487) ----
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const size_t pix_id = (size_t)view * HW + (size_t)W * py + px;
+    const float T_final = inside ? (1 - alphas[pix_id]) : 0;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0;
+    float dLp0 = 0, dLp1 = 0, dLp2 = 0, dLpd = 0, dLa = 0;
+    if (inside) {
+        const float* dp = dL_dpixels + (size_t)view * 3 * HW + ((size_t)W * py + px);
+        dLp0 = dp[0]; dLp1 = dp[HW]; dLp2 = dp[2 * HW];
+        dLpd = dL_dpixel_depths[pix_id];
+        dLa = dL_dalphas[pix_id];
+    }
+    const float bgT = T_final * (bg_color[0] * dLp0 + bg_color[1] * dLp1 + bg_color[2] * dLp2);
+    s_pix[tid] = make_float4(dLp0, dLp1, dLp2, dLpd);
+    float A = 0.f, last_alpha = 0.f, last_s = 0.f;   // A = sum_k accum_rec_k dL_k of the reference's five recurrences
+
+    const uint32_t wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last_contributor));
+    if (lane == 0) s_wmax[wave] = wmax;
+    for (int i = tid; i < 4 * ROUND * kAcc; i += THREADS) (&s_acc[0][0])[i] = 0.f;
+    __syncthreads();
+    const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    const int first_p_block = total - (int)bmax;  // first reverse position any pixel uses
+    const int first_p_wave = total - (int)wmax;
+    const int rounds = (total + ROUND - 1) / ROUND;
+    {   // rows of the list entries behind every pixel's last contributor (whole skipped rounds): zeros
+        const uint32_t skipped = bmax == 0 ? (uint32_t)total : (uint32_t)((first_p_block / ROUND) * ROUND);
+        zero_rows(acc, range.y - skipped, skipped, tid, THREADS);
+        if (bmax == 0) return;
+    }
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+    for (int i = first_p_block / ROUND; i < rounds; i++) {
+        const int round_base = i * ROUND;
+        const int n = min(ROUND, total - round_base);
+        __syncthreads();  // previous round's flush is complete
+        for (int e = (int)tid; e < n; e += THREADS) {
+            const uint32_t id = point_list[range.y - (uint32_t)(round_base + e) - 1];
+            s_id[e] = id;
+            s_xy[e] = means2D[id];
+            s_co[e] = conic_opacity[id];
+            s_fd[e] = rgbd[id];
+        }
+        __syncthreads();
+        const int jstart = max(0, first_p_wave - round_base);
+        for (int c = jstart & ~63; wmax != 0 && c < n; c += 64) {
+            // ---------------- pass A: ballots -> record offsets and per-pixel lists ----------------
+            const int e_mine = c + (int)lane;
+            uint64_t bal = 0;
+            if (e_mine < n && e_mine >= jstart) bal = my_ballots[range.y - 1u - (uint32_t)(round_base + e_mine)];
+            const uint32_t bal_lo = (uint32_t)bal, bal_hi = (uint32_t)(bal >> 32);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(bal);
+            const uint64_t nz = __builtin_amdgcn_ballot_w64(cnt != 0);
+            if (nz == 0) continue;
+            const uint32_t incl = wave_inclusive_scan_u32(cnt);
+            const uint32_t base = incl - cnt;
+            uint32_t list_lo = 0, list_hi = 0;   // bit b: this pixel blended entry c + b
+            {
+                const uint32_t sh = lane & 31u;
+                const bool upper = lane >= 32u;
+                for (uint32_t t = (uint32_t)nz; t; t &= t - 1) {
+                    const int b = __builtin_ctz(t);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)bal_lo, b);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)bal_hi, b);
+                    list_lo |= (((upper ? hi : lo) >> sh) & 1u) << b;
                 }
+                for (uint32_t t = (uint32_t)(nz >> 32); t; t &= t - 1) {
+                    const int b = __builtin_ctz(t);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)bal_lo, b + 32);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)bal_hi, b + 32);
+                    list_hi |= (((upper ? hi : lo) >> sh) & 1u) << b;
+                }
+            }
+            // sub-ranges [b0, b1) of entries whose records fit the record buffer (normally the whole group)
+            uint32_t b0 = 0;
+            while (b0 < 64u) {
+                const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)b0);
+                uint64_t fits = __builtin_amdgcn_ballot_w64(incl - start <= (uint32_t)CAP);   // monotone from lane b0 on
+                fits |= (1ull << b0) - 1ull;
+                const uint32_t b1 = fits == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fits);
+                const uint64_t rmask = (b1 < 64u ? (1ull << b1) - 1ull : ~0ull) & ~((1ull << b0) - 1ull);
+                const uint64_t nzr = nz & rmask;
+                b0 = b1;
+                if (nzr == 0) continue;
+                const bool in_range = ((rmask >> lane) & 1ull) != 0;
+                s_tab[wave][lane] = make_uint4(bal_lo, bal_hi, base - start, cnt);
+                if (in_range && cnt != 0) {
+                    const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzr, 0u));
+                    s_nz[wave][k] = (uint8_t)lane;
+                }
+                const uint32_t nnz = (uint32_t)__builtin_popcountll(nzr);
+                __builtin_amdgcn_wave_barrier();
+                // ---------------- pass B: every pixel walks its own list ----------------
+                if (!(ablate & 1)) {
+                    uint64_t m = (((uint64_t)list_hi << 32) | list_lo) & rmask;
+                    uint4 row; float2 xy; float4 co, fd;
+                    bool have = m != 0;
+                    if (have) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        row = s_tab[wave][b]; xy = s_xy[c + b]; co = s_co[c + b]; fd = s_fd[c + b];
+                    }
+                    while (have) {
+                        // next entry's data is requested before this entry's arithmetic (LDS latency under the VALU chain)
+                        const bool have_next = m != 0;
+                        uint4 row_n = row; float2 xy_n = xy; float4 co_n = co, fd_n = fd;
+                        if (have_next) {
+                            const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                            m &= m - 1;
+                            row_n = s_tab[wave][b]; xy_n = s_xy[c + b]; co_n = s_co[c + b]; fd_n = s_fd[c + b];
+                        }
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(row.y, __builtin_amdgcn_mbcnt_lo(row.x, 0u));
+                        const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
+                        const float power = power_exact(__fmul_rn(__fmul_rn(co.x, dx), dx), __fmul_rn(co.y, dx), co.z, dy);
+                        const float G = __expf(power);
+                        const float alpha = fminf(0.99f, co.w * G);
+                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // shared by T/(1-a), T_final/(1-a)
+                        T = T * inv;
+                        const float sdot = fd.x * dLp0 + fd.y * dLp1 + fd.z * dLp2 + fd.w * dLpd + dLa;
+                        A = last_alpha * last_s + (1.f - last_alpha) * A;
+                        last_s = sdot;
+                        last_alpha = alpha;
+                        const float dL_dopa = (sdot - A) * T - inv * bgT;
+                        s_rec[wave][row.z + rank] = make_float2(alpha * T, G * dL_dopa);
+                        s_rid[wave][row.z + rank] = (uint8_t)lane;
+                        row = row_n; xy = xy_n; co = co_n; fd = fd_n;
+                        have = have_next;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---------------- pass C: lane = quarter of an entry's records ----------------
+                if (!(ablate & 2)) {
+                    for (uint32_t it0 = 0; it0 < 4u * nnz; it0 += 64u) {     // whole quads: 4 nnz is a multiple of 4
+                        const uint32_t it = it0 + lane;
+                        const bool active = it < 4u * nnz;
+                        const uint32_t b = active ? s_nz[wave][it >> 2] : 0u;
+                        const uint4 row = s_tab[wave][b];
+                        const uint32_t qlen = (row.w + 3u) >> 2;
+                        const uint32_t r0 = (it & 3u) * qlen;
+                        const uint32_t r1 = active ? min(row.w, r0 + qlen) : r0;
+                        const float2 xy = s_xy[c + b];
+                        const float4 co = s_co[c + b];
+                        const float ex = xy.x - tile_x0, ey = xy.y - (tile_y0 + 4.0f * (float)wave);   // relative to the strip
+                        float v[kAcc];
+#pragma unroll
+                        for (int k = 0; k < kAcc; k++) v[k] = 0.f;
+                        float sx = 0, sy = 0;
+                        for (uint32_t r = row.z + r0; r < row.z + r1; r++) {
+                            const float2 rc = s_rec[wave][r];
+                            const uint32_t l = s_rid[wave][r];
+                            const float4 g4 = s_pix[wave * 64u + l];
+                            const float dx = ex - (float)(l & 15u), dy = ey - (float)(l >> 4);
+                            v[0] += rc.x * g4.x; v[1] += rc.x * g4.y; v[2] += rc.x * g4.z; v[3] += rc.x * g4.w;
+                            v[9] += rc.y;
+                            const float gdx = rc.y * dx, gdy = rc.y * dy;
+                            sx += gdx; sy += gdy;
+                            v[6] += gdx * dx; v[7] += gdx * dy; v[8] += gdy * dy;
+                        }
+                        // dL_dG G = opacity * (G dL/dalpha): the common factor of the geometric terms (backward.cu:580-598)
+                        const float o = co.w;
+                        v[4] = -ddelx_dx * o * (co.x * sx + co.y * sy);
+                        v[5] = -ddely_dy * o * (co.z * sy + co.y * sx);
+                        v[6] *= -0.5f * o; v[7] *= -0.5f * o; v[8] *= -0.5f * o;
+                        // the four quarters of an entry sit in one quad: two DPP adds per value; the quad's first lane is
+                        // the only writer of this (strip, entry) row (ds_add_f32 costs ~60 LDS cycles per wave-instruction
+                        // plus ~2 per lane on this part -- ten of them per group were half of the kernel)
+#pragma unroll
+                        for (int k = 0; k < kAcc; k++) {
+                            v[k] += dpp_term<0xB1, 0xf, 0xf>(v[k]);   // quad_perm [1,0,3,2]
+                            v[k] += dpp_term<0x4E, 0xf, 0xf>(v[k]);   // quad_perm [2,3,0,1]
+                        }
+                        if (active && (lane & 3u) == 0) {
+                            float* dst = &s_acc[wave][(c + b) * kAcc];     // 8-byte aligned (40-byte rows)
+                            *reinterpret_cast<float2*>(dst + 0) = make_float2(v[0], v[1]);
+                            *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
+                            *reinterpret_cast<float2*>(dst + 4) = make_float2(v[4], v[5]);
+                            *reinterpret_cast<float2*>(dst + 6) = make_float2(v[6], v[7]);
+                            *reinterpret_cast<float2*>(dst + 8) = make_float2(v[8], v[9]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        // flush this round: the four strips' rows are added in a fixed order and stored as the row of list position
+        // range.y - 1 - (round_base + e): no atomics, one writer per row, bitwise reproducible
+        for (int e = tid; e < n; e += THREADS) {
+            float2* dst = reinterpret_cast<float2*>(acc + (size_t)(range.y - 1u - (uint32_t)(round_base + e)) * kAcc);
+#pragma unroll
+            for (int k = 0; k < kAcc; k += 2) {
+                float2 t = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    float2* src = reinterpret_cast<float2*>(&s_acc[w][e * kAcc + k]);
+                    const float2 u = *src;
+                    t.x += u.x; t.y += u.y;
+                    if (u.x != 0.f || u.y != 0.f) *src = make_float2(0.f, 0.f);
+                }
+                dst[k / 2] = t;
             }
         }
     }
@@ -546,34 +857,38 @@ __global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
 
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
-                           float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts)
+                           float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts,
+                           uint64_t* ballots, uint32_t R)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
     hipLaunchKernelGGL(render_forward_kernel, dim3(tiles_total), dim3(kTilePix), 0, s, W, H, (uint32_t)tiles_x,
                        (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D, g.conic_opacity, g.rgbd, bg,
-                       out_color, out_depth, out_alpha, n_contrib, pair_counts);
+                       out_color, out_depth, out_alpha, n_contrib, pair_counts, ballots, R);
 }
 
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const uint32_t* point_list, const GeomState& g, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                            const float* dL_dalphas, float* acc)
+                            const float* dL_dalphas, float* acc, const uint64_t* ballots, uint32_t R)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
-    // pixels per lane (GD_RASTER_BWD_PPL overrides, for tuning).  With the per-strip culling each wave of the
-    // PPL = 1 kernel walks only the entries that can reach ITS 16x4 strip; fatter lanes (PPL 2 / 4) share the
-    // per-entry reduction between strips but must walk the union of their strips' entries.  Measured at 8192
-    // tiles (8 views x 512^2, 100k Gaussians): 857 us (1) vs 889 (2) vs 911 (4).
-    int ppl = 1;
-    if (const char* e = getenv("GD_RASTER_BWD_PPL")) ppl = atoi(e);
-#define GD_BWD(PPL_)                                                                                               \
-    hipLaunchKernelGGL(render_backward_kernel<PPL_>, dim3(tiles_total), dim3(kTilePix / PPL_), 0, s, W, H,         \
-                       (uint32_t)tiles_x, (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D,           \
-                       g.conic_opacity, g.rgbd, bg, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc)
-    if (ppl == 4) GD_BWD(4);
-    else if (ppl == 2) GD_BWD(2);
-    else GD_BWD(1);
-#undef GD_BWD
+    // GD_RASTER_BWD_IMPL=tree selects the wave-uniform walk with the halving-tree reduction (round 1; kept for A/B
+    // measurements and as a second implementation the parity tests run); default: per-pixel lists.  Read once.
+    static const int impl = [] {
+        const char* e = getenv("GD_RASTER_BWD_IMPL");
+        return (e && e[0] == 't') ? 1 : 0;
+    }();
+    static const int ablate = [] { const char* e = getenv("GD_RASTER_BWD_ABLATE"); return e ? atoi(e) : 0; }();
+    if (impl == 1) {
+        hipLaunchKernelGGL(render_backward_kernel<1>, dim3(tiles_total), dim3(kTilePix), 0, s, W, H,
+                           (uint32_t)tiles_x, (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D,
+                           g.conic_opacity, g.rgbd, bg, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc);
+    } else {
+        hipLaunchKernelGGL((render_backward_lists_kernel<GD_BWD_ROUND, GD_BWD_CAP>), dim3(tiles_total), dim3(kTilePix), 0, s, W, H,
+                           (uint32_t)tiles_x, (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D,
+                           g.conic_opacity, g.rgbd, bg, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc,
+                           ballots, R, ablate);
+    }
 }
 
 }  // namespace gd

@@ -116,7 +116,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if not has_scales:  # outputs the kernel does not produce on this path stay defined (zeros)
         dL_dscales.zero_()
         dL_drotations.zero_()
-    scratch = torch.empty(L.gd_raster_backward_scratch_bytes(P, 1), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(L.gd_raster_backward_scratch_bytes(P, 1, int(R)), dtype=torch.uint8, device=dev)
     keep = [_f32c(t, dev) for t in (background, means3D, sh, colors, alphas, scales, rotations, cov3D_precomp,
                                     viewmatrix, projmatrix, campos, dL_dout_color, dL_dout_depth, dL_dout_alpha)]
     bg, m3, shc, col, alp, scl, rot, cov, vm, pm, cp, gcol, gdep, galp = keep
@@ -216,7 +216,7 @@ def rasterize_gaussians_backward_batched(background, means3D, radii, colors, sca
     if scales is None or scales.numel() == 0:
         dL_dscales.zero_()
         dL_drotations.zero_()
-    scratch = torch.empty(L.gd_raster_backward_scratch_bytes(P, V), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(L.gd_raster_backward_scratch_bytes(P, V, int(R)), dtype=torch.uint8, device=dev)
     keep = [_f32c(t, dev) for t in (background, means3D, sh, colors, alphas, scales, rotations, cov3D_precomp,
                                     viewmatrix, projmatrix, campos, dL_dout_color, dL_dout_depth, dL_dout_alpha)]
     bg, m3, shc, col, alp, scl, rot, cov, vm, pm, cp, gcol, gdep, galp = keep

@@ -35,6 +35,7 @@ SIGNATURES = {
     "gd_nn_conv_profile_enable": (_i, [_i]),
     "gd_nn_conv_profile_reset": (_i, []),
     "gd_nn_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "gd_nn_conv_profile_read_bytes": (_i, [C.POINTER(C.c_double)]),
     "gd_nn_geglu_forward": (_i, [_vp, _vp, _vp, C.c_int64, _i]),
     "gd_nn_add_layernorm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, C.c_int64, _i]),
     "gd_nn_attention_ws_bytes": (C.c_size_t, [_i, _i, _i]),
@@ -336,6 +337,13 @@ def conv_profile(enable=None, reset=False):
     ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
     L.gd_nn_conv_profile_read(C.byref(ms), C.byref(n), C.byref(fl))
     return ms.value, n.value, fl.value
+
+
+def conv_profile_bytes() -> float:
+    """Algorithmic HBM bytes (inputs + weights + outputs, each once) of the launches ``conv_profile`` has timed."""
+    b = C.c_double(0)
+    lib().gd_nn_conv_profile_read_bytes(C.byref(b))
+    return b.value
 
 
 class _GNConv3x3(torch.autograd.Function):

@@ -66,6 +66,7 @@ int gd_nn_conv_force_variant(int v);
 int gd_nn_conv_profile_enable(int on);
 int gd_nn_conv_profile_reset(void);
 int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_flops);
+int gd_nn_conv_profile_read_bytes(double* total_bytes);   /* algorithmic HBM bytes of the same launches */
 
 /* gd_nn_conv3x3_forward with a caller-provided scratch buffer: layers whose 128x128 tile grid cannot fill the
  * chip (small feature maps, one view per GPU) are split over the nine taps (3 or 9 workgroups per tile, fp32

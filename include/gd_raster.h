@@ -53,7 +53,7 @@ typedef char* (*gd_alloc_fn)(void* user, size_t bytes);
 size_t gd_raster_geom_bytes(int P, int V);
 size_t gd_raster_image_bytes(int width, int height, int V);
 size_t gd_raster_binning_bytes(int64_t R);
-size_t gd_raster_backward_scratch_bytes(int P, int V);
+size_t gd_raster_backward_scratch_bytes(int P, int V, int64_t R);   /* R = num_rendered of the forward call */
 
 /* Replaces CudaRasterizer::Rasterizer::forward (rasterizer.h:32-57,
  * rasterizer_impl.cu:197-339).  Returns num_rendered (the number of (Gaussian, tile)
@@ -72,7 +72,7 @@ int gd_raster_forward(void* stream, gd_alloc_fn geom_alloc, void* geom_user, gd_
  * rasterizer_impl.cu:343-446).  `alphas` is the forward's out_alpha (the fork reconstructs
  * T_final = 1 - alpha from it: DGR/cuda_rasterizer/backward.cu:463).  Outputs need NOT be
  * zeroed by the caller (the reference requires torch::zeros, rasterize_points.cu:155-164;
- * here every element is written).  bwd_scratch: gd_raster_backward_scratch_bytes(P, 1).
+ * here every element is written).  bwd_scratch: gd_raster_backward_scratch_bytes(P, 1, R).
  * dL_dmean2D[P,3] dL_dconic[P,2,2] dL_dopacity[P] dL_dcolor[P,3] dL_ddepth[P]
  * dL_dmean3D[P,3] dL_dcov3D[P,6] dL_dsh[P,M,3] dL_dscale[P,3] dL_drot[P,4]. */
 int gd_raster_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,

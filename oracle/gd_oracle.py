@@ -14,42 +14,53 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_OMP = None
 
 _f32p = C.POINTER(C.c_float)
 
 
-def build(force: bool = False) -> str:
-    so = os.path.join(_HERE, "libgd_oracle.so")
+def build(force: bool = False, omp: bool = False) -> str:
+    name = "libgd_oracle_omp.so" if omp else "libgd_oracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "gd_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "libgd_oracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", name])
     return so
 
 
-def lib():
-    global _LIB
+def lib(omp: bool = False):
+    """``omp=True``: the same C file built with -fopenmp (tiles over the host cores) -- bench.py's multi-core CPU
+    baseline; the parity tests use the serial, deterministic build."""
+    global _LIB, _LIB_OMP
+    if omp:
+        if _LIB_OMP is None:
+            _LIB_OMP = _bind(C.CDLL(build(omp=True)))
+        return _LIB_OMP
     if _LIB is None:
-        L = C.CDLL(build())
-        L.gdo_forward.restype = C.c_void_p
-        L.gdo_forward.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int] + [_f32p] * 5 + [
-            C.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float]
-        L.gdo_backward.restype = None
-        L.gdo_backward.argtypes = [C.c_void_p] + [_f32p] * 5 + [C.c_float] + [_f32p] * 5 + [C.c_float, C.c_float] + [
-            _f32p] * 13
-        L.gdo_free.argtypes = [C.c_void_p]
-        L.gdo_mark_visible.argtypes = [C.c_int, _f32p, _f32p, _f32p, C.POINTER(C.c_uint8)]
-        L.gdo_higher_msb.restype = C.c_uint32
-        L.gdo_higher_msb.argtypes = [C.c_uint32]
-        for n in ("num_rendered", "pairs_visited_fwd", "pairs_blended_fwd", "pairs_visited_bwd"):
-            getattr(L, "gdo_" + n).restype = C.c_int64
-            getattr(L, "gdo_" + n).argtypes = [C.c_void_p]
-        for n in ("depths", "clamped", "radii", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched",
-                  "point_offsets", "keys_unsorted", "vals_unsorted", "keys", "point_list", "ranges", "n_contrib",
-                  "out_color", "out_depth", "out_alpha"):
-            getattr(L, "gdo_" + n).restype = C.c_void_p
-            getattr(L, "gdo_" + n).argtypes = [C.c_void_p]
-        _LIB = L
+        _LIB = _bind(C.CDLL(build()))
     return _LIB
+
+
+def _bind(L):
+    L.gdo_forward.restype = C.c_void_p
+    L.gdo_forward.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int] + [_f32p] * 5 + [
+        C.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float]
+    L.gdo_backward.restype = None
+    L.gdo_backward.argtypes = [C.c_void_p] + [_f32p] * 5 + [C.c_float] + [_f32p] * 5 + [C.c_float, C.c_float] + [
+        _f32p] * 13
+    L.gdo_free.argtypes = [C.c_void_p]
+    L.gdo_mark_visible.argtypes = [C.c_int, _f32p, _f32p, _f32p, C.POINTER(C.c_uint8)]
+    L.gdo_higher_msb.restype = C.c_uint32
+    L.gdo_higher_msb.argtypes = [C.c_uint32]
+    for n in ("num_rendered", "pairs_visited_fwd", "pairs_blended_fwd", "pairs_visited_bwd"):
+        getattr(L, "gdo_" + n).restype = C.c_int64
+        getattr(L, "gdo_" + n).argtypes = [C.c_void_p]
+    for n in ("depths", "clamped", "radii", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched",
+              "point_offsets", "keys_unsorted", "vals_unsorted", "keys", "point_list", "ranges", "n_contrib",
+              "out_color", "out_depth", "out_alpha"):
+        getattr(L, "gdo_" + n).restype = C.c_void_p
+        getattr(L, "gdo_" + n).argtypes = [C.c_void_p]
+    return L
 
 
 def _f(a):
@@ -73,8 +84,9 @@ def _view(ptr, shape, dtype):
 class OracleState:
     """Forward result + every intermediate the reference keeps in its geom/binning/img buffers."""
 
-    def __init__(self, handle, P, M, W, H, keep):
-        L = lib()
+    def __init__(self, handle, P, M, W, H, keep, omp=False):
+        L = lib(omp)
+        self._omp = omp
         self._h = handle
         self._keep = keep  # inputs kept alive for backward
         self.P, self.M, self.W, self.H = P, M, W, H
@@ -107,14 +119,14 @@ class OracleState:
     def __del__(self):
         try:
             if self._h:
-                lib().gdo_free(self._h)
+                lib(self._omp).gdo_free(self._h)
                 self._h = None
         except Exception:
             pass
 
 
 def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-            projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos) -> OracleState:
+            projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos, omp: bool = False) -> OracleState:
     """Same argument meaning as ``_C.rasterize_gaussians`` (DGR/rasterize_points.cu:35-56)."""
     means3D = np.ascontiguousarray(means3D, dtype=np.float32)
     P = means3D.shape[0]
@@ -125,12 +137,12 @@ def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_mod
     for name, arr in dict(bg=bg, means3D=means3D, sh=sh_a, colors=colors_precomp, opac=opacities, scales=scales,
                           rot=rotations, cov=cov3D_precomp, view=viewmatrix, proj=projmatrix, campos=campos).items():
         keep[name], ptr[name] = _f(arr)
-    h = lib().gdo_forward(P, int(degree), M, ptr["bg"], int(image_width), int(image_height), ptr["means3D"],
+    h = lib(omp).gdo_forward(P, int(degree), M, ptr["bg"], int(image_width), int(image_height), ptr["means3D"],
                           ptr["sh"], ptr["colors"], ptr["opac"], ptr["scales"], float(scale_modifier), ptr["rot"],
                           ptr["cov"], ptr["view"], ptr["proj"], ptr["campos"], float(tanfovx), float(tanfovy))
     keep["ptr"] = ptr
     keep["args"] = dict(scale_modifier=float(scale_modifier), tanfovx=float(tanfovx), tanfovy=float(tanfovy))
-    return OracleState(h, P, M, int(image_width), int(image_height), keep)
+    return OracleState(h, P, M, int(image_width), int(image_height), keep, omp)
 
 
 def backward(st: OracleState, dL_dcolor, dL_ddepth, dL_dalpha) -> dict:
@@ -146,12 +158,12 @@ def backward(st: OracleState, dL_dcolor, dL_ddepth, dL_dalpha) -> dict:
                dL_dcov3D=np.zeros((P, 6), np.float32), dL_dsh=np.zeros((P, max(M, 0), 3), np.float32),
                dL_dscales=np.zeros((P, 3), np.float32), dL_drotations=np.zeros((P, 4), np.float32))
     op = {n: v.ctypes.data_as(_f32p) for n, v in out.items()}
-    lib().gdo_backward(st._h, p["bg"], p["means3D"], p["sh"], p["colors"], p["scales"], a["scale_modifier"],
+    lib(st._omp).gdo_backward(st._h, p["bg"], p["means3D"], p["sh"], p["colors"], p["scales"], a["scale_modifier"],
                        p["rot"], p["cov"], p["view"], p["proj"], p["campos"], a["tanfovx"], a["tanfovy"], gcp, gdp,
                        gap, op["dL_dmeans2D"], op["dL_dconic"], op["dL_dopacity"], op["dL_dcolors"],
                        op["dL_ddepths"], op["dL_dmeans3D"], op["dL_dcov3D"], op["dL_dsh"], op["dL_dscales"],
                        op["dL_drotations"])
-    st.pairs_visited_bwd = int(lib().gdo_pairs_visited_bwd(st._h))
+    st.pairs_visited_bwd = int(lib(st._omp).gdo_pairs_visited_bwd(st._h))
     return out
 
 

@@ -33,10 +33,10 @@ def main():
         unet = sd21.init_random_(sd21.UNet2DConditionModel(block_out_channels=(64, 128, 256, 256),
                                                            attention_head_dim=(1, 2, 4, 4)))
         vae = sd21.init_random_(sd21.AutoencoderKLEncoder(block_out_channels=(32, 64, 128, 128)), 1)
-    # guidance_scale 7.5: at the pipeline's 100 the bf16 rounding of eps_text - eps_uncond (which depends on the
-    # batch composition: 4 vs 8 UNet samples pick different GEMM tiles) would dominate the comparison
-    guidance = StableDiffusionGuidance({"guidance_scale": 7.5, "grad_clip": [0, 1.5, 2.0, 1000]}, device=dev,
-                                       unet=unet, vae=vae)
+    # fp32 UNet / VAE (torch ops): bf16 results depend on the batch composition (4 vs 8 UNet samples pick different
+    # GEMM / conv tiles), which would blur a test whose subject is the sharded rasterizer + collectives + Adam path
+    guidance = StableDiffusionGuidance({"guidance_scale": 7.5, "grad_clip": [0, 1.5, 2.0, 1000],
+                                        "half_precision_weights": False}, device=dev, unet=unet, vae=vae)
     gm = GaussianModel.from_activated(synthetic_gaussians(P, seed=2), device=dev)
     loop = SDSLoop(gm, guidance, PromptEmbeddings.random(dev), torch.ones(3, device=dev), densify_seed=123)
     loop.global_step = FIRST_STEP

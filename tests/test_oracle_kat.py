@@ -244,3 +244,22 @@ def test_gradient_shapes_and_zero_rows_for_culled():
     for name in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dmeans2D"):
         assert np.abs(g[name][culled]).sum() == 0, name
     assert g["dL_dmeans2D"].shape == (200, 3) and np.abs(g["dL_dmeans2D"][:, 2]).sum() == 0
+
+
+def test_openmp_build_of_the_oracle_matches_the_serial_build():
+    """bench.py's multi-core CPU baseline is the same C file built with -fopenmp (tiles over cores): forward outputs
+    bit-identical, backward sums equal up to the fp64 atomic order."""
+    inp = h.raster_inputs(P=3000, H=96, W=112, seed=5)
+    a = h.oracle_forward(inp)
+    b = gd_oracle.forward(inp["bg"], inp["means3D"], inp["colors_precomp"], inp["opacities"], inp["scales"],
+                          inp["rotations"], inp["scale_modifier"], inp["cov3D_precomp"], inp["viewmatrix"],
+                          inp["projmatrix"], inp["tanfovx"], inp["tanfovy"], inp["image_height"], inp["image_width"],
+                          inp["sh"], inp["degree"], inp["campos"], omp=True)
+    for k in ("color", "depth", "alpha", "n_contrib", "point_list", "ranges", "radii"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert a.pairs_visited_fwd == b.pairs_visited_fwd and a.pairs_blended_fwd == b.pairs_blended_fwd
+    gc, gd, ga = h.random_image_grads(96, 112)
+    ra, rb = gd_oracle.backward(a, gc, gd, ga), gd_oracle.backward(b, gc, gd, ga)
+    assert a.pairs_visited_bwd == b.pairs_visited_bwd
+    for k in ra:
+        np.testing.assert_allclose(rb[k], ra[k], rtol=1e-5, atol=1e-7 * (np.abs(ra[k]).max() + 1e-30))

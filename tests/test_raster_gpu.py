@@ -381,7 +381,7 @@ def test_inactive_sh_bands_get_exact_zero_gradient(deg):
     from garmentdreamer_amd.diff_gaussian_rasterization import _C
     from oracle import gd_oracle
     HW, P = 96, 3000
-    inp = h.raster_inputs(P=P, H=HW, W=HW, sh_degree=3, seed=40 + deg)
+    inp = h.raster_inputs(P=P, H=HW, W=HW, sh_degree=3, seed=40 + deg, distance=0.7)   # camera inside the ball
     inp["degree"] = deg
     st = h.oracle_forward(inp)
     gc, gd, ga = h.random_image_grads(HW, HW, seed=deg)

@@ -1,28 +1,28 @@
 #!/bin/bash
-# PMC counters for the rasterizer render kernels (separate pass from timing; --pmc with --kernel-trace only).
-# usage: tools/pmc_raster.sh <outdir> [extra env like GD_RASTER_BWD_PPL=4]
-out=$1; shift
+# SQ counters of the rasterizer's render kernels on the benchmark workload (raster-only, 8 views x 512^2, 100k):
+#   tools/pmc_raster.sh <out.txt>   [env GD_RASTER_BWD_IMPL / GD_RASTER_BWD_ABLATE are passed through]
+out=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p $out
-for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM" \
-           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-  tag=$(echo $grp | cut -d' ' -f1)
-  env "$@" rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_$tag -o pmc -- python bench.py --raster-only --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pmc_$tag.log 2>&1
-  python - "$tag" "$out" <<'PY'
-import csv, sys, glob, collections
-tag, out = sys.argv[1], sys.argv[2]
-f = glob.glob(f"/tmp/pmc_{tag}/**/*counter_collection.csv", recursive=True)
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-for row in csv.DictReader(open(f[0])):
-    k = row["Kernel_Name"]
-    if "render_" not in k: continue
-    k = "render_backward" if "backward" in k else "render_forward"
-    agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); 
-    cnt[(k,row["Counter_Name"])] += 1
-with open(f"{out}/pmc_{tag}.txt","w") as o:
-    for k in agg:
-        for c,v in agg[k].items():
-            line=f"{k} {c} per_launch {v/cnt[(k,c)]:.4g}"
-            print(line); o.write(line+"\n")
+: > $out
+i=0
+for g in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
+         "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES" \
+         "FETCH_SIZE" "WRITE_SIZE"; do
+  rm -rf /tmp/pmcr_$i
+  rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmcr_$i -o pmc -- python bench.py --raster-only --no-cpu-baseline --steps 3 --warmup 1 > /tmp/pmcr_$i.log 2>&1
+  python - /tmp/pmcr_$i >> $out <<'PY'
+import csv, glob, sys, collections
+agg = collections.defaultdict(float); cnt = collections.Counter()
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        key = "render_backward" if "render_backward" in k else ("render_forward" if "render_forward" in k else None)
+        if key is None: continue
+        agg[(key, row["Counter_Name"])] += float(row["Counter_Value"]); cnt[(key, row["Counter_Name"])] += 1
+for (k, c), v in sorted(agg.items()):
+    print(f"{k:18s} {c:24s} {v / cnt[(k, c)]:16.1f} per launch ({cnt[(k, c)]} launches)")
 PY
+  i=$((i+1))
 done
+cat $out

@@ -9,5 +9,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -o bench
 st=$(find /tmp/prof_final -name "*kernel_stats.csv" | head -1); tr=$(find /tmp/prof_final -name "*kernel_trace.csv" | head -1)
 cp "$st" $out/bench_N1_kernel_stats_whole_process.csv
 python tools/steady_stats.py "$tr" $out/bench_N1_kernel_stats_steady.csv --skip 2
-bash tools/pmc_traffic.sh $out/pmc_traffic.json --steps 2 --warmup 1 > /dev/null 2>&1
+bash tools/pmc_all.sh $out/pmc.json > /dev/null 2> $out/pmc_passes.log
 ls -la $out
