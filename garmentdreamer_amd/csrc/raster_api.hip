@@ -128,6 +128,7 @@ BinningState carve_binning(char* chunk, size_t R, size_t* used)
     BinningState b;
     obtain(p, b.point_list, R);
     obtain(p, b.point_list_alt, R);
+    obtain(p, b.slot_vp, R);
     obtain(p, b.keys, R);
     obtain(p, b.keys_alt, R);
     const size_t nblk = (R + kSortTile - 1) / kSortTile;
@@ -230,11 +231,12 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     const bool start_in_alt = (plan.passes & 1) != 0;
     { ProfScope ps(stream, GD_K_DUPLICATE);
     launch_duplicate(stream, (int)VP, P, radii, geom, start_in_alt ? bin.keys_alt : bin.keys,
-                     start_in_alt ? bin.point_list_alt : bin.point_list, dm.tiles_x, dm.tiles_y); }
+                     start_in_alt ? bin.point_list_alt : bin.point_list, bin.slot_vp, dm.tiles_x, dm.tiles_y); }
     if (int e = check_debug(stream, debug, "duplicate")) return e;
     { ProfScope ps(stream, GD_K_SORT); launch_radix_sort(stream, bin, num_rendered, plan, start_in_alt); }
     if (int e = check_debug(stream, debug, "sort")) return e;
-    { ProfScope ps(stream, GD_K_RANGES); launch_tile_ranges(stream, bin.keys, num_rendered, img.ranges, dm.tiles_total); }
+    { ProfScope ps(stream, GD_K_RANGES); launch_tile_ranges(stream, bin.keys, num_rendered, img.ranges, dm.tiles_total, bin.point_list,
+                                                          bin.slot_vp, bin.point_list_alt); }
     if (int e = check_debug(stream, debug, "ranges")) return e;
     { ProfScope ps(stream, GD_K_RENDER_FWD);
     launch_render_forward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
@@ -269,20 +271,23 @@ int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const f
     ImageState img = carve_image(image_buffer, dm.tiles_total, dm.pixels_total, nullptr);
     if (radii == nullptr) radii = geom.radii;
 
-    // backward scratch: one 10-float row per list position (written, never accumulated) + the inverse permutation
+    // backward scratch: one 10-float row per (instance slot, strip) -- stored where the strip's ballot is non-zero,
+    // never accumulated -- and a flag byte per row
     float* inst = nullptr;
-    uint32_t* inv = nullptr;
+    uint8_t* flags = nullptr;
+    float* acc = nullptr;     // [VP][10]: the rows of each (view, Gaussian) added up (instance_sum_kernel)
     {
         char* p = bwd_scratch;
-        obtain(p, inst, (size_t)R * 10);
-        obtain(p, inv, (size_t)R);
+        obtain(p, inst, (size_t)R * 40);
+        obtain(p, flags, (size_t)R * 4);
+        obtain(p, acc, VP * 10);
     }
+    GD_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));
     if (R > 0) {
         { ProfScope ps(stream, GD_K_RENDER_BWD);
         launch_render_backward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
-                               alphas, img.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, inst, bin.ballots, (uint32_t)R); }
-        ProfScope ps(stream, GD_K_PREPROCESS_BWD);
-        launch_instance_slots(stream, (uint32_t)R, P, bin.keys, bin.point_list, radii, geom, dm.tiles_x, dm.tiles_y, inv);
+                               alphas, img.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, inst, flags, bin.ballots,
+                               bin.point_list_alt /* slot_of */); }
     }
     if (int e = check_debug(stream, debug, "render backward")) return e;
 
@@ -290,8 +295,9 @@ int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const f
     const size_t cov_stride = cov3D_precomp ? 0 : (size_t)P * 6;
     { ProfScope ps(stream, GD_K_PREPROCESS_BWD);
     launch_preprocess_backward(stream, P, D, M, V, means3D, radii, shs, geom.clamped, scales, rotations,
-                               scale_modifier, cov3D, cov_stride, viewmatrix, projmatrix, campos, vs, inst, inv,
-                               geom.point_offsets, geom.tiles_touched, colors_precomp != nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth,
+                               scale_modifier, cov3D, cov_stride, viewmatrix, projmatrix, campos, vs, inst, flags,
+                               geom.point_offsets, geom.tiles_touched, acc, colors_precomp != nullptr, dL_dmean2D, dL_dconic,
+                               dL_dopacity, dL_dcolor, dL_ddepth,
                                dL_dmean3D, dL_dcov3D, shs ? dL_dsh : nullptr, scales ? dL_dscale : nullptr,
                                scales ? dL_drot : nullptr, nullptr); }
     if (int e = check_debug(stream, debug, "preprocess backward")) return e;
@@ -328,9 +334,8 @@ size_t gd_raster_binning_bytes(int64_t R)
 }
 size_t gd_raster_backward_scratch_bytes(int P, int V, int64_t R)
 {
-    (void)P; (void)V;
     const size_t r = (size_t)(R < 0 ? 0 : R);
-    return r * 10 * sizeof(float) + r * sizeof(uint32_t) + 384;
+    return r * 40 * sizeof(float) + r * 4 + (size_t)P * (size_t)(V < 1 ? 1 : V) * 10 * sizeof(float) + 512;
 }
 
 int gd_raster_forward(void* stream, gd_alloc_fn geom_alloc, void* geom_user, gd_alloc_fn binning_alloc,

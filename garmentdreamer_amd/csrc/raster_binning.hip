@@ -75,8 +75,8 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
 
 __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, const int* __restrict__ radii,
                                                                 GeomState gs, uint64_t* __restrict__ keys_out,
-                                                                uint32_t* __restrict__ vals_out, uint32_t gx,
-                                                                uint32_t gy)
+                                                                uint32_t* __restrict__ vals_out,
+                                                                uint32_t* __restrict__ slot_vp, uint32_t gx, uint32_t gy)
 {
     __shared__ uint32_t wave_incl[kGaussBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,32 +109,14 @@ __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, c
                 key <<= 32;
                 key |= depth_bits;
                 keys_out[off] = key;
-                vals_out[off] = (uint32_t)vp;
+                // the sort carries the instance's SLOT (its index here), not the Gaussian: the backward blend stores its
+                // per-instance rows BY SLOT, so that a Gaussian's rows are contiguous and can be added without atomics;
+                // the Gaussian of a slot is kept in slot_vp (tile_ranges_kernel turns point_list into Gaussian ids)
+                vals_out[off] = off;
+                if (slot_vp) slot_vp[off] = (uint32_t)vp;
                 off++;
             }
     }
-}
-
-// Sorted position -> the slot duplicate_kernel gave the instance (its Gaussian's offset + the tile's index inside the
-// Gaussian's tile rectangle), inverted: inv[slot] = sorted position.  With it the backward pass needs no atomics: the
-// blend kernel stores one row per list position and preprocess_backward_kernel gathers each Gaussian's rows in a fixed
-// order (deterministic gradients; the reference's 10 atomicAdd per pair, backward.cu:555-598, become 0).
-__global__ __launch_bounds__(256) void instance_slots_kernel(uint32_t R, int P, const uint64_t* __restrict__ keys,
-                                                             const uint32_t* __restrict__ point_list,
-                                                             const int* __restrict__ radii, GeomState gs, uint32_t gx,
-                                                             uint32_t gy, uint32_t* __restrict__ inv)
-{
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    if (s >= R) return;
-    const uint32_t vp = point_list[s];
-    const uint32_t tile = (uint32_t)(keys[s] >> 32);
-    const uint32_t lt = tile - (vp / (uint32_t)P) * gx * gy;
-    const uint32_t ty = lt / gx, tx = lt - ty * gx;
-    const float2 xy = gs.means2D[vp];
-    uint32_t x0, y0, x1, y1;
-    tile_rect(xy.x, xy.y, radii[vp], gx, gy, x0, y0, x1, y1);
-    const uint32_t first = gs.point_offsets[vp] - gs.tiles_touched[vp];
-    inv[first + (ty - y0) * (x1 - x0) + (tx - x0)] = s;
 }
 
 // ---------------- radix sort ----------------
@@ -286,10 +268,17 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
     }
 }
 
-__global__ void tile_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t L, uint2* __restrict__ ranges)
+__global__ void tile_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t L, uint2* __restrict__ ranges,
+                                   uint32_t* __restrict__ point_list, const uint32_t* __restrict__ slot_vp,
+                                   uint32_t* __restrict__ slot_of)
 {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L) return;
+    if (slot_vp) {   // the sort's epilogue: the payload (slot) moves aside, point_list becomes the Gaussian ids
+        const uint32_t slot = point_list[idx];
+        slot_of[idx] = slot;
+        point_list[idx] = slot_vp[slot];
+    }
     const uint32_t cur = (uint32_t)(keys[idx] >> 32);
     if (idx == 0) ranges[cur].x = 0;
     else {
@@ -323,11 +312,11 @@ void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblock
 }
 
 void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* keys_out,
-                      uint32_t* vals_out, int tiles_x, int tiles_y)
+                      uint32_t* vals_out, uint32_t* slot_vp, int tiles_x, int tiles_y)
 {
     const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
     hipLaunchKernelGGL(duplicate_kernel, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, keys_out, vals_out,
-                       (uint32_t)tiles_x, (uint32_t)tiles_y);
+                       slot_vp, (uint32_t)tiles_x, (uint32_t)tiles_y);
 }
 
 // Sorts (keys, vals) of length R on the low plan.total_bits bits.  The unsorted input sits in
@@ -354,18 +343,13 @@ void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan,
     }
 }
 
-void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total)
+void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total,
+                        uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of)
 {
     (void)hipMemsetAsync(ranges, 0, (size_t)tiles_total * sizeof(uint2), s);
-    if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges);
-}
-
-void launch_instance_slots(hipStream_t s, uint32_t R, int P, const uint64_t* keys, const uint32_t* point_list,
-                           const int* radii, const GeomState& g, int tiles_x, int tiles_y, uint32_t* inv)
-{
-    if (R == 0) return;
-    hipLaunchKernelGGL(instance_slots_kernel, dim3((R + 255u) / 256u), dim3(256), 0, s, R, P, keys, point_list, radii, g,
-                       (uint32_t)tiles_x, (uint32_t)tiles_y, inv);
+    if (R > 0)
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges, point_list,
+                           slot_vp, slot_of);
 }
 
 }  // namespace gd

@@ -40,12 +40,14 @@ struct ImageState {
     uint2* pair_counts;   // [V*H*W] {visited, blended} per pixel (work accounting for the roofline)
 };
 struct BinningState {
-    uint32_t* point_list;      // [R] sorted values (vp indices)
-    uint32_t* point_list_alt;  // [R]
+    uint32_t* point_list;      // [R] sort payload = instance SLOT (see slot_vp); after tile_ranges: the Gaussian (vp) ids
+    uint32_t* point_list_alt;  // [R] ping-pong buffer of the sort; after tile_ranges: slot_of[list position]
+    uint32_t* slot_vp;         // [R] Gaussian (vp) of instance slot o; the slots of Gaussian vp are
+                               // point_offsets[vp] - tiles_touched[vp] ... point_offsets[vp] - 1 (duplicate_kernel)
     uint64_t* keys;            // [R] sorted keys
     uint64_t* keys_alt;        // [R]
     uint32_t* sort_hist;       // [bins * nblk + bins]
-    uint64_t* ballots;         // [4][R] per (16x4 strip of the tile, list position): which of the strip's 64 pixels
+    uint64_t* ballots;         // [R][4] per (list position, 16x4 strip of its tile): which of the strip's 64 pixels
                                // BLENDED the entry in the forward pass (written by render_forward, read by the
                                // backward blend: the reverse pass never repeats the contribution test)
 };
@@ -82,17 +84,20 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
                                 const float* shs, const uint8_t* clamped, const float* scales,
                                 const float* rotations, float scale_modifier, const float* cov3D,
                                 size_t cov3D_view_stride, const float* viewmatrix, const float* projmatrix,
-                                const float* campos, const ViewScalars& vs, const float* inst /*[R][10]*/,
-                                const uint32_t* inv /*[R]*/, const uint32_t* point_offsets, const uint32_t* tiles_touched,
+                                const float* campos, const ViewScalars& vs, const float* rows4 /*[R][4][10] by slot*/,
+                                const uint8_t* flags /*[R][4]*/, const uint32_t* point_offsets,
+                                const uint32_t* tiles_touched, float* acc /*[VP][10] scratch, fully written*/,
                                 bool colors_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                                 float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
                                 float* dL_dsh, float* dL_dscale, float* dL_drot, float* view_partials);
 
 void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks);
 void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* keys_out,
-                      uint32_t* vals_out, int tiles_x, int tiles_y);
+                      uint32_t* vals_out, uint32_t* slot_vp, int tiles_x, int tiles_y);
 void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan, bool start_in_alt);
-void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total);
+// identifyTileRanges + the sort's epilogue: slot_of[s] = point_list[s] (the slot), point_list[s] = its Gaussian id
+void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total,
+                        uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of);
 
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
@@ -101,11 +106,10 @@ void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int 
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const uint32_t* point_list, const GeomState& g, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                            const float* dL_dalphas, float* inst /*[R][10]: one row per list position, all written*/,
-                            const uint64_t* ballots, uint32_t R);
-// inv[o] = sorted list position of instance o (o = the slot duplicate_kernel wrote it to: instances of Gaussian vp are
-// point_offsets[vp] - tiles_touched[vp] ... point_offsets[vp] - 1): lets a per-Gaussian thread GATHER its rows.
-void launch_instance_slots(hipStream_t s, uint32_t R, int P, const uint64_t* keys, const uint32_t* point_list,
-                           const int* radii, const GeomState& g, int tiles_x, int tiles_y, uint32_t* inv);
+                            const float* dL_dalphas,
+                            float* rows4 /*[R][4][10] by instance SLOT: one row per (slot, strip) with a non-zero ballot*/,
+                            uint8_t* flags /*[R][4], zeroed: 1 where a row was stored*/, const uint64_t* ballots,
+                            const uint32_t* slot_of);
+
 
 }  // namespace gd

@@ -326,19 +326,75 @@ __device__ void sh_backward(int g, size_t vp, int deg, int M, const float* __res
     dmean[2] = (-v[0] * v[2] * ddir[0] - v[1] * v[2] * ddir[1] + (sum2 - v[2] * v[2]) * ddir[2]) * invsum32;
 }
 
+// acc[vp][10] = sum of the rows rows4[slot][strip][10] the backward blend stored for the instance slots of (view,
+// Gaussian) vp -- one slot per tile the splat touches, contiguous: point_offsets[vp] - tiles_touched[vp] ... -- where
+// flags[slot][strip] is set, added in (slot, strip) order: deterministic, no atomics.  One thread per vp takes up to
+// kOwnSlots slots itself; the few splats that cover more tiles are finished by the whole wave (64 slots per step +
+// a butterfly sum), so that one large splat does not hold 63 idle lanes for hundreds of dependent loads.
+constexpr uint32_t kOwnSlots = 8;
+
+__device__ __forceinline__ void add_slot_rows(const float* __restrict__ rows4, const uint8_t* __restrict__ flags,
+                                              uint32_t o, float a[10])
+{
+    const uint32_t f4 = *reinterpret_cast<const uint32_t*>(flags + 4 * (size_t)o);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (!((f4 >> (8 * w)) & 0xffu)) continue;
+        const float2* row = reinterpret_cast<const float2*>(rows4 + 10 * (4 * (size_t)o + w));
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float2 t = row[k];
+            a[2 * k] += t.x; a[2 * k + 1] += t.y;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void instance_sum_kernel(uint32_t VP, const int* __restrict__ radii,
+                                                           const uint32_t* __restrict__ point_offsets,
+                                                           const uint32_t* __restrict__ tiles_touched,
+                                                           const float* __restrict__ rows4,
+                                                           const uint8_t* __restrict__ flags, float* __restrict__ acc)
+{
+    const uint32_t vp = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool vis = vp < VP && radii[vp] > 0;
+    const uint32_t end = vis ? point_offsets[vp] : 0u;
+    const uint32_t n = vis ? tiles_touched[vp] : 0u;
+    const uint32_t first = end - n;
+    float a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t own_end = first + min(n, kOwnSlots);
+    for (uint32_t o = first; o < own_end; o++) add_slot_rows(rows4, flags, o, a);
+    for (uint64_t big = __builtin_amdgcn_ballot_w64(n > kOwnSlots); big; big &= big - 1) {
+        const int src = (int)__builtin_ctzll(big);
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)own_end, src);
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)end, src);
+        float part[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t o = f + lane; o < e; o += 64u) add_slot_rows(rows4, flags, o, part);
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part[k] += __shfl_xor(part[k], off, 64);
+            if ((int)lane == src) a[k] += part[k];
+        }
+    }
+    if (vp < VP) {
+        float2* dst = reinterpret_cast<float2*>(acc + 10 * (size_t)vp);
+#pragma unroll
+        for (int k = 0; k < 5; k++) dst[k] = make_float2(a[2 * k], a[2 * k + 1]);
+    }
+}
+
 // One thread per Gaussian; loops over the V views so that every output element is written
 // exactly once, in a fixed order (deterministic, no pre-zeroing, no atomics).
-// {dL_dcolor.rgb, dL_ddepth, dL_dmean2D.xy, dL_dconic.x/.y/.w, dL_dopacity} of (view, Gaussian) = the sum of the
-// rows inst[s][10] the backward render kernel stored for the Gaussian's list positions s = inv[slot], gathered here
-// in slot order (the reference accumulates the same terms with atomicAdd, backward.cu:555-598).
+// acc[vp][10] = {dL_dcolor.rgb, dL_ddepth, dL_dmean2D.xy, dL_dconic.x/.y/.w, dL_dopacity} of (view, Gaussian), summed
+// over the Gaussian's tiles by instance_sum_kernel (the reference accumulates the same terms with atomicAdd,
+// backward.cu:555-598).
 __global__ __launch_bounds__(kGaussBlock) void preprocess_backward_kernel(
     int P, int D, int M, const float* __restrict__ means3D, const int* __restrict__ radii,
     const float* __restrict__ shs, const uint8_t* __restrict__ clamped, const float* __restrict__ scales,
     const float* __restrict__ rotations, float scale_modifier, const float* __restrict__ cov3D,
     size_t cov3D_view_stride, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
-    const float* __restrict__ campos, ViewScalars vs, const float* __restrict__ inst,
-    const uint32_t* __restrict__ inv, const uint32_t* __restrict__ point_offsets,
-    const uint32_t* __restrict__ tiles_touched, bool has_colors_precomp,
+    const float* __restrict__ campos, ViewScalars vs, const float* __restrict__ acc, bool has_colors_precomp,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dcolor, float* __restrict__ dL_ddepth, float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
@@ -353,18 +409,7 @@ __global__ __launch_bounds__(kGaussBlock) void preprocess_backward_kernel(
     for (int v = 0; v < vs.V; v++) {
         const size_t vp = (size_t)v * P + g;
         const bool vis = radii[vp] > 0;
-        float a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (vis) {
-            const uint32_t end = point_offsets[vp], first = end - tiles_touched[vp];
-            for (uint32_t o = first; o < end; o++) {
-                const float2* row = reinterpret_cast<const float2*>(inst + 10 * (size_t)inv[o]);
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const float2 t = row[k];
-                    a[2 * k] += t.x; a[2 * k + 1] += t.y;
-                }
-            }
-        }
+        const float* a = acc + 10 * vp;
         // per-view outputs (exist for parity with the reference's intermediates)
         if (dL_dmean2D) {
             dL_dmean2D[3 * vp] = vis ? a[4] : 0.f; dL_dmean2D[3 * vp + 1] = vis ? a[5] : 0.f;
@@ -551,17 +596,19 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
                                 const float* shs, const uint8_t* clamped, const float* scales,
                                 const float* rotations, float scale_modifier, const float* cov3D,
                                 size_t cov3D_view_stride, const float* viewmatrix, const float* projmatrix,
-                                const float* campos, const ViewScalars& vs, const float* inst, const uint32_t* inv,
-                                const uint32_t* point_offsets, const uint32_t* tiles_touched, bool colors_precomp,
+                                const float* campos, const ViewScalars& vs, const float* rows4, const uint8_t* flags,
+                                const uint32_t* point_offsets, const uint32_t* tiles_touched, float* acc,
+                                bool colors_precomp,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                                 float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                                 float* dL_dscale, float* dL_drot, float* /*unused*/)
 {
-    (void)V;
+    const uint32_t VP = (uint32_t)V * (uint32_t)P;
+    hipLaunchKernelGGL(instance_sum_kernel, dim3((VP + 255u) / 256u), dim3(256), 0, s, VP, radii, point_offsets,
+                       tiles_touched, rows4, flags, acc);
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + kGaussBlock - 1) / kGaussBlock), dim3(kGaussBlock), 0,
                        s, P, D, M, means3D, radii, shs, clamped, scales, rotations, scale_modifier, cov3D,
-                       cov3D_view_stride, viewmatrix, projmatrix, campos, vs, inst, inv, point_offsets, tiles_touched,
-                       colors_precomp, dL_dmean2D,
+                       cov3D_view_stride, viewmatrix, projmatrix, campos, vs, acc, colors_precomp, dL_dmean2D,
                        dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                        dL_drot);
 }

@@ -29,9 +29,8 @@
 
 #include "raster_common.h"
 
-#ifndef GD_BWD_ROUND
-#define GD_BWD_ROUND 128
-#define GD_BWD_CAP 512
+#ifndef GD_BWD_CAP
+#define GD_BWD_CAP 512   // records (contributing pairs) a strip buffers per group of 64 list entries
 #endif
 #ifndef GD_ABLATE
 #define GD_ABLATE 0   // 1: skip the cross-lane reduction + LDS atomics (timing ablation only; wrong results)
@@ -246,6 +245,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     // saturates at entry g, then g + 1
     uint32_t contributor = (uint32_t)total, last_contributor = 0, blended = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f;
+    uint32_t ballots_written = 0;   // list positions [0, ballots_written) of this wave's strip have their ballot stored
 
     for (int i = 0; i < rounds; i++, toDo -= kTilePix) {
         if (__syncthreads_count(done) == kTilePix) break;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
             // 64 entries' strip bits -> one scalar bitmap of the entries this wave must look at
             uint64_t bits = __builtin_amdgcn_ballot_w64(((s_mask[c + lane] >> wave) & 1u) != 0);
             // lane l collects, for list entry c + l, the ballot of the strip's pixels that BLEND it: the backward pass
-            // walks exactly these (pixel, entry) pairs (ballots[strip][list position]; zero = nobody, also for the
+            // walks exactly these (pixel, entry) pairs (ballots[list position][strip]; zero = nobody, also for the
             // entries the strip culling or an early exit never looked at)
             uint32_t wb_lo = 0, wb_hi = 0;
             while (bits) {
@@ -319,9 +319,13 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
                 }
             }
             if (c + (int)lane < n)
-                ballots[(size_t)wave * R + (range.x + cbase + (uint32_t)c + lane)] = ((uint64_t)wb_hi << 32) | wb_lo;
+                ballots[(size_t)(range.x + cbase + (uint32_t)c + lane) * 4u + wave] = ((uint64_t)wb_hi << 32) | wb_lo;
+            ballots_written = min((uint32_t)total, cbase + (uint32_t)c + 64u);
         }
     }
+    // the entries this wave never looked at (its pixels saturated earlier) blend nothing: every (position, strip) word
+    // of the tile is defined, the backward pass and its per-Gaussian gather rely on it
+    for (uint32_t p = ballots_written + lane; p < (uint32_t)total; p += 64u) ballots[(size_t)(range.x + p) * 4u + wave] = 0;
     if (inside) {
         n_contrib[(size_t)view * HW + pix_id] = last_contributor;
         pair_counts[(size_t)view * HW + pix_id] = make_uint2(contributor, blended);
@@ -347,234 +351,8 @@ __device__ __forceinline__ void zero_rows(float* __restrict__ inst, uint32_t fir
     for (uint32_t i = tid; i < count * (kAcc / 2); i += threads) p[i] = make_float2(0.f, 0.f);
 }
 
-// Per-pixel state of the reverse walk (backward.cu:461-487).
-struct PixState {
-    float T, T_final, last_alpha, last_c0, last_c1, last_c2, last_depth;
-    float accum_rec0, accum_rec1, accum_rec2, accum_depth_rec, accum_alpha_rec;
-    float dLp0, dLp1, dLp2, dLpd, dLa, bg_dot;
-    float pixf_y;
-    uint32_t last_contributor;
-};
-
-// PPL = pixels per lane.  A 16x16 tile is handled by 256/PPL threads (4/PPL wave64s); lane l owns
-// column l&15 and rows (l>>4) + 4*k' ... so that the per-entry cross-lane reduction (the dominant
-// cost at PPL = 1: ablating it halves the kernel time) is paid once per PPL pixels: the lane first
-// sums its own pixels' partials in registers.  PPL = 4 -> one wave per tile, no cross-wave
-// combine; used when the launch has enough tiles to fill the chip (batched multi-view).
-template <int PPL>
-__global__ __launch_bounds__(kTilePix / PPL) void render_backward_kernel(
-    int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
-    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
-    const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-    const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ acc)
-{
-    constexpr int THREADS = kTilePix / PPL;
-    constexpr int WAVES = THREADS / 64;
-    constexpr int ROWS_PER_PASS = THREADS / 16;   // tile rows covered by one pixel slot of all threads
-    constexpr int ROUND = THREADS;                // list entries staged per round (keeps LDS per wave constant)
-    __shared__ float2 s_xy[ROUND];
-    __shared__ float4 s_co[ROUND];
-    __shared__ float4 s_fd[ROUND];
-    __shared__ uint32_t s_id[ROUND];
-    __shared__ float s_thr[ROUND];                // ln(1 / (255 opacity)): alpha >= 1/255  <=>  power >= s_thr
-    __shared__ float s_acc[ROUND * kAcc];
-    __shared__ uint32_t s_mask[ROUND];            // strip_alive_mask per staged entry (0 beyond the list end)
-    __shared__ uint32_t s_wmax[4];
-
-    const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
-    const uint32_t tpv = gx * gy;
-    const uint32_t view = tile / tpv;
-    const uint32_t lt = tile - view * tpv;
-    const uint32_t ty = lt / gx, tx = lt - ty * gx;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t px = tx * kTile + (tid & 15u);
-    const float pixf_x = (float)px;
-    const size_t HW = (size_t)H * W;
-
-    const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-    const float bg0 = bg_color[0], bg1 = bg_color[1], bg2 = bg_color[2];
-
-    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
-    uint32_t wave_strips = 0;                     // slot q of this wave covers strip wave + q * WAVES
-#pragma unroll
-    for (int q = 0; q < PPL; q++) wave_strips |= 1u << (wave + q * WAVES);
-
-    PixState ps[PPL];
-    uint32_t lane_max = 0;
-#pragma unroll
-    for (int q = 0; q < PPL; q++) {
-        const uint32_t py = ty * kTile + (tid >> 4) + q * ROWS_PER_PASS;
-        const bool inside = px < (uint32_t)W && py < (uint32_t)H;
-        const size_t pix_id = (size_t)view * HW + (size_t)W * py + px;
-        PixState& p = ps[q];
-        p.pixf_y = (float)py;
-        p.T_final = inside ? (1 - alphas[pix_id]) : 0;
-        p.T = p.T_final;
-        p.last_contributor = inside ? n_contrib[pix_id] : 0;
-        p.dLp0 = p.dLp1 = p.dLp2 = p.dLpd = p.dLa = 0;
-        if (inside) {
-            const float* dp = dL_dpixels + (size_t)view * 3 * HW + ((size_t)W * py + px);
-            p.dLp0 = dp[0]; p.dLp1 = dp[HW]; p.dLp2 = dp[2 * HW];
-            p.dLpd = dL_dpixel_depths[pix_id];
-            p.dLa = dL_dalphas[pix_id];
-        }
-        p.bg_dot = bg0 * p.dLp0 + bg1 * p.dLp1 + bg2 * p.dLp2;
-        p.last_alpha = p.last_c0 = p.last_c1 = p.last_c2 = p.last_depth = 0;
-        p.accum_rec0 = p.accum_rec1 = p.accum_rec2 = p.accum_depth_rec = p.accum_alpha_rec = 0;
-        lane_max = max(lane_max, p.last_contributor);
-    }
-
-    // Entries whose ordinal is >= every pixel's last contributor are dead for the whole wave /
-    // workgroup: skip them (the reference walks them and `continue`s per pixel, backward.cu:517-519).
-    const uint32_t wmax = wave_max_u32(lane_max);
-    if (lane == 0) s_wmax[wave] = wmax;
-    for (int i = tid; i < ROUND * kAcc; i += THREADS) s_acc[i] = 0.f;
-    __syncthreads();
-    uint32_t bmax = s_wmax[0];
-#pragma unroll
-    for (int w = 1; w < WAVES; w++) bmax = max(bmax, s_wmax[w]);
-    const int first_p_block = total - (int)bmax;  // first reverse position any pixel uses
-    const int first_p_wave = total - (int)wmax;
-    const int rounds = (total + ROUND - 1) / ROUND;
-    {   // rows of the list entries behind every pixel's last contributor (whole skipped rounds): zeros
-        const uint32_t skipped = bmax == 0 ? (uint32_t)total : (uint32_t)((first_p_block / ROUND) * ROUND);
-        zero_rows(acc, range.y - skipped, skipped, tid, THREADS);
-        if (bmax == 0) return;
-    }
-
-    for (int i = first_p_block / ROUND; i < rounds; i++) {
-        const int round_base = i * ROUND;
-        const int n = min(ROUND, total - round_base);
-        __syncthreads();  // previous round's flush is complete
-        {
-            const int e = (int)tid;                   // ROUND == THREADS: one entry per thread
-            uint32_t alive = 0;
-            if (e < n) {
-                const uint32_t id = point_list[range.y - (uint32_t)(round_base + e) - 1];
-                s_id[e] = id;
-                const float2 xy = means2D[id];
-                s_xy[e] = xy;
-                const float4 c4 = conic_opacity[id];
-                s_co[e] = c4;
-                const float thr = alpha_threshold_exact(c4.w);
-                s_thr[e] = thr;
-                s_fd[e] = rgbd[id];
-                alive = strip_alive_mask(xy, c4, -thr + 1e-2f + 1e-3f * fabsf(thr), tile_x0, tile_y0);
-            }
-            s_mask[e] = alive;
-        }
-        __syncthreads();
-        if (wmax != 0) {
-            const int jstart = max(0, first_p_wave - round_base);
-            for (int c = jstart & ~63; c < n; c += 64) {
-              // 64 entries' strip bits -> scalar bitmap of the entries that can reach one of this wave's strips
-              const uint32_t mv = s_mask[c + lane];
-              uint64_t bits = __builtin_amdgcn_ballot_w64((mv & wave_strips) != 0);
-              if (c < jstart) bits &= ~0ull << (jstart - c);
-              while (bits) {
-                const int jl = (int)__builtin_ctzll(bits);
-                bits &= bits - 1;
-                const int j = c + jl;
-                const uint32_t mj = PPL > 1 ? (uint32_t)__builtin_amdgcn_readlane((int)mv, jl) : 0u;
-                const uint32_t ordinal = (uint32_t)(total - 1 - (round_base + j));
-                const float2 xy = s_xy[j];
-                const float4 co = s_co[j];
-                const float thr = s_thr[j];
-                const float dx = xy.x - pixf_x;
-                // power in the reference's expression order (backward.cu:528, as the forward pass): for large splats
-                // a dx^2, c dy^2 and b dx dy reach 1e3..1e4 and cancel to O(1), so a re-associated (Horner) form
-                // differs from the forward pass's G by up to 1e-3 relative.  a dx^2 and b dx are per-lane constants.
-                const float pa = __fmul_rn(__fmul_rn(co.x, dx), dx), pb = __fmul_rn(co.y, dx);
-                float v[kAcc];
-#pragma unroll
-                for (int k = 0; k < kAcc; k++) v[k] = 0.f;
-                bool any_valid = false;
-#pragma unroll
-                for (int q = 0; q < PPL; q++) {
-                    if (PPL > 1 && !((mj >> (wave + q * WAVES)) & 1u)) continue;   // strip of slot q cannot be reached
-                    PixState& p = ps[q];
-                    const float dy = xy.y - p.pixf_y;
-                    const float power = power_exact(pa, pb, co.z, dy);
-                    // alpha >= 1/255 decided on the exponent, with the exact per-entry threshold: the same pairs as
-                    // the forward pass and the oracle, and the exp is only paid by contributing pairs
-                    const bool valid = (ordinal < p.last_contributor) && !(power > 0.0f) && (power >= thr);
-                    if (valid) {
-                        any_valid = true;
-                        // v_exp_f32 path (relative error ~3e-7); the forward pass keeps libm expf for n_contrib
-                        const float G = __expf(power);
-                        const float alpha = fminf(0.99f, co.w * G);
-                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // shared by T/(1-a), T_final/(1-a)
-                        p.T = p.T * inv;
-                        const float dchannel_dcolor = alpha * p.T;
-                        const float4 fd = s_fd[j];
-                        float dL_dopa = 0.0f;
-                        p.accum_rec0 = p.last_alpha * p.last_c0 + (1.f - p.last_alpha) * p.accum_rec0;
-                        p.accum_rec1 = p.last_alpha * p.last_c1 + (1.f - p.last_alpha) * p.accum_rec1;
-                        p.accum_rec2 = p.last_alpha * p.last_c2 + (1.f - p.last_alpha) * p.accum_rec2;
-                        p.last_c0 = fd.x; p.last_c1 = fd.y; p.last_c2 = fd.z;
-                        dL_dopa += (fd.x - p.accum_rec0) * p.dLp0;
-                        dL_dopa += (fd.y - p.accum_rec1) * p.dLp1;
-                        dL_dopa += (fd.z - p.accum_rec2) * p.dLp2;
-                        v[0] += dchannel_dcolor * p.dLp0;
-                        v[1] += dchannel_dcolor * p.dLp1;
-                        v[2] += dchannel_dcolor * p.dLp2;
-                        p.accum_depth_rec = p.last_alpha * p.last_depth + (1.f - p.last_alpha) * p.accum_depth_rec;
-                        p.last_depth = fd.w;
-                        dL_dopa += (fd.w - p.accum_depth_rec) * p.dLpd;
-                        v[3] += dchannel_dcolor * p.dLpd;
-                        p.accum_alpha_rec = p.last_alpha + (1.f - p.last_alpha) * p.accum_alpha_rec;
-                        dL_dopa += (1 - p.accum_alpha_rec) * p.dLa;
-                        dL_dopa *= p.T;
-                        p.last_alpha = alpha;
-                        dL_dopa += (-p.T_final * inv) * p.bg_dot;
-                        const float dL_dG = co.w * dL_dopa;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                        const float dG_ddely = -gdy * co.z - gdx * co.y;
-                        v[4] += dL_dG * dG_ddelx * ddelx_dx;
-                        v[5] += dL_dG * dG_ddely * ddely_dy;
-                        v[6] += -0.5f * gdx * dx * dL_dG;
-                        v[7] += -0.5f * gdx * dy * dL_dG;
-                        v[8] += -0.5f * gdy * dy * dL_dG;
-                        v[9] += G * dL_dopa;
-                    }
-                }
-                if (!__any(any_valid)) continue;
-#if GD_ABLATE == 1
-#pragma unroll
-                for (int k = 0; k < kAcc; k++) asm volatile("" ::"v"(v[k]));
-#else
-                const float z = wave_reduce10(v, lane);
-                const uint32_t vid = 4u * (lane >> 4) + ((lane & 4u) ? 2u + ((lane >> 3) & 1u) : ((lane >> 3) & 1u));
-                if ((lane & 3u) == 0 && vid < (uint32_t)kAcc) {
-                    if (WAVES == 1) s_acc[j * kAcc + vid] = z;   // single writer per tile
-                    else atomicAdd(&s_acc[j * kAcc + vid], z);
-                }
-#endif
-              }
-            }
-        }
-        __syncthreads();
-        // flush this round: the row of list position range.y - 1 - (round_base + e) (no atomics: one writer per row)
-        for (int e = tid; e < n; e += THREADS) {
-            float2* dst = reinterpret_cast<float2*>(acc + (size_t)(range.y - 1u - (uint32_t)(round_base + e)) * kAcc);
-#pragma unroll
-            for (int k = 0; k < kAcc; k += 2) {
-                float2* src = reinterpret_cast<float2*>(&s_acc[e * kAcc + k]);
-                dst[k / 2] = *src;
-                *src = make_float2(0.f, 0.f);
-            }
-        }
-    }
-}
-
-
 // =================================================================================================================
-// render_backward_lists_kernel -- the reverse-order gradient pass re-organised around PER-PIXEL LISTS.
+// The reverse-order gradient pass, re-organised around PER-PIXEL LISTS (implemented by render_backward_strip_kernel).
 //
 // The wave-uniform walk above executes its ~60-instruction body for all 64 lanes of a strip although on the
 // benchmark scene only a third of the 64 pixels blend a given (strip, entry) pair -- and for half of the pairs the
@@ -610,43 +388,55 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
     return v;
 }
 
-template <int ROUND, int CAP>
-__global__ __launch_bounds__(kTilePix) void render_backward_lists_kernel(
+// =================================================================================================================
+// render_backward_strip_kernel -- one INDEPENDENT wave per (tile, 16x4 strip): the list-based reverse pass of
+// render_backward_lists_kernel without any workgroup barrier.
+//
+// With the forward pass's ballots a strip knows which list entries it needs (about a fifth of the tile's list), so
+// nothing has to be staged by the tile as a whole: the wave gathers the centre / conic / colour of just those entries
+// (one group of 64 list positions ahead of the arithmetic, the ballots and Gaussian ids two groups ahead), runs the
+// passes A-C described above on them and stores ONE row of ten sums per (instance, strip) that has a contributing
+// pixel -- rows4[slot][strip][10] + a flag byte, written once, never accumulated; `slot` is where duplicate_kernel put
+// the instance, so the rows of a Gaussian are contiguous and preprocess_backward_kernel just adds the flagged ones.
+// No atomics, no __syncthreads, no zero filling of rows; gradients are bitwise reproducible.
+// =================================================================================================================
+template <int CAP>
+__global__ __launch_bounds__(64) void render_backward_strip_kernel(
     int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
     const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
     const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-    const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ acc,
-    const uint64_t* __restrict__ ballots, uint32_t R, int ablate)
+    const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ rows4,
+    uint8_t* __restrict__ flags, const uint64_t* __restrict__ ballots, const uint32_t* __restrict__ slot_of, int ablate)
 {
-    static_assert(ROUND % 64 == 0 && CAP >= 64, "round = whole 64-entry groups; one entry has up to 64 records");
-    constexpr int THREADS = kTilePix;
-    __shared__ float2 s_xy[ROUND];
-    __shared__ float4 s_co[ROUND];
-    __shared__ float4 s_fd[ROUND];
-    __shared__ uint32_t s_id[ROUND];
-    __shared__ float s_acc[4][ROUND * kAcc];   // PER WAVE (strip): every (strip, entry) row has exactly one writer -> plain stores
-    __shared__ uint4 s_tab[4][64];          // per wave, per entry of the current group: {ballot lo, hi, record base, count}
-    __shared__ uint8_t s_nz[4][64];         // per wave: the entries of the group that have records, compacted
-    __shared__ float2 s_rec[4][CAP];        // per wave: {alpha T, G dL/dalpha} per contributing pair, grouped by entry
-    __shared__ uint8_t s_rid[4][CAP];       //           ... and the pixel (lane) it belongs to
-    __shared__ float4 s_pix[kTilePix];      // per pixel: dL/dC rgb, dL/ddepth
-    __shared__ uint32_t s_wmax[4];
+    static_assert(CAP >= 64, "one entry has up to 64 records");
+    __shared__ float2 s_xy[64];            // the current group's entries (only those with a non-zero ballot are filled)
+    __shared__ float4 s_co[64];
+    __shared__ float4 s_fd[64];
+    __shared__ uint4 s_tab[64];            // {ballot lo, hi, record base | count << 16, instance slot}
+    __shared__ uint8_t s_nz[64];           // entries of the group that have records, compacted
+    __shared__ float2 s_rec[CAP];          // {alpha T, G dL/dalpha} per contributing pair, grouped by entry
+    __shared__ uint8_t s_rid[CAP];         // ... and its pixel (lane)
+    __shared__ float4 s_pix[64];           // per pixel: dL/dC rgb, dL/ddepth
 
-    const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
+    // workgroup b runs on XCD b % 8: the four strips of a tile and neighbouring tiles share an XCD (they share most
+    // of their Gaussians in that XCD's L2)
+    const uint32_t nblk = tiles_total * 4u;
+    uint32_t unit = blockIdx.x;
+    if ((nblk & 7u) == 0) unit = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const uint32_t tile = unit >> 2;
+    const uint32_t strip = unit & 3u;
     const uint32_t tpv = gx * gy;
     const uint32_t view = tile / tpv;
     const uint32_t lt = tile - view * tpv;
     const uint32_t ty = lt / gx, tx = lt - ty * gx;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t px = tx * kTile + (tid & 15u), py = ty * kTile + (tid >> 4);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t px = tx * kTile + (lane & 15u), py = ty * kTile + 4u * strip + (lane >> 4);
     const float pixf_x = (float)px, pixf_y = (float)py;
     const size_t HW = (size_t)H * W;
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
-    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
-    const uint64_t* my_ballots = ballots + (size_t)wave * R;
+    const float strip_x0 = (float)(tx * kTile), strip_y0 = (float)(ty * kTile + 4u * strip);
 
     // ---- per-pixel constants and the state of the reverse walk (backward.cu:461-487) ----
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
@@ -654,6 +444,8 @@ __global__ __launch_bounds__(kTilePix) void render_backward_lists_kernel(
     const float T_final = inside ? (1 - alphas[pix_id]) : 0;
     float T = T_final;
     const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0;
+    const uint32_t wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last_contributor));
+    if (wmax == 0) return;        // no pixel of the strip blended anything: all its ballots are zero, no rows
     float dLp0 = 0, dLp1 = 0, dLp2 = 0, dLpd = 0, dLa = 0;
     if (inside) {
         const float* dp = dL_dpixels + (size_t)view * 3 * HW + ((size_t)W * py + px);
@@ -662,46 +454,47 @@ __global__ __launch_bounds__(kTilePix) void render_backward_lists_kernel(
         dLa = dL_dalphas[pix_id];
     }
     const float bgT = T_final * (bg_color[0] * dLp0 + bg_color[1] * dLp1 + bg_color[2] * dLp2);
-    s_pix[tid] = make_float4(dLp0, dLp1, dLp2, dLpd);
+    s_pix[lane] = make_float4(dLp0, dLp1, dLp2, dLpd);
     float A = 0.f, last_alpha = 0.f, last_s = 0.f;   // A = sum_k accum_rec_k dL_k of the reference's five recurrences
-
-    const uint32_t wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last_contributor));
-    if (lane == 0) s_wmax[wave] = wmax;
-    for (int i = tid; i < 4 * ROUND * kAcc; i += THREADS) (&s_acc[0][0])[i] = 0.f;
-    __syncthreads();
-    const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-    const int first_p_block = total - (int)bmax;  // first reverse position any pixel uses
-    const int first_p_wave = total - (int)wmax;
-    const int rounds = (total + ROUND - 1) / ROUND;
-    {   // rows of the list entries behind every pixel's last contributor (whole skipped rounds): zeros
-        const uint32_t skipped = bmax == 0 ? (uint32_t)total : (uint32_t)((first_p_block / ROUND) * ROUND);
-        zero_rows(acc, range.y - skipped, skipped, tid, THREADS);
-        if (bmax == 0) return;
-    }
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
-    for (int i = first_p_block / ROUND; i < rounds; i++) {
-        const int round_base = i * ROUND;
-        const int n = min(ROUND, total - round_base);
-        __syncthreads();  // previous round's flush is complete
-        for (int e = (int)tid; e < n; e += THREADS) {
-            const uint32_t id = point_list[range.y - (uint32_t)(round_base + e) - 1];
-            s_id[e] = id;
-            s_xy[e] = means2D[id];
-            s_co[e] = conic_opacity[id];
-            s_fd[e] = rgbd[id];
+    // reverse index e = 0 is the LAST list entry; the strip's first useful one is e = total - wmax
+    const int jstart = total - (int)wmax;
+    const int c_first = jstart & ~63;
+    auto load_ballot_id = [&](int c, uint64_t& bal, uint32_t& id, uint32_t& slot) {
+        const int e = c + (int)lane;
+        bal = 0; id = 0; slot = 0;
+        if (e < total && e >= jstart) {
+            const uint32_t pos = range.y - 1u - (uint32_t)e;
+            bal = ballots[(size_t)pos * 4u + strip];
+            id = point_list[pos];
+            slot = slot_of[pos];
         }
-        __syncthreads();
-        const int jstart = max(0, first_p_wave - round_base);
-        for (int c = jstart & ~63; wmax != 0 && c < n; c += 64) {
+    };
+    struct Data { float2 xy; float4 co, fd; };
+    auto load_data = [&](uint64_t bal, uint32_t id, Data& d) {
+        if (bal != 0) { d.xy = means2D[id]; d.co = conic_opacity[id]; d.fd = rgbd[id]; }
+    };
+    uint64_t bal_cur, bal_nxt = 0, bal_nn = 0;
+    uint32_t id_cur, id_nxt = 0, id_nn = 0, slot_cur, slot_nxt = 0, slot_nn = 0;
+    Data d_cur, d_nxt;
+    d_cur.xy = make_float2(0, 0); d_cur.co = d_cur.fd = make_float4(0, 0, 0, 0); d_nxt = d_cur;
+    load_ballot_id(c_first, bal_cur, id_cur, slot_cur);
+    load_data(bal_cur, id_cur, d_cur);
+    if (c_first + 64 < total) load_ballot_id(c_first + 64, bal_nxt, id_nxt, slot_nxt);
+
+    for (int c = c_first; c < total; c += 64) {
+        // requests for the following groups go out before this group's arithmetic
+        load_data(bal_nxt, id_nxt, d_nxt);
+        if (c + 128 < total) load_ballot_id(c + 128, bal_nn, id_nn, slot_nn); else { bal_nn = 0; id_nn = 0; slot_nn = 0; }
+
+        const uint64_t bal = bal_cur;
+        const uint32_t bal_lo = (uint32_t)bal, bal_hi = (uint32_t)(bal >> 32);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(bal);
+        const uint64_t nz = __builtin_amdgcn_ballot_w64(cnt != 0);
+        if (nz != 0) {
+            if (cnt != 0) { s_xy[lane] = d_cur.xy; s_co[lane] = d_cur.co; s_fd[lane] = d_cur.fd; }
             // ---------------- pass A: ballots -> record offsets and per-pixel lists ----------------
-            const int e_mine = c + (int)lane;
-            uint64_t bal = 0;
-            if (e_mine < n && e_mine >= jstart) bal = my_ballots[range.y - 1u - (uint32_t)(round_base + e_mine)];
-            const uint32_t bal_lo = (uint32_t)bal, bal_hi = (uint32_t)(bal >> 32);
-            const uint32_t cnt = (uint32_t)__builtin_popcountll(bal);
-            const uint64_t nz = __builtin_amdgcn_ballot_w64(cnt != 0);
-            if (nz == 0) continue;
             const uint32_t incl = wave_inclusive_scan_u32(cnt);
             const uint32_t base = incl - cnt;
             uint32_t list_lo = 0, list_hi = 0;   // bit b: this pixel blended entry c + b
@@ -733,48 +526,53 @@ __global__ __launch_bounds__(kTilePix) void render_backward_lists_kernel(
                 b0 = b1;
                 if (nzr == 0) continue;
                 const bool in_range = ((rmask >> lane) & 1ull) != 0;
-                s_tab[wave][lane] = make_uint4(bal_lo, bal_hi, base - start, cnt);
+                s_tab[lane] = make_uint4(bal_lo, bal_hi, ((base - start) & 0xffffu) | (cnt << 16), slot_cur);
                 if (in_range && cnt != 0) {
                     const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzr, 0u));
-                    s_nz[wave][k] = (uint8_t)lane;
+                    s_nz[k] = (uint8_t)lane;
                 }
                 const uint32_t nnz = (uint32_t)__builtin_popcountll(nzr);
                 __builtin_amdgcn_wave_barrier();
                 // ---------------- pass B: every pixel walks its own list ----------------
                 if (!(ablate & 1)) {
                     uint64_t m = (((uint64_t)list_hi << 32) | list_lo) & rmask;
-                    uint4 row; float2 xy; float4 co, fd;
-                    bool have = m != 0;
-                    if (have) {
+                    struct Ent { uint4 row; float2 xy; float4 co, fd; };
+                    auto fetch = [&](Ent& q) {           // pops the list's next entry and requests its data
                         const uint32_t b = (uint32_t)__builtin_ctzll(m);
                         m &= m - 1;
-                        row = s_tab[wave][b]; xy = s_xy[c + b]; co = s_co[c + b]; fd = s_fd[c + b];
-                    }
-                    while (have) {
-                        // next entry's data is requested before this entry's arithmetic (LDS latency under the VALU chain)
-                        const bool have_next = m != 0;
-                        uint4 row_n = row; float2 xy_n = xy; float4 co_n = co, fd_n = fd;
-                        if (have_next) {
-                            const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                            m &= m - 1;
-                            row_n = s_tab[wave][b]; xy_n = s_xy[c + b]; co_n = s_co[c + b]; fd_n = s_fd[c + b];
-                        }
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(row.y, __builtin_amdgcn_mbcnt_lo(row.x, 0u));
-                        const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
-                        const float power = power_exact(__fmul_rn(__fmul_rn(co.x, dx), dx), __fmul_rn(co.y, dx), co.z, dy);
+                        q.row = s_tab[b]; q.xy = s_xy[b]; q.co = s_co[b]; q.fd = s_fd[b];
+                    };
+                    auto step = [&](const Ent& q) {      // backward.cu:534-578 for one contributing (pixel, entry) pair
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(q.row.y, __builtin_amdgcn_mbcnt_lo(q.row.x, 0u));
+                        const float dx = q.xy.x - pixf_x, dy = q.xy.y - pixf_y;
+                        const float power = power_exact(__fmul_rn(__fmul_rn(q.co.x, dx), dx), __fmul_rn(q.co.y, dx), q.co.z, dy);
                         const float G = __expf(power);
-                        const float alpha = fminf(0.99f, co.w * G);
+                        const float alpha = fminf(0.99f, q.co.w * G);
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // shared by T/(1-a), T_final/(1-a)
                         T = T * inv;
-                        const float sdot = fd.x * dLp0 + fd.y * dLp1 + fd.z * dLp2 + fd.w * dLpd + dLa;
+                        const float sdot = q.fd.x * dLp0 + q.fd.y * dLp1 + q.fd.z * dLp2 + q.fd.w * dLpd + dLa;
                         A = last_alpha * last_s + (1.f - last_alpha) * A;
                         last_s = sdot;
                         last_alpha = alpha;
                         const float dL_dopa = (sdot - A) * T - inv * bgT;
-                        s_rec[wave][row.z + rank] = make_float2(alpha * T, G * dL_dopa);
-                        s_rid[wave][row.z + rank] = (uint8_t)lane;
-                        row = row_n; xy = xy_n; co = co_n; fd = fd_n;
-                        have = have_next;
+                        const uint32_t at = (q.row.z & 0xffffu) + rank;
+                        s_rec[at] = make_float2(alpha * T, G * dL_dopa);
+                        s_rid[at] = (uint8_t)lane;
+                    };
+                    // two-deep software pipeline, unrolled so that the two entry buffers never need copying
+                    if (m != 0) {
+                        Ent e0, e1;
+                        fetch(e0);
+                        while (true) {
+                            const bool more1 = m != 0;
+                            if (more1) fetch(e1);
+                            step(e0);
+                            if (!more1) break;
+                            const bool more0 = m != 0;
+                            if (more0) fetch(e0);
+                            step(e1);
+                            if (!more0) break;
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -783,73 +581,79 @@ __global__ __launch_bounds__(kTilePix) void render_backward_lists_kernel(
                     for (uint32_t it0 = 0; it0 < 4u * nnz; it0 += 64u) {     // whole quads: 4 nnz is a multiple of 4
                         const uint32_t it = it0 + lane;
                         const bool active = it < 4u * nnz;
-                        const uint32_t b = active ? s_nz[wave][it >> 2] : 0u;
-                        const uint4 row = s_tab[wave][b];
-                        const uint32_t qlen = (row.w + 3u) >> 2;
+                        const uint32_t b = active ? s_nz[it >> 2] : 0u;
+                        const uint4 row = s_tab[b];
+                        const uint32_t rcnt = row.z >> 16, rbase = row.z & 0xffffu;
+                        const uint32_t qlen = (rcnt + 3u) >> 2;
                         const uint32_t r0 = (it & 3u) * qlen;
-                        const uint32_t r1 = active ? min(row.w, r0 + qlen) : r0;
-                        const float2 xy = s_xy[c + b];
-                        const float4 co = s_co[c + b];
-                        const float ex = xy.x - tile_x0, ey = xy.y - (tile_y0 + 4.0f * (float)wave);   // relative to the strip
+                        const uint32_t r1 = active ? min(rcnt, r0 + qlen) : r0;
+                        const float2 xy = s_xy[b];
+                        const float4 co = s_co[b];
+                        const float ex = xy.x - strip_x0, ey = xy.y - strip_y0;
                         float v[kAcc];
 #pragma unroll
                         for (int k = 0; k < kAcc; k++) v[k] = 0.f;
                         float sx = 0, sy = 0;
-                        for (uint32_t r = row.z + r0; r < row.z + r1; r++) {
-                            const float2 rc = s_rec[wave][r];
-                            const uint32_t l = s_rid[wave][r];
-                            const float4 g4 = s_pix[wave * 64u + l];
-                            const float dx = ex - (float)(l & 15u), dy = ey - (float)(l >> 4);
-                            v[0] += rc.x * g4.x; v[1] += rc.x * g4.y; v[2] += rc.x * g4.z; v[3] += rc.x * g4.w;
-                            v[9] += rc.y;
-                            const float gdx = rc.y * dx, gdy = rc.y * dy;
+                        struct Rec { float2 rc; uint32_t l; float4 g4; };
+                        auto accum = [&](const Rec& q) {
+                            const float dx = ex - (float)(q.l & 15u), dy = ey - (float)(q.l >> 4);
+                            v[0] += q.rc.x * q.g4.x; v[1] += q.rc.x * q.g4.y; v[2] += q.rc.x * q.g4.z; v[3] += q.rc.x * q.g4.w;
+                            v[9] += q.rc.y;
+                            const float gdx = q.rc.y * dx, gdy = q.rc.y * dy;
                             sx += gdx; sy += gdy;
                             v[6] += gdx * dx; v[7] += gdx * dy; v[8] += gdy * dy;
+                        };
+                        uint32_t r = rbase + r0;
+                        const uint32_t rend = rbase + r1;
+                        auto fetchr = [&](Rec& q) {
+                            q.rc = s_rec[r];
+                            q.l = s_rid[r];
+                            q.g4 = s_pix[q.l];
+                            r++;
+                        };
+                        if (r < rend) {
+                            Rec q0, q1;
+                            fetchr(q0);
+                            while (true) {
+                                const bool more1 = r < rend;
+                                if (more1) fetchr(q1);
+                                accum(q0);
+                                if (!more1) break;
+                                const bool more0 = r < rend;
+                                if (more0) fetchr(q0);
+                                accum(q1);
+                                if (!more0) break;
+                            }
                         }
                         // dL_dG G = opacity * (G dL/dalpha): the common factor of the geometric terms (backward.cu:580-598)
                         const float o = co.w;
                         v[4] = -ddelx_dx * o * (co.x * sx + co.y * sy);
                         v[5] = -ddely_dy * o * (co.z * sy + co.y * sx);
                         v[6] *= -0.5f * o; v[7] *= -0.5f * o; v[8] *= -0.5f * o;
-                        // the four quarters of an entry sit in one quad: two DPP adds per value; the quad's first lane is
-                        // the only writer of this (strip, entry) row (ds_add_f32 costs ~60 LDS cycles per wave-instruction
-                        // plus ~2 per lane on this part -- ten of them per group were half of the kernel)
+                        // the four quarters of an entry sit in one quad: two DPP adds per value; the quad's first lane
+                        // stores the row of (list position, strip)
 #pragma unroll
                         for (int k = 0; k < kAcc; k++) {
                             v[k] += dpp_term<0xB1, 0xf, 0xf>(v[k]);   // quad_perm [1,0,3,2]
                             v[k] += dpp_term<0x4E, 0xf, 0xf>(v[k]);   // quad_perm [2,3,0,1]
                         }
                         if (active && (lane & 3u) == 0) {
-                            float* dst = &s_acc[wave][(c + b) * kAcc];     // 8-byte aligned (40-byte rows)
-                            *reinterpret_cast<float2*>(dst + 0) = make_float2(v[0], v[1]);
-                            *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
-                            *reinterpret_cast<float2*>(dst + 4) = make_float2(v[4], v[5]);
-                            *reinterpret_cast<float2*>(dst + 6) = make_float2(v[6], v[7]);
-                            *reinterpret_cast<float2*>(dst + 8) = make_float2(v[8], v[9]);
+                            const size_t at = (size_t)row.w * 4u + strip;     // (instance slot, strip)
+                            flags[at] = 1;
+                            float2* dst = reinterpret_cast<float2*>(rows4 + at * kAcc);
+                            dst[0] = make_float2(v[0], v[1]);
+                            dst[1] = make_float2(v[2], v[3]);
+                            dst[2] = make_float2(v[4], v[5]);
+                            dst[3] = make_float2(v[6], v[7]);
+                            dst[4] = make_float2(v[8], v[9]);
                         }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();
-        // flush this round: the four strips' rows are added in a fixed order and stored as the row of list position
-        // range.y - 1 - (round_base + e): no atomics, one writer per row, bitwise reproducible
-        for (int e = tid; e < n; e += THREADS) {
-            float2* dst = reinterpret_cast<float2*>(acc + (size_t)(range.y - 1u - (uint32_t)(round_base + e)) * kAcc);
-#pragma unroll
-            for (int k = 0; k < kAcc; k += 2) {
-                float2 t = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    float2* src = reinterpret_cast<float2*>(&s_acc[w][e * kAcc + k]);
-                    const float2 u = *src;
-                    t.x += u.x; t.y += u.y;
-                    if (u.x != 0.f || u.y != 0.f) *src = make_float2(0.f, 0.f);
-                }
-                dst[k / 2] = t;
-            }
-        }
+        bal_cur = bal_nxt; id_cur = id_nxt; slot_cur = slot_nxt; d_cur = d_nxt;
+        bal_nxt = bal_nn; id_nxt = id_nn; slot_nxt = slot_nn;
     }
 }
 
@@ -869,26 +673,16 @@ void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int 
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const uint32_t* point_list, const GeomState& g, const float* bg, const float* alphas,
                             const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                            const float* dL_dalphas, float* acc, const uint64_t* ballots, uint32_t R)
+                            const float* dL_dalphas, float* rows4, uint8_t* flags, const uint64_t* ballots,
+                            const uint32_t* slot_of)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
-    // GD_RASTER_BWD_IMPL=tree selects the wave-uniform walk with the halving-tree reduction (round 1; kept for A/B
-    // measurements and as a second implementation the parity tests run); default: per-pixel lists.  Read once.
-    static const int impl = [] {
-        const char* e = getenv("GD_RASTER_BWD_IMPL");
-        return (e && e[0] == 't') ? 1 : 0;
-    }();
+    // GD_RASTER_BWD_ABLATE (timing experiments only, wrong results): 1 = skip pass B, 2 = skip pass C.  Read once.
     static const int ablate = [] { const char* e = getenv("GD_RASTER_BWD_ABLATE"); return e ? atoi(e) : 0; }();
-    if (impl == 1) {
-        hipLaunchKernelGGL(render_backward_kernel<1>, dim3(tiles_total), dim3(kTilePix), 0, s, W, H,
-                           (uint32_t)tiles_x, (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D,
-                           g.conic_opacity, g.rgbd, bg, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc);
-    } else {
-        hipLaunchKernelGGL((render_backward_lists_kernel<GD_BWD_ROUND, GD_BWD_CAP>), dim3(tiles_total), dim3(kTilePix), 0, s, W, H,
-                           (uint32_t)tiles_x, (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D,
-                           g.conic_opacity, g.rgbd, bg, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, acc,
-                           ballots, R, ablate);
-    }
+    hipLaunchKernelGGL((render_backward_strip_kernel<GD_BWD_CAP>), dim3(tiles_total * 4u), dim3(64), 0, s, W, H,
+                       (uint32_t)tiles_x, (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D,
+                       g.conic_opacity, g.rgbd, bg, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, rows4,
+                       flags, ballots, slot_of, ablate);
 }
 
 }  // namespace gd

@@ -52,7 +52,7 @@ def test_scratch_size_queries_and_sort_plan():
     assert L.gd_raster_image_bytes(512, 512, 1) >= 512 * 512 * 4 + 1024 * 8
     assert L.gd_raster_binning_bytes(0) > 0
     assert L.gd_raster_binning_bytes(1000000) >= 24 * 1000000
-    assert L.gd_raster_backward_scratch_bytes(1000, 2, 5000) >= 5000 * 44
+    assert L.gd_raster_backward_scratch_bytes(1000, 2, 5000) >= 5000 * 164
     # 32 + getHigherMsb(tiles): 256 tiles -> 41, 1024 -> 43, 4096 -> 45; batched keys carry the view
     assert L.gd_raster_sort_bits(256, 256, 1) == 41
     assert L.gd_raster_sort_bits(512, 512, 1) == 43
