@@ -16,10 +16,10 @@ Rank 0 prints ONE JSON line.  Extra objects on that line:
                 of GPU time): algorithmic FLOPs (2*N*H*W*Cout*9*Cin per launch) / its summed launch
                 duration, from HIP events recorded around every launch inside the timed region; peak =
                 2.5 PFLOP/s dense bf16 MFMA.
-  roofline_raster_bwd  the rasterizer backward render kernel (the kernel north_star names): algorithmic
-                FLOPs per launch (14 per visited pair + 87 per contributing pair, counted on the
-                GPU from n_contrib / pair_counts; derivation in DESIGN.md) / its average launch
-                duration from HIP events; peak = 157.3 TFLOP/s fp32.
+  roofline_raster_bwd  the rasterizer backward blend kernel (the kernel north_star names): algorithmic
+                FLOPs per launch (14 per visited pair + 87 per contributing pair of the reference's
+                backward, counted on the GPU from n_contrib / pair_counts; derivation in DESIGN.md) /
+                its average launch duration from HIP events; peak = 157.3 TFLOP/s fp32 VALU.
   roofline_dense  UNet + VAE part: analytic FLOPs (0.804 TF/UNet sample, 1.117 TF/VAE image, dgrad
                 = 1x fwd) / event time of guidance fwd + its backward, vs the 2.5 PF bf16 MFMA roof.
   cpu_baseline  the CPU oracle (rasterizer fwd+bwd, 1 thread) + fp32 PyTorch-CPU UNet/VAE for ONE of
@@ -272,6 +272,7 @@ def main():
         loop.render_batch_fn = per_view
 
     gen = torch.Generator(device=device)
+    from garmentdreamer_amd import nn_ops as nn_ops_mod
 
     def one_step(step):
         batch = camera_batch(args, step, view_ids)
@@ -280,7 +281,7 @@ def main():
         if args.raster_only:
             out = loop.render_views(batch)
             w = torch.randn(out["comp_rgb"].shape, device=device, generator=gen)
-            loss = (out["comp_rgb"] * w).sum() + (out["opacity"] ** 2 + 0.01).sqrt().mean()
+            loss = (out["comp_rgb"] * w).sum() + nn_ops_mod.sparsity_loss(out["depth"], out["depth_max"])
             if loop.native_scene:
                 gaussians.zero_grad()
             else:
@@ -369,14 +370,18 @@ def main():
         avg_s = bwd_ms / bwd_n * 1e-3
         ach = flops_launch / avg_s / 1e12
         V_ = counts["views"]
-        alg_bytes = 44.0 * counts["num_rendered"] + 20.0 * V_ * args.res * args.res + 40.0 * V_ * args.gaussians
+        # ballots 32 B + id / slot 8 B per list position, 44 B per (strip, entry) with a contribution gathered and 40 B
+        # stored (about 0.83 per position on this scene -> counted as 1), 20 B per pixel
+        alg_bytes = (40.0 + 84.0) * counts["num_rendered"] + 20.0 * V_ * args.res * args.res
         roofline = {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
-                    "kernel": "render_backward_kernel", "avg_launch_us": avg_s * 1e6, "launches": bwd_n,
+                    "kernel": "render_backward_strip_kernel", "avg_launch_us": avg_s * 1e6, "launches": bwd_n,
                     "flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": alg_bytes,
                     "note": ("fp32 VALU roof: 157.3 TF/s (4 SIMD-32 per CU, v_fma_f32 every 2 cycles) == the f32-input "
-                             "MFMA rate on gfx950; no MFMA is issued. Algorithmic HBM bytes = 44 B per instance + 20 B "
-                             "per pixel + 40 B per (view, Gaussian) accumulator row")}
+                             "MFMA rate on gfx950; no MFMA is issued.  FLOPs are the REFERENCE algorithm's (14 per pair "
+                             "its backward visits + 87 per contributing pair, backward.cu:517-598); this kernel visits "
+                             "only the contributing pairs (the forward pass hands it their ballots), so its executed "
+                             "work is smaller than the algorithmic count")}
 
     # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/pmc_all.sh -> profiles/):
     # bench.py cannot read hardware counters itself, so `traffic` quotes the committed counter file

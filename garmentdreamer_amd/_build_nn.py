@@ -6,6 +6,7 @@ NN_SOURCES = [
     ("nn_conv3x3.hip", []),
     ("nn_elementwise.hip", []),
     ("nn_attention.hip", []),
+    ("nn_prologue.hip", ["-munsafe-fp-atomics"]),
 ]
 
 

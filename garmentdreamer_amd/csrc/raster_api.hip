@@ -501,7 +501,7 @@ const char* gd_raster_profile_kernel_name(int kernel_id)
 {
     static const char* names[GD_K_COUNT] = {"preprocess_kernel", "scan_block_sums_kernel", "duplicate_kernel",
                                             "radix_sort(all passes)", "tile_ranges_kernel", "render_forward_kernel",
-                                            "render_backward_kernel", "preprocess_backward_kernel"};
+                                            "render_backward_strip_kernel", "instance_sum_kernel + preprocess_backward_kernel"};
     return (kernel_id >= 0 && kernel_id < GD_K_COUNT) ? names[kernel_id] : "";
 }
 

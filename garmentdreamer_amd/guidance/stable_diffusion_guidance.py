@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _runtime_env
+from .. import _runtime_env, nn_ops
 from . import sd21
 
 
@@ -190,20 +190,22 @@ class StableDiffusionGuidance(nn.Module):
         return fn(imgs)
 
     def encode_images(self, imgs, vae_noise: Optional[torch.Tensor] = None):
-        input_dtype = imgs.dtype
-        imgs = imgs * 2.0 - 1.0
-        if self.cfg.use_hip_graphs and imgs.is_cuda and torch.is_grad_enabled() and imgs.requires_grad:
-            x = imgs.to(self.weights_dtype).contiguous(memory_format=torch.channels_last)
+        return self._encode_prepared((imgs * 2.0 - 1.0).to(self.weights_dtype), vae_noise, imgs.dtype)
+
+    def _encode_prepared(self, x, vae_noise, out_dtype):
+        """``x``: images already mapped to [-1, 1] in the VAE's dtype (``encode_images`` or the fused prologue)."""
+        if self.cfg.use_hip_graphs and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+            xc = x.contiguous(memory_format=torch.channels_last)
             try:
-                posterior = sd21.DiagonalGaussianDistribution(self._graphed_vae_moments(x))
+                posterior = sd21.DiagonalGaussianDistribution(self._graphed_vae_moments(xc))
             except RuntimeError as e:
                 self._graphs_failed(e)
-                posterior = self.vae.encode(imgs.to(self.weights_dtype)).latent_dist
+                posterior = self.vae.encode(x).latent_dist
         else:
-            posterior = self.vae.encode(imgs.to(self.weights_dtype)).latent_dist
+            posterior = self.vae.encode(x).latent_dist
         noise = None if vae_noise is None else vae_noise.to(self.weights_dtype)
         latents = posterior.sample(noise) * self.vae.config.scaling_factor
-        return latents.to(input_dtype)
+        return latents.to(out_dtype)
 
     def compute_grad_sds(self, latents, t, prompt_utils, elevation, azimuth, camera_distances,
                          noise: Optional[torch.Tensor] = None):
@@ -242,6 +244,10 @@ class StableDiffusionGuidance(nn.Module):
         rgb_BCHW = rgb.permute(0, 3, 1, 2)
         if rgb_as_latents:
             latents = F.interpolate(rgb_BCHW, (64, 64), mode="bilinear", align_corners=False)
+        elif self.weights_dtype == torch.bfloat16 and nn_ops.vae_prologue_supported(rgb_BCHW):
+            # bilinear 512^2 + (2x - 1) + bf16 / NHWC cast: ONE launch each way (csrc/nn_prologue.hip) instead of
+            # interpolate, mul-add, dtype copy, layout copy and their backward kernels
+            latents = self._encode_prepared(nn_ops.vae_prologue(rgb_BCHW, 512, 512), vae_noise, rgb.dtype)
         else:
             rgb_BCHW_512 = F.interpolate(rgb_BCHW, (512, 512), mode="bilinear", align_corners=False)
             latents = self.encode_images(rgb_BCHW_512, vae_noise)

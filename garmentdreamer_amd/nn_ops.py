@@ -42,6 +42,11 @@ SIGNATURES = {
     "gd_nn_attention_d64_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i,
                                          C.c_int64, _i, C.c_int64, _i, _f]),
     "gd_nn_attention_last_error": (C.c_char_p, []),
+    "gd_nn_vae_prologue_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gd_nn_vae_prologue_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "gd_nn_sparsity_forward": (_i, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "gd_nn_sparsity_backward": (_i, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "gd_nn_prologue_last_error": (C.c_char_p, []),
     "gd_nn_conv_last_error": (C.c_char_p, []),
     "gd_nn_elementwise_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
@@ -718,3 +723,89 @@ def attention_d64(q, k, v):
     if ret < 0:
         raise RuntimeError(f"gd_nn_attention_d64_forward failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
     return o
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# image prologue of the guidance and the depth-sparsity head (csrc/nn_prologue.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+class _VaePrologue(torch.autograd.Function):
+    """``bf16_nhwc(2 * F.interpolate(x, (OH, OW), mode="bilinear", align_corners=False) - 1)`` as one launch forward and
+    one backward (stable_diffusion_guidance.py:394-396,164 + the casts the VAE's first convolution needs)."""
+
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, 3, OH, OW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        L = lib()
+        with torch.cuda.device(x.device):
+            _check(L.gd_nn_vae_prologue_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(),
+                                                N, H, W, OH, OW), "gd_nn_vae_prologue_forward")
+        ctx.shape = (N, H, W, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, OH, OW = ctx.shape
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        # the first convolution's input gradient comes on 4 zero-padded channels (a [:, :3] slice of an NHWC tensor):
+        # read it in place, pixel stride CG
+        base = dy._base if dy._base is not None and dy.storage_offset() == 0 else None
+        if (base is not None and base.dim() == 4 and base.shape[0] == N and base.shape[2:] == dy.shape[2:]
+                and base.is_contiguous(memory_format=torch.channels_last) and dy.stride() == base.stride()):
+            src, CG = base, base.shape[1]
+        else:
+            src, CG = dy.contiguous(memory_format=torch.channels_last), 3
+        dx = torch.empty((N, 3, H, W), dtype=torch.float32, device=dy.device)
+        L = lib()
+        with torch.cuda.device(dy.device):
+            _check(L.gd_nn_vae_prologue_backward(torch.cuda.current_stream(dy.device).cuda_stream, src.data_ptr(),
+                                                 dx.data_ptr(), N, H, W, OH, OW, CG), "gd_nn_vae_prologue_backward")
+        return dx, None, None
+
+
+def vae_prologue_supported(x) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous()
+
+
+def vae_prologue(x, OH: int = 512, OW: int = 512):
+    """x: planar fp32 [N,3,H,W] in [0,1] -> bf16 channels_last [N,3,OH,OW] = 2 * bilinear(x) - 1."""
+    return _VaePrologue.apply(x, OH, OW)
+
+
+class _SparsityHead(torch.autograd.Function):
+    """``mean(sqrt((depth / (dmax + 1e-5))^2 + 0.01))`` (GaussianDreamer.py:215,253) given the maximum as a tensor:
+    one kernel forward (value + d/d dmax), one backward."""
+
+    @staticmethod
+    def forward(ctx, depth, dmax):
+        d = depth.contiguous()
+        m = dmax.detach().reshape(1).to(torch.float32)
+        sums = torch.empty(2, dtype=torch.float64, device=d.device)
+        n = d.numel()
+        L = lib()
+        with torch.cuda.device(d.device):
+            _check(L.gd_nn_sparsity_forward(torch.cuda.current_stream(d.device).cuda_stream, d.data_ptr(), m.data_ptr(), n,
+                                            sums.data_ptr()), "gd_nn_sparsity_forward")
+        ctx.save_for_backward(d, m, sums)
+        return (sums[0] / n).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        d, m, sums = ctx.saved_tensors
+        n = d.numel()
+        g32 = g.reshape(1).to(torch.float32).contiguous()
+        dd = torch.empty_like(d)
+        L = lib()
+        with torch.cuda.device(d.device):
+            _check(L.gd_nn_sparsity_backward(torch.cuda.current_stream(d.device).cuda_stream, d.data_ptr(), m.data_ptr(),
+                                             g32.data_ptr(), n, dd.data_ptr()), "gd_nn_sparsity_backward")
+        dmax_grad = (-(sums[1] / n).to(torch.float32) / (m[0] + 1e-5)) * g32[0]
+        return dd, dmax_grad.reshape(())
+
+
+def sparsity_loss(depth, dmax):
+    """depth: fp32 CUDA tensor (any shape), dmax: 0-d tensor = its (global) maximum, attached to the graph."""
+    if depth.is_cuda and depth.dtype == torch.float32:
+        return _SparsityHead.apply(depth, dmax.reshape(()))
+    return ((depth / (dmax + 1e-5)) ** 2 + 0.01).sqrt().mean()

@@ -28,6 +28,18 @@ from . import dist as gdist
 from .cameras import Camera, CameraBatch
 
 
+class _RenderOut(dict):
+    """The dict ``GaussianDreamer.forward`` returns (:212-219); ``opacity = depth / (depth.max() + 1e-5)`` (:215) is
+    materialised only if somebody reads it -- the loop's sparsity loss uses the fused head (nn_ops.sparsity_loss)."""
+
+    def __missing__(self, key):
+        if key == "opacity":
+            v = self["depth"] / (self["depth_max"] + 1e-5)
+            self[key] = v
+            return v
+        raise KeyError(key)
+
+
 class SDSLoop:
     def __init__(self, gaussians, guidance, prompt_utils, bg_color: torch.Tensor,
                  render_batch_fn: Optional[Callable] = None, lambda_sds: float = 1.0, lambda_sparsity: float = 1.0,
@@ -82,8 +94,8 @@ class SDSLoop:
         images = pkg["render"].permute(0, 2, 3, 1)      # [V,H,W,3]
         depths = pkg["depth_3dgs"].permute(0, 2, 3, 1)  # [V,H,W,1]
         dmax = gdist.global_max(depths.max())
-        return {**pkg, "comp_rgb": images, "depth": depths, "opacity": depths / (dmax + 1e-5),
-                "alphas": pkg["alpha"].permute(0, 2, 3, 1)}
+        return _RenderOut({**pkg, "comp_rgb": images, "depth": depths, "depth_max": dmax,
+                           "alphas": pkg["alpha"].permute(0, 2, 3, 1)})
 
     # -- one iteration ----------------------------------------------------------------------------
     def step(self, batch: Dict, noise=None, timesteps=None, vae_noise=None) -> Dict:
@@ -104,7 +116,8 @@ class SDSLoop:
                               batch["camera_distances"], rgb_as_latents=False, guidance_eval=False, noise=noise,
                               timesteps=timesteps, vae_noise=vae_noise)
         loss_sds = g_out["loss_sds"]
-        loss_sparsity = (out["opacity"] ** 2 + 0.01).sqrt().mean()
+        from . import nn_ops
+        loss_sparsity = nn_ops.sparsity_loss(out["depth"], out["depth_max"])   # mean(sqrt(opacity^2 + 0.01)), :253
         loss = loss_sds * self.lambda_sds + loss_sparsity * self.lambda_sparsity
         if self.native_scene:
             self.gaussians.zero_grad()               # one memset of the flat gradient buffer

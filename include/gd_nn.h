@@ -147,6 +147,24 @@ int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, cons
                                 int64_t o_bs, int o_rs, float scale);
 const char* gd_nn_attention_last_error(void);
 
+/* The guidance's image prologue as ONE kernel each way (threestudio stable_diffusion_guidance.py:394-396 + :164):
+ *   y = bf16( 2 * bilinear_resize(x, (OH, OW), align_corners = False) - 1 ),  x: planar fp32 [N,3,H,W] (what the
+ * rasterizer writes), y: NHWC bf16 [N,OH,OW,3] (what the VAE's first convolution reads).  Backward: dy NHWC bf16 with
+ * CG >= 3 channels per pixel (only the first 3 are read) -> dx planar fp32 [N,3,H,W]; a gather per source pixel, no
+ * atomics, every dx element written once. */
+int gd_nn_vae_prologue_forward(void* stream, const float* x, void* y, int N, int H, int W, int OH, int OW);
+int gd_nn_vae_prologue_backward(void* stream, const void* dy, float* dx, int N, int H, int W, int OH, int OW, int CG);
+
+/* Depth-sparsity head (threestudio systems/GaussianDreamer.py:215,253): with x = depth / (dmax + 1e-5),
+ *   sums2[0] = sum_i sqrt(x_i^2 + 0.01),  sums2[1] = sum_i x_i^2 / sqrt(x_i^2 + 0.01)      (fp64, zeroed inside)
+ * so that loss = sums2[0] / n and d loss / d dmax = -sums2[1] / (n (dmax + 1e-5)).  dmax is a DEVICE scalar (the batch /
+ * all-ranks maximum, produced by the caller so that its own gradient path is kept).  Backward:
+ *   d_depth[i] = grad_out / n * x_i / sqrt(x_i^2 + 0.01) / (dmax + 1e-5). */
+int gd_nn_sparsity_forward(void* stream, const float* depth, const float* dmax, int64_t n, double* sums2);
+int gd_nn_sparsity_backward(void* stream, const float* depth, const float* dmax, const float* grad_out, int64_t n,
+                            float* d_depth);
+const char* gd_nn_prologue_last_error(void);
+
 const char* gd_nn_conv_last_error(void);
 const char* gd_nn_elementwise_last_error(void);
 const char* gd_nn_last_error(void);

@@ -536,3 +536,51 @@ def test_full_size_sds_steps_stay_finite_with_hip_graphs():
         assert torch.isfinite(gm.flat_grad).all().item() and gm.flat_grad.abs().max().item() > 0
         assert torch.isfinite(gm._flat).all().item()
         assert int(out["num_visible"]) == 20000
+
+
+@pytest.mark.parametrize("H,W", [(512, 512), (1024, 1024), (128, 128), (300, 420), (777, 600)])
+def test_vae_prologue_matches_interpolate_affine_cast(H, W):
+    """One launch each way == F.interpolate(bilinear, align_corners=False) * 2 - 1 -> bf16 NHWC and its autograd
+    (stable_diffusion_guidance.py:394-396,164): identity size, the reference's 1024 -> 512, up-sampling, ragged."""
+    from garmentdreamer_amd.nn_ops import vae_prologue, vae_prologue_supported
+    g = torch.Generator(DEV).manual_seed(H + W)
+    x = torch.rand(2, 3, H, W, device=DEV, generator=g)
+    assert vae_prologue_supported(x)
+    xa = x.clone().requires_grad_(True)
+    ya = vae_prologue(xa, 512, 512)
+    assert ya.shape == (2, 3, 512, 512) and ya.dtype == torch.bfloat16 and ya.is_contiguous(memory_format=torch.channels_last)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, (512, 512), mode="bilinear", align_corners=False) * 2.0 - 1.0
+    assert (ya.float() - yr).abs().max().item() <= 2 ** -8 + 1e-6            # one bf16 rounding of values in [-1, 1]
+    # gradient: a 4-channel NHWC gradient whose first three channels are the image's (the first conv's dgrad layout)
+    gy4 = torch.randn(2, 4, 512, 512, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ya.backward(gy4[:, :3])
+    yr.backward(gy4[:, :3].float())
+    scale = xr.grad.abs().max().item()
+    assert (xa.grad - xr.grad).abs().max().item() <= 2e-6 * scale + 1e-6
+    # ... and a plain contiguous 3-channel gradient
+    xb = x.clone().requires_grad_(True)
+    gy3 = torch.randn(2, 3, 512, 512, device=DEV, generator=g)
+    vae_prologue(xb, 512, 512).backward(gy3)
+    xc = x.clone().requires_grad_(True)
+    (F.interpolate(xc, (512, 512), mode="bilinear", align_corners=False) * 2.0 - 1.0).backward(gy3.to(torch.bfloat16).float())
+    assert (xb.grad - xc.grad).abs().max().item() <= 2e-6 * xc.grad.abs().max().item() + 1e-6
+
+
+def test_sparsity_head_matches_torch_ops():
+    """mean(sqrt((depth / (depth.max() + 1e-5))^2 + 0.01)) (GaussianDreamer.py:215,253): value, d/d depth and the
+    gradient that flows through the maximum, against the torch expression."""
+    from garmentdreamer_amd.nn_ops import sparsity_loss
+    g = torch.Generator(DEV).manual_seed(3)
+    d0 = torch.rand(4, 96, 160, 1, device=DEV, generator=g) * 3.0
+    d0[1, 5, 7, 0] = 7.5     # a unique maximum
+    da = d0.clone().requires_grad_(True)
+    la = sparsity_loss(da, da.max())
+    db = d0.clone().requires_grad_(True)
+    lb = ((db / (db.max() + 1e-5)) ** 2 + 0.01).sqrt().mean()
+    assert abs(la.item() - lb.item()) <= 1e-6 * abs(lb.item())
+    (la * 3.0).backward()
+    (lb * 3.0).backward()
+    s = db.grad.abs().max().item()
+    assert (da.grad - db.grad).abs().max().item() <= 1e-5 * s
+    assert abs(da.grad[1, 5, 7, 0].item() - db.grad[1, 5, 7, 0].item()) <= 1e-4 * abs(db.grad[1, 5, 7, 0].item())

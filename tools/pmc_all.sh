@@ -18,7 +18,7 @@ for g in "${groups[@]}"; do
 done
 python - "$out" <<'PY'
 import csv, glob, json, re, sys, collections
-KEEP = ("render_backward", "render_forward", "preprocess", "radix_", "duplicate", "tile_ranges", "conv3x3", "conv_splitk",
+KEEP = ("render_backward", "render_forward", "preprocess", "instance_sum", "radix_", "duplicate", "tile_ranges", "conv3x3", "conv_splitk",
         "gn_", "attn_", "geglu", "add_layernorm", "adam", "activate", "sds_", "vae_prologue", "sparsity", "gemm_", "xattn")
 def short(name):
     n = name.replace("(anonymous namespace)::", "").replace("gd::", "")

@@ -12,7 +12,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # steady region: last 8 render_backward launches delimit 7 steps
-idx = [i for i, r in enumerate(rows) if "render_backward_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "render_backward_strip_kernel" in r["Kernel_Name"]]
 a, b = idx[-8], idx[-1]
 seg = rows[a:b]
 wall = int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])
