@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--per-view-raster", action="store_true", help="reference-style Python loop over views")
     ap.add_argument("--raster-only", action="store_true", help="time only rasterizer fwd+bwd (diagnostic)")
     ap.add_argument("--no-graphs", action="store_true", help="eager launches instead of hipGraph replay of UNet/VAE")
+    ap.add_argument("--fp8", action="store_true",
+                    help="e4m3 3x3 convolutions in the no-grad UNet forward (second, non-headline line: dtype says so)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="six nn.Parameters + torch.optim.Adam(fused) instead of the flat-buffer GaussianModel")
     ap.add_argument("--vsd", action="store_true",
@@ -257,7 +259,8 @@ def main():
         guidance, prompt = None, None
     else:
         guidance = StableDiffusionGuidance({"guidance_scale": 100.0, "grad_clip": [0, 1.5, 2.0, 1000],
-                                            "use_hip_graphs": not args.no_graphs}, device=device)
+                                            "use_hip_graphs": not args.no_graphs, "fp8_unet": bool(args.fp8)},
+                                           device=device)
         prompt = PromptEmbeddings.random(device)
     loop = SDSLoop(gaussians, guidance, prompt, bg)
     if args.per_view_raster:
@@ -417,13 +420,17 @@ def main():
         line = {
             "metric": METRIC, "value": args.steps / elapsed, "unit": "iters/s", "n_gpus": ws, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if not args.fp8 else "bf16 + fp8(e4m3) 3x3 convolutions of the no-grad UNet forward",
+            "data": "synthetic",
             "config": {"workload": (f"SDS loop: {args.gaussians} Gaussians x {args.views} views @{args.res}^2, "
                                     f"SD-2.1 UNet+VAE random-init, {V} view(s)/GPU"),
                        "gaussians": args.gaussians, "views": args.views, "resolution": args.res,
                        "views_per_gpu": V, "parallelism": f"view-sharded dp{ws}",
                        "raster": "per-view loop" if args.per_view_raster else "batched",
                        "raster_only": bool(args.raster_only), "hip_graphs": graphs_active,
+                       "fp8_unet_sites": (guidance.unet.fp8.sites_run if guidance is not None and
+                                          getattr(guidance.unet, "fp8", None) is not None else 0),
                        "kernels_per_step": kernels_per_step},
             "roofline": roofline_conv if roofline_conv is not None else roofline,
             "roofline_raster_bwd": roofline,

@@ -7,6 +7,7 @@ NN_SOURCES = [
     ("nn_elementwise.hip", []),
     ("nn_attention.hip", []),
     ("nn_prologue.hip", ["-munsafe-fp-atomics"]),
+    ("nn_fp8.hip", []),
 ]
 
 

@@ -177,6 +177,47 @@ __global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict
     }
 }
 
+// Same pass with an e4m3 result (one fp32 scale per tensor, value = scale * byte): the input of the fp8 convolution of
+// the no-grad UNet forward (csrc/nn_fp8.hip) -- the quantisation costs no extra pass and halves the bytes written.
+__global__ void gn_apply_fp8_kernel(const bf16x8* __restrict__ x, uint2* __restrict__ y,
+                                    const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta, int HW, int C,
+                                    int G, int vpp, int rows, int ppb, int apply_silu,
+                                    const float* __restrict__ mean_rstd, float inv_scale)
+{
+    const int n = blockIdx.y;
+    const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    const int cg = C / G;
+    float a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = tv * 8 + k, g = c / cg;
+        const float mean = mean_rstd[((size_t)n * G + g) * 2];
+        const float rstd = mean_rstd[((size_t)n * G + g) * 2 + 1];
+        a[k] = rstd * bf2f(gamma[c]);
+        b[k] = bf2f(beta[c]) - mean * a[k];
+    }
+    const bf16x8* xn = x + (size_t)n * HW * vpp;
+    uint2* yn = y + (size_t)n * HW * vpp;
+    for (int p = p0 + tr; p < p1; p += rows) {
+        const bf16x8 v = xn[(size_t)p * vpp + tv];
+        float z[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float t = bf2f(v.v[k]) * a[k] + b[k];
+            if (apply_silu) t = silu_f(t);
+            // the bf16 rounding of the unfused path first (same values as gn_apply_kernel), then scale + saturate
+            z[k] = fminf(fmaxf(bf2f(f2bf(t)) * inv_scale, -448.f), 448.f);
+        }
+        int o0 = 0, o1 = 0;
+        o0 = __builtin_amdgcn_cvt_pk_fp8_f32(z[0], z[1], o0, false);
+        o0 = __builtin_amdgcn_cvt_pk_fp8_f32(z[2], z[3], o0, true);
+        o1 = __builtin_amdgcn_cvt_pk_fp8_f32(z[4], z[5], o1, false);
+        o1 = __builtin_amdgcn_cvt_pk_fp8_f32(z[6], z[7], o1, true);
+        yn[(size_t)p * vpp + tv] = make_uint2((uint32_t)o0, (uint32_t)o1);
+    }
+}
+
 // dz = dy * silu'(z) (or dy); per group: s1 = sum gamma*dz, s2 = sum gamma*dz*xhat
 __global__ void gn_bwd_stats_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy,
                                     const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
@@ -327,6 +368,24 @@ int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const voi
                        g.ppb_stats, eps, stats_ws, mean_rstd, N, 0);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (bf16x8*)y, (const uint16_t*)gamma,
                        (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, apply_silu, mean_rstd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_groupnorm_silu_forward_fp8(void* stream, const void* x, void* y_fp8, const void* gamma, const void* beta, int N,
+                                     int HW, int C, int G, float eps, int apply_silu, double* stats_ws, float* mean_rstd,
+                                     float inv_scale)
+{
+    Geo g;
+    if (!x || !y_fp8 || !gamma || !beta || !stats_ws || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(g.nchunks, N), block(g.threads), grid_s(g.nchunks_stats, N);
+    hipLaunchKernelGGL(gn_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows,
+                       g.ppb_stats, eps, stats_ws, mean_rstd, N, 0);
+    hipLaunchKernelGGL(gn_apply_fp8_kernel, grid, block, 0, s, (const bf16x8*)x, (uint2*)y_fp8, (const uint16_t*)gamma,
+                       (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, apply_silu, mean_rstd, inv_scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

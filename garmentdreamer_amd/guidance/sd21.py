@@ -43,6 +43,7 @@ from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, co
 import os as _os
 
 _FUSED_QKV = _os.environ.get("GD_FUSED_QKV", "1") != "0"   # A/B toggle of the fused self-attention projection
+_FP8_ACTIVE = [None]   # the nn_ops.Fp8State of the UNet whose no-grad forward is running (set by its forward)
 
 
 def _gn(norm: nn.GroupNorm, x, silu: bool):
@@ -74,6 +75,17 @@ def _gn_conv3(norm: nn.GroupNorm, conv: nn.Conv2d, x, image_bias=None, residual=
     GroupNorm kernel + plain convolution (LDS-DMA patch kernel or implicit GEMM, chosen by the library) is faster."""
     frozen = not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
     frozen = frozen and (image_bias is None or not image_bias.requires_grad)
+    st = _FP8_ACTIVE[0]
+    if st is not None and frozen and not torch.is_grad_enabled() and st.wants(conv, x):
+        # e4m3 path of the no-grad UNet forward (nn_ops.Fp8State): calibration runs this site in bf16 and records
+        # the activation range, afterwards GroupNorm+SiLU writes e4m3 and the convolution runs on the fp8 kernel
+        bias = conv.bias if image_bias is None else image_bias
+        if st.mode == "run" and id(conv) in st.amax:
+            return st.gn_conv(norm, conv, x, bias, residual)
+        act = _gn(norm, x, True)
+        if st.mode == "calibrate":
+            st.observe(conv, act)
+        return _conv3(conv, act, image_bias=image_bias, residual=residual)
     if x.is_cuda and frozen and gn_conv_prefers_fused(x, conv.out_channels) and \
             gn_conv3x3_supported(x, norm.weight, conv.weight):
         return gn_conv3x3(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True, conv.weight,
@@ -484,7 +496,26 @@ class UNet2DConditionModel(nn.Module):
             off += c
         return TembProjections(temb, out)
 
+    fp8 = None    # nn_ops.Fp8State: e4m3 convolutions in the no-grad forward (enable_fp8); None = bf16 everywhere
+
+    def enable_fp8(self, state=None):
+        """Run the 3x3 convolutions of the no-grad forward in e4m3 (nn_ops.Fp8State).  The first no-grad forward(s)
+        calibrate the activation ranges in bf16 until ``fp8.mode`` is set to "run" (the guidance does that after one
+        call).  Returns the state."""
+        from ..nn_ops import Fp8State
+        self.fp8 = state if state is not None else Fp8State()
+        return self.fp8
+
     def forward(self, sample, timestep, encoder_hidden_states, **kwargs):
+        if self.fp8 is not None and not torch.is_grad_enabled() and sample.is_cuda:
+            _FP8_ACTIVE[0] = self.fp8
+            try:
+                return self._forward(sample, timestep, encoder_hidden_states, **kwargs)
+            finally:
+                _FP8_ACTIVE[0] = None
+        return self._forward(sample, timestep, encoder_hidden_states, **kwargs)
+
+    def _forward(self, sample, timestep, encoder_hidden_states, **kwargs):
         dtype = self.conv_in.weight.dtype
         if timestep.dim() == 0:
             timestep = timestep[None].expand(sample.shape[0])

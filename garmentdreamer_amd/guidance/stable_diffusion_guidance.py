@@ -74,6 +74,9 @@ class StableDiffusionGuidance(nn.Module):
         # batch shape).  The step is launch-bound once a GPU holds only 1-2 views (8-GPU sharding:
         # ~1500 kernels of ~5 us each); graphs remove the per-kernel host cost.  Numerics unchanged.
         use_hip_graphs: bool = False
+        # e4m3 3x3 convolutions in the no-grad UNet forward (BASELINE configs[4], nn_ops.Fp8State): the first
+        # forward_unet call calibrates the activation ranges in bf16, later calls run fp8.  bf16 stays the default.
+        fp8_unet: bool = False
 
     def __init__(self, cfg: Optional[dict] = None, device="cuda", unet: Optional[nn.Module] = None,
                  vae: Optional[nn.Module] = None):
@@ -115,6 +118,9 @@ class StableDiffusionGuidance(nn.Module):
         self.grad_clip_val: Optional[float] = None
         self._unet_graphs = {}
         self._vae_graphs = {}
+        self._fp8_calibrated = False
+        if self.cfg.fp8_unet and self.weights_dtype == torch.bfloat16 and self.device.type == "cuda":
+            self.unet.enable_fp8()
         if self.cfg.use_hip_graphs and not _runtime_env.graph_replay_safe():
             import warnings
             warnings.warn(f"{_runtime_env.FLAG}=0 was not in place before the HIP runtime started; hipGraph replay of "
@@ -132,6 +138,13 @@ class StableDiffusionGuidance(nn.Module):
         # would round t > 256 to a multiple of 2 or 4, so with bf16 weights the timestep stays fp32
         t_dtype = torch.float32 if self.weights_dtype == torch.bfloat16 else self.weights_dtype
         x, tt, ctx = latents.to(self.weights_dtype), t.to(t_dtype), encoder_hidden_states.to(self.weights_dtype)
+        fp8 = getattr(self.unet, "fp8", None)
+        if fp8 is not None and not self._fp8_calibrated and not torch.is_grad_enabled():
+            # one eager bf16 forward on the real inputs records every fp8 site's activation range
+            out = self.unet(x, tt, encoder_hidden_states=ctx).to(input_dtype)
+            fp8.mode = "run"
+            self._fp8_calibrated = True
+            return out
         if self.cfg.use_hip_graphs and x.is_cuda and not torch.is_grad_enabled():
             try:
                 return self._graphed_unet(x, tt, ctx).to(input_dtype)

@@ -26,6 +26,7 @@ SIGNATURES = {
     "gd_nn_conv_force_split": (_i, [_i]),
     "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
     "gd_nn_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "gd_nn_groupnorm_silu_forward_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _f]),
     "gd_nn_conv3x3_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
@@ -47,6 +48,11 @@ SIGNATURES = {
     "gd_nn_sparsity_forward": (_i, [_vp, _vp, _vp, C.c_int64, _vp]),
     "gd_nn_sparsity_backward": (_i, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "gd_nn_prologue_last_error": (C.c_char_p, []),
+    "gd_nn_fp8_quantize": (_i, [_vp, _vp, _vp, C.c_int64, _f]),
+    "gd_nn_fp8_pack_weights": (_i, [_vp, _vp, _vp, C.c_int64, _i, _i, _f]),
+    "gd_nn_fp8_linear_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _i, _f]),
+    "gd_nn_fp8_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f]),
+    "gd_nn_fp8_last_error": (C.c_char_p, []),
     "gd_nn_conv_last_error": (C.c_char_p, []),
     "gd_nn_elementwise_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
@@ -809,3 +815,123 @@ def sparsity_loss(depth, dmax):
     if depth.is_cuda and depth.dtype == torch.float32:
         return _SparsityHead.apply(depth, dmax.reshape(()))
     return ((depth / (dmax + 1e-5)) ** 2 + 0.01).sqrt().mean()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3) path of the no-grad UNet forward (csrc/nn_fp8.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+FP8_MAX = 448.0
+
+
+def _check8(ret, what):
+    if ret < 0:
+        raise RuntimeError(f"{what} failed ({ret}): {lib().gd_nn_fp8_last_error().decode()}")
+
+
+def fp8_quantize(x, scale: float):
+    """bf16 tensor -> e4m3 bytes (uint8 tensor of the same shape), value = scale * byte."""
+    xc = x.contiguous()
+    y = torch.empty(xc.shape, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _check8(lib().gd_nn_fp8_quantize(torch.cuda.current_stream(x.device).cuda_stream, xc.data_ptr(), y.data_ptr(),
+                                         xc.numel(), 1.0 / scale), "gd_nn_fp8_quantize")
+    return y
+
+
+def fp8_pack_weights(w2d, scale: float):
+    """bf16 [rows, K] -> e4m3 [rows, Kp] with Kp = K rounded up to 128 (zero padded)."""
+    rows, K = w2d.shape
+    Kp = (K + 127) // 128 * 128
+    wc = w2d.contiguous()
+    out = torch.empty((rows, Kp), dtype=torch.uint8, device=w2d.device)
+    with torch.cuda.device(w2d.device):
+        _check8(lib().gd_nn_fp8_pack_weights(torch.cuda.current_stream(w2d.device).cuda_stream, wc.data_ptr(),
+                                             out.data_ptr(), rows, K, Kp, 1.0 / scale), "gd_nn_fp8_pack_weights")
+    return out
+
+
+def fp8_linear(x8, w8, bias, residual, K: int, dq: float):
+    """x8: e4m3 [..., K], w8: e4m3 [Nout, Kp] -> bf16 [..., Nout] = dq * x8 . w8^T + bias + residual."""
+    Nout, Kp = w8.shape
+    M = x8.numel() // K
+    y = torch.empty(x8.shape[:-1] + (Nout,), dtype=torch.bfloat16, device=x8.device)
+    p = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    with torch.cuda.device(x8.device):
+        _check8(lib().gd_nn_fp8_linear_forward(torch.cuda.current_stream(x8.device).cuda_stream, x8.data_ptr(), w8.data_ptr(),
+                                               p(bias), p(residual), y.data_ptr(), M, K, Kp, Nout, dq),
+                "gd_nn_fp8_linear_forward")
+    return y
+
+
+def fp8_conv3x3(x8, w8, bias, residual, Cin: int, dq: float):
+    """x8: e4m3 NHWC bytes as a channels_last uint8 tensor [N, Cin, H, W]; w8: e4m3 [Cout * 9, CinP];
+    bias: bf16 [Cout] or per image [N, Cout]; residual: bf16 channels_last [N, Cout, H, W]."""
+    N, _, H, W = x8.shape
+    CinP = w8.shape[1]
+    Cout = w8.shape[0] // 9
+    y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x8.device, memory_format=torch.channels_last)
+    b, bs = _bias_and_stride(bias)
+    with torch.cuda.device(x8.device):
+        _check8(lib().gd_nn_fp8_conv3x3_forward(torch.cuda.current_stream(x8.device).cuda_stream, x8.data_ptr(),
+                                                w8.data_ptr(), None if b is None else b.data_ptr(), bs,
+                                                None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W,
+                                                Cin, CinP, Cout, dq), "gd_nn_fp8_conv3x3_forward")
+    return y
+
+
+def group_norm_silu_fp8(x, weight, bias, groups: int, eps: float, silu: bool, scale: float):
+    """``e4m3(act(GN(x)) / scale)`` of a bf16 channels_last tensor as a channels_last uint8 tensor (inference only)."""
+    N, Cc, H, W = x.shape
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    y = torch.empty((N, Cc, H, W), dtype=torch.uint8, device=x.device, memory_format=torch.channels_last)
+    ws = _gn_workspace(x, N, groups)
+    mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+    w, b = weight.contiguous(), bias.contiguous()
+    with torch.cuda.device(x.device):
+        _check(lib().gd_nn_groupnorm_silu_forward_fp8(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
+                                                      y.data_ptr(), w.data_ptr(), b.data_ptr(), N, H * W, Cc, groups,
+                                                      float(eps), int(silu), ws.data_ptr(), mr.data_ptr(), 1.0 / scale),
+               "gd_nn_groupnorm_silu_forward_fp8")
+    return y
+
+
+class Fp8State:
+    """Static per-tensor e4m3 quantisation of the frozen UNet's 3x3 convolutions for the no-grad forward.
+
+    ``mode == "calibrate"``: the forward runs in bf16 and records the largest |activation| every fp8 site sees;
+    ``mode == "run"``: sites whose shape profits (tools/fp8_bench.py: everything but the 8x8 maps) run
+    GroupNorm+SiLU -> e4m3 (one kernel) and the fp8 implicit-GEMM convolution with scale = margin * amax / 448 for
+    the activations and |w|max / 448 for the (cached) weights."""
+
+    def __init__(self, margin: float = 2.0, min_pixels: int = 2048):
+        self.mode = "calibrate"
+        self.margin, self.min_pixels = margin, min_pixels
+        self.amax = {}       # id(conv) -> python float
+        self.weights = {}    # id(conv) -> (w8, w_scale, weight version)
+        self.sites_run = 0
+
+    def wants(self, conv, x) -> bool:
+        N, Cin, H, W = x.shape
+        return (x.is_cuda and x.dtype == torch.bfloat16 and N * H * W >= self.min_pixels and Cin % 16 == 0
+                and conv.out_channels % 4 == 0 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                and conv.padding == (1, 1))
+
+    def observe(self, conv, act):
+        self.amax[id(conv)] = max(self.amax.get(id(conv), 0.0), float(act.detach().abs().max()))
+
+    def _weights(self, conv):
+        w = conv.weight
+        ent = self.weights.get(id(conv))
+        if ent is None or ent[2] != w._version:
+            ws = max(float(w.detach().abs().max()), 1e-12) / FP8_MAX
+            w2d = w.detach().to(torch.bfloat16).permute(0, 2, 3, 1).reshape(w.shape[0] * 9, w.shape[1])   # [Cout][3][3][Cin]
+            ent = self.weights[id(conv)] = (fp8_pack_weights(w2d, ws), ws, w._version)
+        return ent
+
+    def gn_conv(self, norm, conv, x, bias, residual):
+        sx = max(self.amax[id(conv)], 1e-6) * self.margin / FP8_MAX
+        w8, ws, _ = self._weights(conv)
+        x8 = group_norm_silu_fp8(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True, sx)
+        self.sites_run += 1
+        return fp8_conv3x3(x8, w8, bias, residual, x.shape[1], sx * ws)

@@ -165,6 +165,28 @@ int gd_nn_sparsity_backward(void* stream, const float* depth, const float* dmax,
                             float* d_depth);
 const char* gd_nn_prologue_last_error(void);
 
+/* ---- fp8 (OCP e4m3) path of the no-grad UNet forward (csrc/nn_fp8.hip) --------------------------------------------
+ * One fp32 scale per tensor: value = scale * e4m3 byte.  dq = scale_x * scale_w is applied to the fp32 accumulator,
+ * then bias (bf16) and residual (bf16) are added and the result is stored as bf16.
+ *   gd_nn_fp8_quantize       y8[i] = e4m3(clamp(x[i] * inv_scale, +-448)), x bf16, n % 8 == 0
+ *   gd_nn_fp8_pack_weights   w8[r][0..Kp) = e4m3(w[r][0..K) * inv_scale) zero-padded to Kp (% 128 == 0); rows = Cout
+ *                            (linear) or Cout * 9 (3x3 weights in [Cout][3][3][Cin] order)
+ *   gd_nn_fp8_linear_forward y[M][Nout] = dq * x8[M][K] . w8[Nout][Kp]^T + bias[Nout] + residual[M][Nout]
+ *                            (nn.Linear of the transformer blocks: diffusers Attention / FeedForward / proj_in / proj_out)
+ *   gd_nn_fp8_conv3x3_forward  3x3 / stride 1 / pad 1 on NHWC e4m3 activations, per-image bias stride as
+ *                            gd_nn_conv3x3_forward (diffusers ResnetBlock2D convolutions). */
+int gd_nn_fp8_quantize(void* stream, const void* x_bf16, void* y_fp8, int64_t n, float inv_scale);
+/* gd_nn_groupnorm_silu_forward with an e4m3 result: y8 = e4m3(clamp(bf16(act(GN(x))) * inv_scale, +-448)), NHWC bytes. */
+int gd_nn_groupnorm_silu_forward_fp8(void* stream, const void* x, void* y_fp8, const void* gamma, const void* beta, int N,
+                                     int HW, int C, int G, float eps, int apply_silu, double* stats_ws, float* mean_rstd,
+                                     float inv_scale);
+int gd_nn_fp8_pack_weights(void* stream, const void* w_bf16, void* w_fp8, int64_t rows, int K, int Kp, float inv_scale);
+int gd_nn_fp8_linear_forward(void* stream, const void* x_fp8, const void* w_fp8, const void* bias, const void* residual,
+                             void* y, int64_t M, int K, int Kp, int Nout, float dq);
+int gd_nn_fp8_conv3x3_forward(void* stream, const void* x_fp8, const void* w_fp8, const void* bias, int bias_img_stride,
+                              const void* residual, void* y, int N, int H, int W, int Cin, int CinP, int Cout, float dq);
+const char* gd_nn_fp8_last_error(void);
+
 const char* gd_nn_conv_last_error(void);
 const char* gd_nn_elementwise_last_error(void);
 const char* gd_nn_last_error(void);
