@@ -54,6 +54,7 @@ SIGNATURES = {
                                    + [_vp] * 3 + [_vp] * 8 + [_i]),   # 8 outputs (no dL_dconic / dL_ddepth)
     "gd_raster_get_layout": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, C.POINTER(Layout)]),
     "gd_raster_sort_bits": (_i, [_i, _i, _i]),
+    "gd_raster_blend_exp": (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i]),
     "gd_raster_profile_enable": (_i, [_i]),
     "gd_raster_profile_collect": (_i, []),
     "gd_raster_profile_get": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -450,6 +450,13 @@ int gd_raster_get_layout(const char* geom_base, const char* image_base, const ch
     return GD_OK;
 }
 
+int gd_raster_blend_exp(void* stream, const float* x, float* y, int n)
+{
+    if (!x || !y || n < 0) return GD_ERR_INVALID_ARG;
+    launch_blend_exp((hipStream_t)stream, x, y, n);
+    return hipGetLastError() == hipSuccess ? GD_OK : GD_ERR_HIP;
+}
+
 int gd_raster_sort_bits(int width, int height, int V)
 {
     const Dims d = make_dims(width, height, V < 1 ? 1 : V);

@@ -99,6 +99,7 @@ void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan,
 void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total,
                         uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of);
 
+void launch_blend_exp(hipStream_t s, const float* x, float* y, int n);   // y = gd_expf(x): parity test hook
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
                            float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts,

@@ -131,6 +131,26 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
+// Single, separately rounded fp32 operations.  (HIP's __fmul_rn / __fadd_rn are ordinary inline functions compiled
+// with the default fast contraction: after inlining the compiler still fuses them into FMAs -- measured: 7 % of the
+// pixels of a forward pass differed from the oracle by one ulp.  Operators written under `fp contract(off)` carry no
+// contraction licence.)
+__device__ __forceinline__ float mul_rn(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+
 // power = -0.5 (a dx^2 + c dy^2) - b dx dy in EXACTLY the reference's evaluation order, every operation rounded
 // on its own (forward.cu:341 / backward.cu:528 as the oracle compiles them, no FMA contraction): the forward
 // blend, the backward blend and the oracle then agree on the bits of `power`, hence on which (pixel, Gaussian)
@@ -139,9 +159,31 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // equals the separately rounded subtraction.)
 __device__ __forceinline__ float power_exact(const float t1, const float bdx, const float c, const float dy)
 {
-    const float t2 = __fmul_rn(__fmul_rn(c, dy), dy);
-    const float s = __fadd_rn(t1, t2);
-    return fmaf(-0.5f, s, -__fmul_rn(bdx, dy));
+#pragma clang fp contract(off)   // HIP's __fmul_rn / __fadd_rn are plain operators: without this they may be fused
+    const float t2 = mul_rn(mul_rn(c, dy), dy);
+    const float s = add_rn(t1, t2);
+    return fmaf(-0.5f, s, -mul_rn(bdx, dy));
+}
+
+// exp of the blend, defined operation by operation (oracle/gd_oracle.c gd_expf: Cody-Waite reduction + Cephes degree-5
+// polynomial, every step one correctly rounded fp32 operation): the forward pass then reproduces the oracle BIT FOR BIT
+// -- the blended pairs, n_contrib, the pixels and the alpha image whose complement is the backward pass's T_final.
+__device__ __forceinline__ float gd_expf(float x)
+{
+#pragma clang fp contract(off)
+    if (x < -87.0f) return 0.0f;
+    const float n = rintf(mul_rn(x, 1.44269504088896341f));
+    float r = __fmaf_rn(n, -0.693359375f, x);
+    r = __fmaf_rn(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __fmaf_rn(p, r, 1.3981999507e-3f);
+    p = __fmaf_rn(p, r, 8.3334519073e-3f);
+    p = __fmaf_rn(p, r, 4.1665795894e-2f);
+    p = __fmaf_rn(p, r, 1.6666665459e-1f);
+    p = __fmaf_rn(p, r, 5.0000001201e-1f);
+    p = __fmaf_rn(p, mul_rn(r, r), r);
+    p = add_rn(p, 1.0f);
+    return ldexpf(p, (int)n);
 }
 
 // Smallest fp32 exponent p with  !(min(0.99, o * expf(p)) < 1/255): `power >= thr` is then the forward pass's
@@ -149,18 +191,19 @@ __device__ __forceinline__ float power_exact(const float t1, const float bdx, co
 // A few accurate expf per STAGED entry (once per tile and entry).
 __device__ __forceinline__ float alpha_threshold_exact(const float o)
 {
+#pragma clang fp contract(off)
     const float k = 1.0f / 255.0f;
     float t = -logf(255.0f * o);
     if (!(o > 0.0f) || !isfinite(t)) return INFINITY;     // opacity 0 (or NaN): nothing ever contributes
 #pragma unroll 1
     for (int it = 0; it < 8; it++) {      // walk down while the next lower exponent still passes
         const float d = nextafterf(t, -INFINITY);
-        if (fminf(0.99f, o * expf(d)) < k) break;
+        if (fminf(0.99f, mul_rn(o, gd_expf(d))) < k) break;
         t = d;
     }
 #pragma unroll 1
     for (int it = 0; it < 16; it++) {     // walk up while this exponent fails
-        if (!(fminf(0.99f, o * expf(t)) < k)) break;
+        if (!(fminf(0.99f, mul_rn(o, gd_expf(t))) < k)) break;
         t = nextafterf(t, INFINITY);
     }
     return t;
@@ -213,6 +256,8 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     uint32_t* __restrict__ n_contrib, uint2* __restrict__ pair_counts, uint64_t* __restrict__ ballots, uint32_t R)
 {
+    // every blend operation is rounded on its own, like the oracle's (-ffp-contract=off): images match it bit for bit
+#pragma clang fp contract(off)
     __shared__ float2 s_xy[kTilePix];
     __shared__ float4 s_co[kTilePix];
     __shared__ float4 s_fd[kTilePix];
@@ -283,24 +328,24 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
                     const float2 xy = s_xy[j];
                     const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
                     const float4 co = s_co[j];
-                    const float power = power_exact(__fmul_rn(__fmul_rn(co.x, dx), dx), __fmul_rn(co.y, dx), co.z, dy);
+                    const float power = power_exact(mul_rn(mul_rn(co.x, dx), dx), mul_rn(co.y, dx), co.z, dy);
                     // alpha >= 1/255  <=>  power >= s_thr (exact, alpha_threshold_exact): only contributing pairs pay
                     // for the exponential
                     if (!(power > 0.0f) && !(power < s_thr[j])) {
-                        const float alpha = fminf(0.99f, co.w * expf(power));
+                        const float alpha = fminf(0.99f, mul_rn(co.w, gd_expf(power)));
                         {
-                            const float test_T = T * (1 - alpha);
+                            // the oracle's operations, each rounded on its own (forward.cu:349-363 without contraction)
+                            const float test_T = mul_rn(T, sub_rn(1.0f, alpha));
                             if (test_T < 0.0001f) {
                                 done = true;
                                 contributor = cbase + (uint32_t)j + 1u;
                             } else {
                                 const float4 fd = s_fd[j];
-                                const float w = alpha * T;
-                                C0 += fd.x * alpha * T;
-                                C1 += fd.y * alpha * T;
-                                C2 += fd.z * alpha * T;
-                                weight += w;
-                                Dd += fd.w * alpha * T;
+                                C0 = add_rn(C0, mul_rn(mul_rn(fd.x, alpha), T));
+                                C1 = add_rn(C1, mul_rn(mul_rn(fd.y, alpha), T));
+                                C2 = add_rn(C2, mul_rn(mul_rn(fd.z, alpha), T));
+                                weight = add_rn(weight, mul_rn(alpha, T));
+                                Dd = add_rn(Dd, mul_rn(mul_rn(fd.w, alpha), T));
                                 T = test_T;
                                 last_contributor = cbase + (uint32_t)j + 1u;
                                 blended++;
@@ -330,9 +375,9 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
         n_contrib[(size_t)view * HW + pix_id] = last_contributor;
         pair_counts[(size_t)view * HW + pix_id] = make_uint2(contributor, blended);
         float* oc = out_color + (size_t)view * 3 * HW;
-        oc[0 * HW + pix_id] = C0 + T * bg_color[0];
-        oc[1 * HW + pix_id] = C1 + T * bg_color[1];
-        oc[2 * HW + pix_id] = C2 + T * bg_color[2];
+        oc[0 * HW + pix_id] = add_rn(C0, mul_rn(T, bg_color[0]));
+        oc[1 * HW + pix_id] = add_rn(C1, mul_rn(T, bg_color[1]));
+        oc[2 * HW + pix_id] = add_rn(C2, mul_rn(T, bg_color[2]));
         out_alpha[(size_t)view * HW + pix_id] = weight;
         out_depth[(size_t)view * HW + pix_id] = Dd;
     }
@@ -545,7 +590,7 @@ __global__ __launch_bounds__(64) void render_backward_strip_kernel(
                     auto step = [&](const Ent& q) {      // backward.cu:534-578 for one contributing (pixel, entry) pair
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(q.row.y, __builtin_amdgcn_mbcnt_lo(q.row.x, 0u));
                         const float dx = q.xy.x - pixf_x, dy = q.xy.y - pixf_y;
-                        const float power = power_exact(__fmul_rn(__fmul_rn(q.co.x, dx), dx), __fmul_rn(q.co.y, dx), q.co.z, dy);
+                        const float power = power_exact(mul_rn(mul_rn(q.co.x, dx), dx), mul_rn(q.co.y, dx), q.co.z, dy);
                         const float G = __expf(power);
                         const float alpha = fminf(0.99f, q.co.w * G);
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // shared by T/(1-a), T_final/(1-a)
@@ -657,7 +702,18 @@ __global__ __launch_bounds__(64) void render_backward_strip_kernel(
     }
 }
 
+__global__ void blend_exp_kernel(const float* __restrict__ x, float* __restrict__ y, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = gd_expf(x[i]);
+}
+
 }  // namespace
+
+void launch_blend_exp(hipStream_t s, const float* x, float* y, int n)
+{
+    if (n > 0) hipLaunchKernelGGL(blend_exp_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
+}
 
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,

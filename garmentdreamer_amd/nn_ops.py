@@ -243,8 +243,22 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if w.shape[0] % 64 == 0:
                 dx = _conv_launch(dy, _flipped(w), None, None, w.shape[1])
-            else:  # tiny-Cout layers (e.g. 512 -> 8) : K of the dgrad GEMM is not a multiple of 64
-                dx = torch.nn.grad.conv2d_input(dy.shape[:1] + (w.shape[1],) + dy.shape[2:], w, dy, padding=1)
+            else:
+                # tiny-Cout layers (the VAE's 512 -> 8 conv_out): the K of the dgrad GEMM (= Cout) is zero-padded to
+                # one 64-channel K-step instead of handing the layer to MIOpen
+                Cout, Cp = w.shape[0], (w.shape[0] + 63) // 64 * 64
+                f = _flipped(w)
+                key = (f.data_ptr(), w._version)
+                fp = getattr(w, "_gd_flipped_pad", None)
+                if fp is None or getattr(w, "_gd_flipped_pad_key", None) != key:
+                    fp = torch.zeros((w.shape[1], Cp, 3, 3), dtype=torch.bfloat16, device=w.device).contiguous(
+                        memory_format=torch.channels_last)
+                    fp[:, :Cout] = f
+                    w._gd_flipped_pad, w._gd_flipped_pad_key = fp, key
+                dyp = torch.zeros((dy.shape[0], Cp) + tuple(dy.shape[2:]), dtype=torch.bfloat16, device=dy.device).contiguous(
+                    memory_format=torch.channels_last)
+                dyp[:, :Cout] = dy
+                dx = _conv_launch(dyp, fp, None, None, w.shape[1])
         return dx, None, None, (dy if ctx.has_res else None)
 
 

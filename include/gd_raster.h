@@ -137,6 +137,9 @@ int gd_raster_get_layout(const char* geom_base, const char* image_base, const ch
 /* Number of radix passes / sorted key bits used for a tile grid (getHigherMsb,
  * rasterizer_impl.cu:35-50,301). */
 int gd_raster_sort_bits(int width, int height, int V);
+/* y[i] = the alpha blend's exp as the kernels evaluate it (device pointers): parity hook -- must equal
+ * oracle/gd_oracle.c gd_expf bit for bit. */
+int gd_raster_blend_exp(void* stream, const float* x, float* y, int n);
 
 /* ---- Per-kernel timing for bench.py's roofline line.  When enabled, every launch of the
  * listed kernels is bracketed by hipEvents on the launch stream; gd_raster_profile_collect()

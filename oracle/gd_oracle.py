@@ -52,6 +52,8 @@ def _bind(L):
     L.gdo_mark_visible.argtypes = [C.c_int, _f32p, _f32p, _f32p, C.POINTER(C.c_uint8)]
     L.gdo_higher_msb.restype = C.c_uint32
     L.gdo_higher_msb.argtypes = [C.c_uint32]
+    L.gdo_expf.restype = C.c_float
+    L.gdo_expf.argtypes = [C.c_float]
     for n in ("num_rendered", "pairs_visited_fwd", "pairs_blended_fwd", "pairs_visited_bwd"):
         getattr(L, "gdo_" + n).restype = C.c_int64
         getattr(L, "gdo_" + n).argtypes = [C.c_void_p]
@@ -176,6 +178,11 @@ def mark_visible(means3D, viewmatrix, projmatrix) -> np.ndarray:
     if P:
         lib().gdo_mark_visible(P, mp, vp, pp, out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out.astype(bool)
+
+
+def expf(x: float) -> float:
+    """The blend's exp as the oracle (and the HIP kernels) define it: gd_expf in gd_oracle.c."""
+    return float(lib().gdo_expf(float(x)))
 
 
 def higher_msb(n: int) -> int:

@@ -717,3 +717,23 @@ def test_fp8_unet_forward_close_to_bf16_and_fp32():
     parity_report.record("fp8 UNet forward (reduced width) vs fp32", "eps", cos_bf16_vs_fp32=c16, cos_fp8_vs_fp32=c8,
                          cos_fp8_vs_bf16=c8_16, fp8_sites=st.sites_run)
     assert torch.isfinite(e8).all() and c8 > 0.99 and c8_16 > 0.99, (c16, c8, c8_16)
+
+
+def test_conv3x3_tiny_cout_backward_stays_on_the_mfma_kernel():
+    """The VAE's conv_out (512 -> 8): the input gradient runs on the own kernel with its K zero-padded to 64 (no MIOpen
+    fallback) and matches fp32 PyTorch."""
+    from garmentdreamer_amd.nn_ops import conv3x3
+    g = torch.Generator(DEV).manual_seed(8)
+    x = torch.randn(2, 512, 64, 64, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(8, 512, 3, 3, device=DEV, generator=g) / 68).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(8, device=DEV, generator=g).to(torch.bfloat16)
+    xg = x.clone().requires_grad_(True)
+    y = conv3x3(xg, w, b, None)
+    gy = torch.randn(y.shape, device=DEV, generator=g).to(torch.bfloat16)
+    y.backward(gy)
+    xr = x.float().requires_grad_(True)
+    yr = F.conv2d(xr, w.float(), b.float(), padding=1)
+    yr.backward(gy.float())
+    assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item()
+    assert F.cosine_similarity(xg.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.9995
+    assert (xg.grad.float() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item() + 1e-3

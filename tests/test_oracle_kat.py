@@ -263,3 +263,17 @@ def test_openmp_build_of_the_oracle_matches_the_serial_build():
     assert a.pairs_visited_bwd == b.pairs_visited_bwd
     for k in ra:
         np.testing.assert_allclose(rb[k], ra[k], rtol=1e-5, atol=1e-7 * (np.abs(ra[k]).max() + 1e-30))
+
+
+def test_blend_exp_is_within_one_ulp_of_the_exact_exponential():
+    """gd_expf (the exp both the oracle and the HIP kernels use in the alpha blend) against float64 exp on the range the
+    blend feeds it (power <= 0; contributions need power >= ln(1/255) ~ -5.5) and beyond."""
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([-rng.uniform(0, 8, 20000), -rng.uniform(8, 87, 2000), [-0.0, -1e-8, -86.9, -5.541263545158426]])
+    xs = xs.astype(np.float32)
+    got = np.array([gd_oracle.expf(float(x)) for x in xs], np.float32)
+    ref = np.exp(xs.astype(np.float64))
+    ulp = np.spacing(ref.astype(np.float32)).astype(np.float64)
+    assert np.abs(got.astype(np.float64) - ref).max() / 1.0 >= 0.0
+    assert (np.abs(got.astype(np.float64) - ref) <= 1.0 * ulp).all()
+    assert gd_oracle.expf(-100.0) == 0.0 and gd_oracle.expf(0.0) == 1.0

@@ -61,7 +61,11 @@ def _check_forward(inp, st, out, exact_ncontrib=True):
         err = np.abs(g - o)
         tol = 1e-5 + 1e-4 * np.abs(o)
         bad = (err > tol) & ok[None]
-        parity_report.record(case, name, max_abs_err=(err * ok[None]).max(), max_err_over_tol=(err / tol * ok[None]).max())
+        parity_report.record(case, name, max_abs_err=(err * ok[None]).max(), max_err_over_tol=(err / tol * ok[None]).max(),
+                             max_bit_mismatches=int((g.view(np.uint32) != o.view(np.uint32)).sum()))
+        # the blend is defined operation by operation (gd_expf + separately rounded mul / add, oracle/gd_oracle.c): the
+        # HIP forward pass reproduces the oracle's images BIT FOR BIT, not just within the SURVEY 8d tolerance
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), f"{name}: {(g != o).sum()} pixels differ in bits"
         assert not bad.any(), f"{name}: {bad.sum()} pixels beyond tolerance, max err {err.max()}"
     return sc
 
@@ -313,10 +317,10 @@ def test_batched_matches_per_view():
 
 def _check_backward_dense(st, args, out, seed):
     """Backward parity for dense scenes.  This fork derives T_final = 1 - out_alpha (backward.cu:463); where most
-    pixels saturate (T_final ~ 1e-4) one ulp of out_alpha -- the GPU's expf / FMA vs the oracle's -- is a 6e-4
-    relative change of every gradient term of that pixel.  That sensitivity belongs to the reference's formulation
-    (its own CUDA build has it w.r.t. its own expf), so the standard tolerance is checked with the ORACLE's alpha
-    image as the saved forward output, and the GPU's own alpha image at a tolerance that covers the effect."""
+    pixels saturate (T_final ~ 1e-4) one ulp of out_alpha is a 6e-4 relative change of every gradient term of that
+    pixel.  Round 1 therefore had to feed the kernel the ORACLE's alpha image to meet the standard tolerance; now the
+    forward pass is bit-exact (gd_expf, separately rounded blend operations), the GPU's own alpha image IS the
+    oracle's, and the drop-in path meets the standard tolerance."""
     from garmentdreamer_amd.diff_gaussian_rasterization import _C
     from oracle import gd_oracle
     R, color, depth, alpha, radii, geom, binning, img = out
@@ -328,8 +332,8 @@ def _check_backward_dense(st, args, out, seed):
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
              "dL_drotations")
     P_ = means3D.shape[0]
-    for label, alpha_img, rtol, atol in (("oracle alpha", t(st.alpha).reshape(alpha.shape), 1e-3, 2e-5),
-                                         ("GPU alpha", alpha, 5e-3, 5e-4)):
+    assert torch.equal(alpha.cpu(), torch.as_tensor(st.alpha).reshape(alpha.shape))   # bit-exact forward -> same T_final
+    for label, alpha_img, rtol, atol in (("GPU alpha", alpha, 1e-3, 2e-5),):
         grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
                                                 t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img,
                                                 alpha_img, False)
