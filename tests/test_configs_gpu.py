@@ -123,7 +123,7 @@ def test_config2_100k_gaussians_4_views_full_nets_graph_vs_eager_and_oracle():
     from tests.test_raster_gpu import _check_grads
     for nm, gr in zip(names, grads):
         # the forward pass is bit-exact against the oracle, so the GPU's own alpha image gives the standard tolerance
-        _check_grads(nm, gr, ref[nm], rtol=1e-3, atol_scale=2e-5,
+        _check_grads(nm, gr, ref[nm], rtol=1e-3, atol_scale=5e-6,
                      case="configs[2] view 0 of the step vs oracle (GPU alpha, SDS dL/dimage)")
     # ... and the gradient the LOOP saw for that view (batched launch) is the single-view one
     vs0 = g["viewspace"][0]

@@ -1,9 +1,10 @@
 """GPU parity: HIP rasterizer (through the C-ABI, via the _C-shaped shim) vs the CPU oracle.
 
 Bar: integers bit-exact (radii, tiles_touched, point_offsets, sorted keys,
-point_list, ranges, num_rendered, n_contrib); pixels abs <= 1e-5 + 1e-4*|x|; gradients
-rtol 1e-3 with an absolute floor scaled to the tensor (atomic-order / fp32-accumulation noise;
-the oracle sums per-pair terms in fp64).
+point_list, ranges, num_rendered, n_contrib); pixels: SURVEY asks abs <= 1e-5 + 1e-4*|x|, the
+kernels deliver BIT-EXACT images (asserted); gradients rtol 1e-3 with an absolute floor of
+5e-6 * max|ref| per tensor (fp32 accumulation in a fixed order vs the oracle's fp64 sums; the
+largest error measured is 9.7e-7 * max|ref|, profiles/r02_parity_report.json).
 """
 import numpy as np
 import pytest
@@ -70,7 +71,7 @@ def _check_forward(inp, st, out, exact_ncontrib=True):
     return sc
 
 
-def _check_grads(name, g, o, rtol=1e-3, atol_scale=2e-5, case=None):
+def _check_grads(name, g, o, rtol=1e-3, atol_scale=5e-6, case=None):
     g = g.detach().cpu().numpy().reshape(o.shape)
     scale = np.abs(o).max() + 1e-20
     err = np.abs(g - o)
@@ -170,13 +171,14 @@ def test_strip_culling_needles_forward_and_backward(P, HW, seed):
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
              "dL_drotations")
     # Needles are ill-conditioned in fp32: power = -0.5 (a dx^2 + c dy^2) - b dx dy cancels terms of ~1e4 down to
-    # O(1), so G = exp(power) carries ~1e-3 relative rounding that depends on the exp implementation (v_exp_f32 here,
-    # libm in the oracle; nvcc's own contraction of the reference is unspecified).  Only the blend kernel's own sums
-    # are compared here; the preprocess-backward chain (cov2D -> cov3D -> scales / rotations) amplifies the same
-    # rounding further for 60:1 needles and is covered at the standard tolerance by test_backward_parity.
+    # O(1), so G = exp(power) carries rounding that depends on the exp implementation (v_exp_f32 in the backward
+    # kernel, gd_expf in the oracle); the preprocess-backward chain (cov2D -> cov3D -> scales / rotations) amplifies it
+    # for 60:1 needles (measured: up to 9.2e-4 * max|ref| on dL_drotations).  All eight tensors are checked; the blend's
+    # own sums are within 4.7e-6 * max|ref|.
     for n, g in zip(names, grads):
-        if n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity"):
-            _check_grads(n, g, ref[n], rtol=5e-3, atol_scale=2e-3)
+        blend_sum = n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity")
+        _check_grads(n, g, ref[n], rtol=2e-3 if blend_sum else 5e-3, atol_scale=2e-5 if blend_sum else 2e-3,
+                     case=f"needles P={P} {HW}^2")
     # the backward pass is atomic-free: same inputs -> the same bits
     grads2 = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty, t(gc),
                                              t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha, False)
@@ -333,7 +335,7 @@ def _check_backward_dense(st, args, out, seed):
              "dL_drotations")
     P_ = means3D.shape[0]
     assert torch.equal(alpha.cpu(), torch.as_tensor(st.alpha).reshape(alpha.shape))   # bit-exact forward -> same T_final
-    for label, alpha_img, rtol, atol in (("GPU alpha", alpha, 1e-3, 2e-5),):
+    for label, alpha_img, rtol, atol in (("GPU alpha", alpha, 1e-3, 5e-6),):
         grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
                                                 t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img,
                                                 alpha_img, False)
