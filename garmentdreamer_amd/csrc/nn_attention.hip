@@ -56,14 +56,14 @@ constexpr int kTile = kTk * kD * 2;   // 8 KB
 // V [B][Skv][H*64] (row stride v_rs elements)  ->  Vt [B][H][64][Skv] with the keys of every 16-group stored in
 // the order {0,1,2,3, 8,9,10,11, 4,5,6,7, 12,13,14,15} (see the header).  64 keys x 64 d per workgroup through LDS.
 __global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, int Skv,
-                                                      int H, int64_t v_bs, int v_rs)
+                                                      int H, int64_t v_bs, int v_rs, int kv_len)
 {
     __shared__ uint16_t tile[64][66];
     const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
     const uint16_t* src = v + b * v_bs + (int64_t)k0 * v_rs + h * 64;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int key = i >> 6, d = i & 63;
-        tile[key][d] = src[(int64_t)key * v_rs + d];
+        tile[key][d] = k0 + key < kv_len ? src[(int64_t)key * v_rs + d] : (uint16_t)0;   // padded keys: V = 0
     }
     __syncthreads();
     uint16_t* dst = vt + (((int64_t)b * H + h) * 64) * Skv + k0;
@@ -81,7 +81,7 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                            const uint16_t* __restrict__ vt, uint16_t* __restrict__ o, int S,
                                                            int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs,
-                                                           int64_t o_bs, int o_rs, float c /* scale * log2(e) */)
+                                                           int64_t o_bs, int o_rs, float c /* scale * log2(e) */, int kv_len)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                 // 3 stages
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
     // K rows: [key][64 d], row stride k_rs elements; Vt rows: [d][Skv]
     const uint32_t k_row_bytes = (uint32_t)k_rs * 2u, v_row_bytes = (uint32_t)Skv * 2u;
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(k + b * k_bs + h * kD), 0, (int)((uint32_t)Skv * k_row_bytes), 0x00020000);
+        (void*)(k + b * k_bs + h * kD), 0, (int)((uint32_t)kv_len * k_row_bytes), 0x00020000);   // rows >= kv_len read as 0
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(vt + (((int64_t)b * H + h) * kD) * Skv), 0, (int)((uint32_t)kD * v_row_bytes), 0x00020000);
     uint32_t k_off[NP], v_off[NP];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
         vrd[j] = (uint32_t)swz(32 * j + fn, fh);       // V^T fragment of d block j, 16-key group 0
     }
     // S^T tile of 64 keys x 32 queries (two 32x32 accumulators) from the K stage at `pk`
-    auto qk = [&](const char* pk, f32x16& s0, f32x16& s1) {
+    auto qk = [&](const char* pk, f32x16& s0, f32x16& s1, int tile) {
 #pragma unroll
         for (int r = 0; r < 16; r++) s0[r] = s1[r] = 0.f;
 #pragma unroll
@@ -146,6 +146,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
             const bf16x8_t k1 = *(const bf16x8_t*)(pk + (krd[1] ^ (uint32_t)(kk << 5)));
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kk], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], s1, 0, 0, 0);
+        }
+        if ((tile + 1) * kTk > kv_len) {      // last tile of a key count that is not a multiple of 64 (cross-attention:
+#pragma unroll                                   // 77 text tokens): padded keys get no weight
+            for (int r = 0; r < 16; r++) {
+                const int key = tile * kTk + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (key >= kv_len) s0[r] = -INFINITY;
+                if (key + 32 >= kv_len) s1[r] = -INFINITY;
+            }
         }
     };
     // Part 1 of the online softmax of the lane's 64 scores: the (deferred) running maximum.
@@ -214,13 +222,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x16 sa0, sa1, sb0, sb1;
-    qk(sK, sa0, sa1);
+    qk(sK, sa0, sa1, 0);
     auto iteration = [&](int t, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t+1 (issued one iteration ago) has landed
         __syncthreads();                                      // ... for every wave; stage (t+2)%3 is free again
         if (t + 2 < ntiles) issue((t + 2) % 3, t + 2);
         update_max(c0, c1);
-        qk(sK + ((t + 1) % 3) * kTile, n0, n1);
+        qk(sK + ((t + 1) % 3) * kTile, n0, n1, t + 1);
         exp_pv(c0, c1, sV + (t % 3) * kTile);
     };
     int t = 0;
@@ -263,28 +271,28 @@ size_t gd_nn_attention_ws_bytes(int B, int Skv, int H) { return (size_t)B * H * 
 
 int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, const void* v, void* o, void* vt_ws, int B, int S,
                                 int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs, int v_rs,
-                                int64_t o_bs, int o_rs, float scale)
+                                int64_t o_bs, int o_rs, float scale, int kv_len)
 {
     if (!q || !k || !v || !o || !vt_ws) return fail(GD_NN_ERR_INVALID_ARG, "attention: null pointer");
-    if (B <= 0 || S <= 0 || H <= 0 || Skv <= 0 || Skv % 64)
-        return fail(GD_NN_ERR_INVALID_ARG, "attention: need Skv % 64 == 0 (head_dim is 64)");
+    if (B <= 0 || S <= 0 || H <= 0 || Skv <= 0 || Skv % 64 || kv_len <= Skv - 64 || kv_len > Skv)
+        return fail(GD_NN_ERR_INVALID_ARG, "attention: need Skv % 64 == 0 and Skv - 64 < kv_len <= Skv (head_dim is 64)");
     if (q_rs % 8 || k_rs % 8 || o_rs % 4 || (double)Skv * k_rs * 2.0 >= 2147483648.0)
         return fail(GD_NN_ERR_INVALID_ARG, "attention: row strides must keep 16-byte (q, k) / 8-byte (o) alignment");
     hipStream_t s = (hipStream_t)stream;
     if (const char* e = getenv("GD_NN_ATTN_WAVES")) g_attn_waves = atoi(e);
     hipLaunchKernelGGL(attn_vt_kernel, dim3(Skv / 64, H, B), dim3(256), 0, s, (const uint16_t*)v, (uint16_t*)vt_ws, Skv, H,
-                       v_bs, v_rs);
+                       v_bs, v_rs, kv_len);
     const float c = scale * 1.4426950408889634f;
     int waves = 4;     // 8 waves per workgroup measured the same at batch 16 and worse on small grids (tools/attn_bench.py)
     if (g_attn_waves == 4 || g_attn_waves == 8) waves = g_attn_waves;
     if (waves == 8)
         hipLaunchKernelGGL(attn_fwd_d64_kernel<8>, dim3((S + 255) / 256, B * H), dim3(512), 6 * kTile, s, (const uint16_t*)q,
                            (const uint16_t*)k, (const uint16_t*)vt_ws, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
-                           o_rs, c);
+                           o_rs, c, kv_len);
     else
         hipLaunchKernelGGL(attn_fwd_d64_kernel<4>, dim3((S + 127) / 128, B * H), dim3(256), 6 * kTile, s, (const uint16_t*)q,
                            (const uint16_t*)k, (const uint16_t*)vt_ws, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
-                           o_rs, c);
+                           o_rs, c, kv_len);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

@@ -41,7 +41,7 @@ SIGNATURES = {
     "gd_nn_add_layernorm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, C.c_int64, _i]),
     "gd_nn_attention_ws_bytes": (C.c_size_t, [_i, _i, _i]),
     "gd_nn_attention_d64_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i,
-                                         C.c_int64, _i, C.c_int64, _i, _f]),
+                                         C.c_int64, _i, C.c_int64, _i, _f, _i]),
     "gd_nn_attention_last_error": (C.c_char_p, []),
     "gd_nn_vae_prologue_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_vae_prologue_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
@@ -724,14 +724,16 @@ def attention_d64_supported(q, k, v) -> bool:
     """q, k, v: [B, S, H, 64] views (any batch / row stride, head and channel dims contiguous)."""
     ok = lambda t: (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[-1] == 64 and t.stride(-1) == 1
                     and t.stride(2) == 64 and t.stride(1) % 8 == 0)   # noqa: E731
-    return (ok(q) and ok(k) and ok(v) and k.shape[1] % 64 == 0 and k.shape == v.shape and q.shape[0] == k.shape[0]
+    return (ok(q) and ok(k) and ok(v) and k.shape == v.shape and q.shape[0] == k.shape[0]
             and q.shape[2] == k.shape[2] and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)))
 
 
 def attention_d64(q, k, v):
-    """softmax(q k^T / 8) v for [B, S, H, 64] views; returns [B, S, H*64] (contiguous)."""
+    """softmax(q k^T / 8) v for [B, S, H, 64] views; returns [B, S, H*64] (contiguous).  Any number of keys: the kernel
+    works on 64-key tiles and masks the padding (cross-attention over 77 text tokens)."""
     B, S, H, _ = q.shape
-    Skv = k.shape[1]
+    kv_len = k.shape[1]
+    Skv = (kv_len + 63) // 64 * 64
     L = lib()
     o = torch.empty((B, S, H * 64), dtype=torch.bfloat16, device=q.device)
     ws = torch.empty(L.gd_nn_attention_ws_bytes(B, Skv, H), dtype=torch.uint8, device=q.device)
@@ -739,7 +741,7 @@ def attention_d64(q, k, v):
         ret = L.gd_nn_attention_d64_forward(torch.cuda.current_stream(q.device).cuda_stream, q.data_ptr(), k.data_ptr(),
                                             v.data_ptr(), o.data_ptr(), ws.data_ptr(), B, S, Skv, H, q.stride(0), q.stride(1),
                                             k.stride(0), k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1),
-                                            64 ** -0.5)
+                                            64 ** -0.5, kv_len)
     if ret < 0:
         raise RuntimeError(f"gd_nn_attention_d64_forward failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
     return o

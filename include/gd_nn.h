@@ -139,12 +139,13 @@ int gd_nn_add_layernorm_forward(void* stream, const void* x, const void* residua
 
 /* Fused self-attention forward, head_dim 64, bf16, no mask (diffusers Attention -> scaled_dot_product_attention in
  * the UNet's spatial self-attention).  q, o: [B][S][H*64] with row stride q_rs / o_rs and batch stride q_bs / o_bs
- * (elements); k, v: [B][Skv][H*64] likewise; Skv % 64 == 0.  vt_ws: gd_nn_attention_ws_bytes(B, Skv, H) bytes of
+ * (elements); k, v: [B][kv_len][H*64] likewise; Skv = kv_len rounded up to 64 (the padded keys get no weight: the
+ * UNet's cross-attention over 77 text tokens runs as Skv = 128, kv_len = 77).  vt_ws: gd_nn_attention_ws_bytes(B, Skv, H) bytes of
  * scratch (V transposed per head with the key order the MFMA accumulator layout wants).  o = softmax(q k^T scale) v. */
 size_t gd_nn_attention_ws_bytes(int B, int Skv, int H);
 int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, const void* v, void* o, void* vt_ws, int B, int S,
                                 int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs, int v_rs,
-                                int64_t o_bs, int o_rs, float scale);
+                                int64_t o_bs, int o_rs, float scale, int kv_len);
 const char* gd_nn_attention_last_error(void);
 
 /* The guidance's image prologue as ONE kernel each way (threestudio stable_diffusion_guidance.py:394-396 + :164):

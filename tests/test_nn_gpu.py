@@ -737,3 +737,24 @@ def test_conv3x3_tiny_cout_backward_stays_on_the_mfma_kernel():
     assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item()
     assert F.cosine_similarity(xg.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.9995
     assert (xg.grad.float() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("B,H,S,Skv", [(2, 5, 4096, 77), (3, 20, 256, 77), (1, 10, 1024, 100), (2, 5, 300, 64), (2, 5, 320, 1)])
+def test_attention_d64_with_a_key_count_that_is_not_a_multiple_of_64(B, H, S, Skv):
+    """Cross-attention over the 77 text tokens (and other ragged key counts) on the own kernel: padded keys must get no
+    weight.  K / V are column slices of a wider matrix (sd21.ContextProjections hands the kernel strided views)."""
+    from garmentdreamer_amd.nn_ops import attention_d64, attention_d64_supported
+    g = torch.Generator(DEV).manual_seed(S + Skv)
+    q = (torch.randn(B, S, H * 64, device=DEV, generator=g) * 1.5).to(torch.bfloat16).view(B, S, H, 64)
+    wide = (torch.randn(B, Skv, 3 * H * 64 + 128, device=DEV, generator=g) * 1.5).to(torch.bfloat16)
+    k = wide[..., 64:64 + H * 64].view(B, Skv, H, 64)
+    v = wide[..., 64 + H * 64:64 + 2 * H * 64].view(B, Skv, H, 64)
+    assert attention_d64_supported(q, k, v)
+    with torch.no_grad():
+        out = attention_d64(q, k, v)
+        ref = F.scaled_dot_product_attention(q.transpose(1, 2).float(), k.transpose(1, 2).float(), v.transpose(1, 2).float())
+        ref = ref.transpose(1, 2).reshape(B, S, H * 64)
+    assert torch.isfinite(out).all()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item() + 2e-3, err
+    assert F.cosine_similarity(out.float().flatten(), ref.flatten(), dim=0).item() > 0.9995
