@@ -100,6 +100,7 @@ constexpr uint32_t kOOB = 0x80000000u;   // voffset that fails the buffer range 
 // ty / tx / widx are packed 4 bits per tap (ty, tx biased by +8) so the tap walk stays in scalar registers.
 struct ConvGeom {
     int Hin, Win, Hg, Wg, sy, sx, Hout, Wout, osy, osx, ooy, oox, ntaps, back;
+    int wtaps;            // taps per output channel in the weight tensor ([Cout][wtaps][Cin]; 0 = 9)
     uint64_t ty4, tx4, w4;
 };
 
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)in - back), 0, (int)((uint32_t)Nimg * (uint32_t)(H * W) * row_bytes + back), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)wt, 0, (int)((uint32_t)Cout * 9u * row_bytes), 0x00020000);
+        (void*)wt, 0, (int)((uint32_t)Cout * (uint32_t)g.wtaps * row_bytes), 0x00020000);
 
     // LDS image: 256-byte lines = two consecutive 128-byte tile rows = 16 slots of 16 B; logical
     // slot c = (row&1)*8 + chunk is stored at slot c ^ (line & 15): a 64-lane fragment read then
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
         const int line = q >> 4, c = (q & 15) ^ (line & 15);
         const int r = 2 * line + (c >> 3);
         const int co = n0 + r;
-        b_off[i] = co < Cout ? (uint32_t)co * 9u * row_bytes + (uint32_t)(c & 7) * 16u : kOOB;
+        b_off[i] = co < Cout ? (uint32_t)co * (uint32_t)g.wtaps * row_bytes + (uint32_t)(c & 7) * 16u : kOOB;
     }
     const int kc = Cin / BK;         // K-steps per tap
     // split-K over taps (small-M layers): blockIdx.y walks tap subsets, fp32 partial sums go to partial[split]
@@ -1075,6 +1076,7 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
         minlin = dy * g.Win + dx < minlin ? dy * g.Win + dx : minlin;
     }
     g.back = -minlin;
+    if (g.wtaps == 0) g.wtaps = 9;
     if (((double)N * g.Hin * g.Win + g.back) * Cin * 2.0 >= 2147483648.0 || (double)Cout * 9.0 * Cin * 2.0 >= 2147483648.0)
         return fail(GD_NN_ERR_INVALID_ARG, "conv3x3: activation / weight tensor must be < 2 GiB (32-bit buffer offsets)");
     const int64_t M = (int64_t)N * g.Hg * g.Wg;
@@ -1401,6 +1403,22 @@ int gd_nn_conv3x3_up2_forward(void* stream, const void* x, const void* w_even_ro
             if (r < 0) return r;
         }
     return GD_NN_OK;
+}
+
+/* nn.Linear as a one-tap implicit GEMM: y[M][Nout] = x[M][K] . w[Nout][K]^T + bias[Nout] + residual[M][Nout] (bf16). */
+int gd_nn_linear_forward(void* stream, const void* x, const void* weight, const void* bias, const void* residual, void* y,
+                         int64_t M, int K, int Nout)
+{
+    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (M <= 0 || M > 0x7fffffff || K <= 0 || K % BK || Nout <= 0 || Nout % 4)
+        return fail(GD_NN_ERR_INVALID_ARG, "linear: need K % 64 == 0 and Nout % 4 == 0");
+    ConvGeom g = {};
+    g.Hin = g.Hg = g.Hout = 1;
+    g.Win = g.Wg = g.Wout = (int)M;
+    g.sy = g.sx = g.osy = g.osx = 1;
+    g.wtaps = 1;
+    add_tap(g, 0, 0, 0);
+    return launch_conv((hipStream_t)stream, x, weight, bias, 0, residual, y, 1, g, K, Nout);
 }
 
 int gd_nn_conv_force_variant(int v)

@@ -33,6 +33,7 @@ SIGNATURES = {
     "gd_nn_conv3x3_s2_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_up2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv_force_variant": (_i, [_i]),
+    "gd_nn_linear_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
     "gd_nn_conv_profile_enable": (_i, [_i]),
     "gd_nn_conv_profile_reset": (_i, []),
     "gd_nn_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -951,3 +952,23 @@ class Fp8State:
         x8 = group_norm_silu_fp8(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True, sx)
         self.sites_run += 1
         return fp8_conv3x3(x8, w8, bias, residual, x.shape[1], sx * ws)
+
+
+def linear_supported(x, weight) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous()
+            and weight.is_contiguous() and weight.shape[1] % 64 == 0 and weight.shape[0] % 4 == 0
+            and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)))
+
+
+def linear(x, weight, bias=None, residual=None):
+    """``F.linear(x, weight, bias) + residual`` on the own MFMA implicit-GEMM kernel (one tap), inference only."""
+    K = weight.shape[1]
+    M = x.numel() // K
+    y = torch.empty(x.shape[:-1] + (weight.shape[0],), dtype=torch.bfloat16, device=x.device)
+    p = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    with torch.cuda.device(x.device):
+        ret = lib().gd_nn_linear_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), weight.data_ptr(),
+                                         p(bias), p(residual), y.data_ptr(), M, K, weight.shape[0])
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_linear_forward failed ({ret}): {lib().gd_nn_conv_last_error().decode()}")
+    return y

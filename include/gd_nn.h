@@ -63,6 +63,10 @@ int gd_nn_conv3x3_flip_weights(void* stream, const void* weight, void* flipped, 
 int gd_nn_conv_force_variant(int v);
 
 /* Event timing of the conv kernel for bench.py's roofline object (off by default). */
+/* nn.Linear on the MFMA implicit-GEMM kernel (one tap): y[M][Nout] = x[M][K] . w[Nout][K]^T + bias + residual, bf16,
+ * K % 64 == 0, Nout % 4 == 0 (diffusers Attention / FeedForward / proj_in / proj_out linears). */
+int gd_nn_linear_forward(void* stream, const void* x, const void* weight, const void* bias, const void* residual, void* y,
+                         int64_t M, int K, int Nout);
 int gd_nn_conv_profile_enable(int on);
 int gd_nn_conv_profile_reset(void);
 int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_flops);
