@@ -1,26 +1,34 @@
 #!/bin/bash
-# GPU-busy time vs wall time of the 1-view-per-GPU step (what every rank runs at N = 8).  usage: tools/v1_profile.sh <outdir>
-out=$1; mkdir -p $out
-python bench.py --views 1 --steps 20 --warmup 3 --no-cpu-baseline > $out/v1_line.json 2>/dev/null
+# per-kernel steady-state stats of the one-view-per-GPU step (bench.py --views ${VIEWS:-1}): what the 8-GPU run executes per rank
+V=${VIEWS:-1}
+python bench.py --views $V --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf /tmp/prof_v1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_v1 -o bench -- python bench.py --views 1 --steps 10 --warmup 3 --no-cpu-baseline > $out/v1_line_under_rocprof.json 2> /tmp/prof_v1.err
-tr=$(find /tmp/prof_v1 -name "*kernel_trace.csv" | head -1)
-python tools/steady_stats.py "$tr" $out/v1_kernel_stats_steady.csv --skip 3
-python - "$tr" <<'P'
+rm -rf /tmp/v1p
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/v1p -o v -- python bench.py --views $V --steps 20 --warmup 4 --no-cpu-baseline > /tmp/v1p.log 2>&1
+tail -1 /tmp/v1p.log | cut -c1-200
+tr=$(find /tmp/v1p -name "*kernel_trace.csv" | head -1)
+mkdir -p gpurun_out
+python tools/steady_stats.py "$tr" gpurun_out/v${V}_steady.csv --skip 4
+python - gpurun_out/v${V}_steady.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
+print("kernel ms/step", sum(float(r["MsPerStep"]) for r in rows), "launches/step", sum(float(r["CallsPerStep"]) for r in rows))
+for r in rows[:45]:
+    print(f'{r["Name"][:80]:82s} {float(r["CallsPerStep"]):6.1f}/step avg {float(r["AverageNs"])/1e3:8.1f} us  {float(r["MsPerStep"]):6.3f} ms/step')
+PY
+python - "$tr" <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# steady region: last 8 render_backward launches delimit 7 steps
-idx = [i for i, r in enumerate(rows) if "render_backward_strip_kernel" in r["Kernel_Name"]]
-a, b = idx[-8], idx[-1]
-seg = rows[a:b]
-wall = int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])
-busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg)
-gaps = []
-for p, q in zip(seg[:-1], seg[1:]):
-    gaps.append(max(0, int(q["Start_Timestamp"]) - int(p["End_Timestamp"])))
-import statistics
-print(f"steps 7  wall/step {wall/7e6:.3f} ms  kernel-busy/step {busy/7e6:.3f} ms  kernels/step {len(seg)/7:.0f}  "
-      f"median gap {statistics.median(gaps)/1e3:.2f} us  sum gaps/step {sum(gaps)/7e6:.3f} ms  gaps>50us/step {sum(g for g in gaps if g>50000)/7e6:.3f} ms")
-P
+marks = [i for i, r in enumerate(rows) if "render_backward_strip_kernel" in r["Kernel_Name"]]
+rows = rows[marks[3]:marks[-1]]; steps = len(marks) - 4
+for pat in ("conv3x3_nhwc_bf16_kernel<128, 128", "gn_stats_kernel", "Cijk"):
+    agg = collections.OrderedDict()
+    for r in rows:
+        if pat in r["Kernel_Name"]:
+            k = (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r["Workgroup_Size_X"])
+            d = agg.setdefault(k, [0, 0]); d[0] += 1; d[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    print(pat)
+    for k, d in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+        print("   grid", k, "calls/step %.1f avg %.1f us  %.3f ms/step" % (d[0] / steps, d[1] / d[0] / 1e3, d[1] / steps / 1e6))
+PY
