@@ -173,7 +173,7 @@ def vsd_main(args):
     rk, lr, ws = gdist.init_from_env()
     device = torch.device("cuda", lr)
     torch.cuda.set_device(device)
-    gd = StableDiffusionVSD(device, fp16=True)
+    gd = StableDiffusionVSD(device, fp16=True, use_hip_graphs=not args.no_graphs)
     with torch.device(device):
         lora = sd21.init_random_(sd21.LoraUNet2DConditionModel(), 2)
     lora = lora.to(torch.bfloat16).to(memory_format=torch.channels_last)
@@ -219,7 +219,8 @@ def vsd_main(args):
                           "value": ws * args.steps / el, "unit": "view-iters/s", "n_gpus": ws, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": "VSD step, SD-2.1 UNet + LoRA UNet (rank 4) random-init, batch 1"},
+                          "config": {"workload": "VSD step, SD-2.1 UNet + LoRA UNet (rank 4) random-init, batch 1",
+                                     "hip_graphs": bool(gd.use_hip_graphs)},
                           "roofline_dense": {"bound": "mfma", "achieved": tfl / (el / args.steps),
                                              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                              "frac": tfl / (el / args.steps) / PEAK_BF16_TFLOPS}}), flush=True)

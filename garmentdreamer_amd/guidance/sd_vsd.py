@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import sd21
+from .. import _runtime_env
 
 
 class SpecifyGradient(torch.autograd.Function):
@@ -44,8 +45,14 @@ class SpecifyGradient(torch.autograd.Function):
 
 class StableDiffusionVSD(nn.Module):
     def __init__(self, device, fp16: bool = True, t_range=(0.02, 0.5), unet: Optional[nn.Module] = None,
-                 vae: Optional[nn.Module] = None, init_seed: int = 0):
+                 vae: Optional[nn.Module] = None, init_seed: int = 0, use_hip_graphs: bool = False):
         super().__init__()
+        # MI355X-side option (the reference has none): at batch 1 the iteration is ~5500 kernels of ~10 us and the
+        # host cannot issue them fast enough; with it the frozen UNet forward, the LoRA UNet's no-grad forward, the
+        # VAE encoder forward/backward and the LoRA UNet's training forward/backward replay as hipGraphs.
+        self.use_hip_graphs = bool(use_hip_graphs) and torch.device(device).type == "cuda" and \
+            _runtime_env.graph_replay_safe()
+        self._graphs = {}
         self.device = torch.device(device)
         self.dtype = torch.bfloat16 if fp16 else torch.float32
         if unet is None:
@@ -71,10 +78,101 @@ class StableDiffusionVSD(nn.Module):
         self.embeddings = {"pos": pos, "neg": neg, "front": front if front is not None else pos,
                            "side": side if side is not None else pos, "back": back if back is not None else pos}
 
+    # ---- hipGraph replay (same scheme as StableDiffusionGuidance._graphed_unet / _graphed_vae_moments) ----
+    def _graphs_failed(self, err):
+        import warnings
+        warnings.warn(f"hipGraph capture failed ({err}); continuing with eager kernel launches")
+        self.use_hip_graphs = False
+        self._graphs.clear()
+        torch.cuda.synchronize()
+        from .. import nn_ops
+        nn_ops.reset_workspaces()
+
+    def _replay_nograd(self, key, fn, *tensors):
+        """``fn(*tensors)`` under no_grad, captured once per (key, shapes) and replayed on static copies."""
+        key = (key,) + tuple(tuple(t.shape) for t in tensors)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static = [t.clone() for t in tensors]
+            dev = static[0].device
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):
+                    fn(*static)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                out = fn(*static)
+            entry = self._graphs[key] = (g, static, out)
+        g, static, out = entry
+        for st, t in zip(static, tensors):
+            st.copy_(t)
+        g.replay()
+        return out.clone()
+
+    def _graphed_module(self, key, make_module, *tensors):
+        """Autograd-aware forward/backward graph pair of ``make_module()`` (torch.cuda.make_graphed_callables)."""
+        key = (key,) + tuple(tuple(t.shape) for t in tensors)
+        fn = self._graphs.get(key)
+        if fn is None:
+            sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in tensors)
+            fn = self._graphs[key] = torch.cuda.make_graphed_callables(make_module(), sample, allow_unused_input=True)
+        return fn(*tensors)
+
     def encode_imgs(self, imgs, vae_noise=None):
         imgs = 2 * imgs - 1
-        posterior = self.vae.encode(imgs.to(self.dtype)).latent_dist
+        x = imgs.to(self.dtype)
+        posterior = None
+        if self.use_hip_graphs and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+            vae = self.vae
+
+            class _Moments(nn.Module):
+                def forward(self, z):
+                    return vae.quant_conv(vae.encoder(z))
+
+            try:
+                posterior = sd21.DiagonalGaussianDistribution(
+                    self._graphed_module("vae", _Moments, x.contiguous(memory_format=torch.channels_last)))
+            except RuntimeError as e:
+                self._graphs_failed(e)
+        if posterior is None:
+            posterior = self.vae.encode(x).latent_dist
         return posterior.sample(vae_noise) * self.vae.config.scaling_factor
+
+    def _frozen_unet(self, x, t, ctx):
+        x, ctx = x.to(self.dtype), ctx.to(self.dtype)
+        if self.use_hip_graphs and x.is_cuda:
+            try:
+                return self._replay_nograd("unet", lambda a, b, c: self.unet(a, b, encoder_hidden_states=c), x, t, ctx)
+            except RuntimeError as e:
+                self._graphs_failed(e)
+        return self.unet(x, t, encoder_hidden_states=ctx)
+
+    def _q_nograd(self, q_unet, x, t, text, pose, shading):
+        if self.use_hip_graphs and x.is_cuda:
+            try:
+                return self._replay_nograd(("q", id(q_unet), shading),
+                                           lambda a, b, c, d: q_unet(a, b, c, c=d, shading=shading), x, t, text, pose)
+            except RuntimeError as e:
+                self._graphs_failed(e)
+        return q_unet(x, t, text, c=pose, shading=shading)
+
+    def _q_train(self, q_unet, x, t, text, pose, shading):
+        if self.use_hip_graphs and x.is_cuda and isinstance(q_unet, nn.Module):
+            class _Q(nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.q = q_unet
+
+                def forward(self, a, b, c, d):
+                    return self.q(a, b, c, c=d, shading=shading)
+
+            try:
+                return self._graphed_module(("q_train", id(q_unet), shading), _Q, x, t, text, pose)
+            except RuntimeError as e:
+                self._graphs_failed(e)
+        return q_unet(x, t, text, c=pose, shading=shading)
 
     def train_step(self, pred_rgb, guidance_scale=7.5, q_unet=None, pose=None, shading=None, as_latent=False,
                    t5=False, hors=None, noise=None, timesteps=None, vae_noise=None):
@@ -103,13 +201,13 @@ class StableDiffusionVSD(nn.Module):
                     return "front" if abs(h) < 60 else ("side" if abs(h) < 120 else "back")
                 embeddings = torch.cat([self.embeddings[_dir(h)] for h in hors] +
                                        [self.embeddings["neg"].expand(batch_size, -1, -1)])
-            noise_pred = self.unet(latent_model_input, tt, encoder_hidden_states=embeddings).float()
+            noise_pred = self._frozen_unet(latent_model_input, tt, embeddings).float()
             noise_pred_cond, noise_pred_uncond = noise_pred.chunk(2)
             noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_cond - noise_pred_uncond)
             if q_unet is None or pose is None:
                 raise NotImplementedError("VSD needs the LoRA UNet and a pose (sd_vsd_utils.py:192-197)")
-            v_q = q_unet(latents_noisy, t, self.embeddings["pos"].expand(batch_size, -1, -1), c=pose,
-                         shading=shading or "albedo").float()
+            v_q = self._q_nograd(q_unet, latents_noisy, t, self.embeddings["pos"].expand(batch_size, -1, -1).contiguous(),
+                                 pose, shading or "albedo").float()
             a = self.alphas[t].view(-1, 1, 1, 1)
             noise_pred_q = a.sqrt() * v_q + (1 - a).sqrt() * latents_noisy   # v -> eps
         w = (1 - self.alphas[t]).view(batch_size, 1, 1, 1)
@@ -135,8 +233,8 @@ class StableDiffusionVSD(nn.Module):
                 noise = torch.randn(latents_clean.shape, device=self.device)
             latents_noisy = self.scheduler.add_noise(latents_clean, noise, timesteps)
             target = self.scheduler.get_velocity(latents_clean, noise, timesteps) if v_pred else noise
-        out = q_unet(latents_noisy, timesteps, self.embeddings["pos"].expand(unet_bs, -1, -1), c=pose_b,
-                     shading=shading).float()
+        out = self._q_train(q_unet, latents_noisy, timesteps,
+                            self.embeddings["pos"].expand(unet_bs, -1, -1).contiguous(), pose_b, shading).float()
         return F.mse_loss(out, target)
 
 

