@@ -110,7 +110,7 @@ template <int BN, int BM, int WN, int WM>
 __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
     int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, const ConvGeom g,
-    int Cin, int Cout, int tiles_n, int nwg, float* __restrict__ partial, int taps_per_split)
+    int Cin, int Cout, int tiles_n, int nwg, float* __restrict__ partial, int steps_per_split)
 {
     constexpr int THREADS = 64 * WN * WM;
     constexpr int NA = BM * 8 / THREADS;      // 16-B chunks of the pixel tile per thread per K-step
@@ -176,14 +176,16 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
         b_off[i] = co < Cout ? (uint32_t)co * (uint32_t)g.wtaps * row_bytes + (uint32_t)(c & 7) * 16u : kOOB;
     }
     const int kc = Cin / BK;         // K-steps per tap
-    // split-K over taps (small-M layers): blockIdx.y walks tap subsets, fp32 partial sums go to partial[split]
-    const int tap0 = partial ? (int)blockIdx.y * taps_per_split : 0;
-    const int tap1 = partial ? min(g.ntaps, tap0 + taps_per_split) : g.ntaps;
-    const int nsteps = (tap1 - tap0) * kc;
+    // split-K (small-M layers): blockIdx.y walks contiguous ranges of the (tap, channel step) sequence, fp32 partial
+    // sums go to partial[split]
+    const int step0 = partial ? (int)blockIdx.y * steps_per_split : 0;
+    const int step1 = partial ? min(g.ntaps * kc, step0 + steps_per_split) : g.ntaps * kc;
+    const int nsteps = step1 - step0;
+    const int tap0 = step0 / kc;
 
     // loader state: (tap, channel step) of the NEXT stage to fetch; halo validity is re-evaluated
     // once per tap, the per-K-step cost is one scalar add
-    int ld_tap = tap0, ld_c = 0;
+    int ld_tap = tap0, ld_c = step0 - tap0 * kc;
     uint32_t a_voff[NA];
     auto set_tap = [&](int tap) {
         const int dy = (int)((g.ty4 >> (4 * tap)) & 15u) - 8, dx = (int)((g.tx4 >> (4 * tap)) & 15u) - 8;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
 #endif
         if (++ld_c == kc) {
             ld_c = 0;
-            if (++ld_tap < tap1) set_tap(ld_tap);
+            if (++ld_tap < g.ntaps) set_tap(ld_tap);
         }
     };
 
@@ -297,9 +299,8 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[a][b][4 * q + e];
-                if (partial) {
-                    const size_t Mo = (size_t)Nimg * g.Hout * g.Wout;
-                    *(float4*)(partial + ((size_t)blockIdx.y * Mo + opix) * Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+                if (partial) {   // fp32 partial of this K range, indexed by GEMM row (compact also for strided outputs)
+                    *(float4*)(partial + ((size_t)blockIdx.y * (size_t)M + (size_t)m) * Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
                     continue;
                 }
                 if (bias_n) {
@@ -889,9 +890,12 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
     }
 }
 
-// out = bf16( sum_s partial[s] + bias + residual ): second half of the split-K path; 8 channels per thread
+// out = bf16( sum_s partial[s] + bias + residual ): second half of the split-K path; 8 channels per thread.  Partials
+// are indexed by GEMM row; the row -> output pixel map is the convolution's (identity for stride-1 layers, every
+// second pixel for the parity classes of a stride-2 input gradient).
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ partial, int S, size_t MC,
-                                                                 int Cout, size_t pix_per_img,
+                                                                 int Cout, int HWg, int Wg, int Hout, int Wout, int osy,
+                                                                 int osx, int ooy, int oox,
                                                                  const uint16_t* __restrict__ bias, int bias_img_stride,
                                                                  const uint16_t* __restrict__ residual,
                                                                  uint16_t* __restrict__ out)
@@ -907,20 +911,24 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
         v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
         v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
     }
-    const size_t pix = i / Cout;
-    const int co = (int)(i - pix * Cout);
+    const size_t m = i / Cout;
+    const int co = (int)(i - m * Cout);
+    const size_t nimg = m / (size_t)HWg;
+    const int rem = (int)(m - nimg * (size_t)HWg);
+    const int ga = rem / Wg, gb = rem - ga * Wg;
+    const size_t o = (((size_t)nimg * Hout + (size_t)(ga * osy + ooy)) * Wout + (size_t)(gb * osx + oox)) * Cout + co;
     if (bias) {
-        const uint16_t* bn = bias + (pix / pix_per_img) * (size_t)bias_img_stride + co;
+        const uint16_t* bn = bias + nimg * (size_t)bias_img_stride + co;
 #pragma unroll
         for (int k = 0; k < 8; k++) v[k] += bf2f(bn[k]);
     }
     if (residual) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] += bf2f(residual[i + k]);
+        for (int k = 0; k < 8; k++) v[k] += bf2f(residual[o + k]);
     }
-    uint4 o;
-    o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
-    *(uint4*)(out + i) = o;
+    uint4 ov;
+    ov.x = pack_bf16(v[0], v[1]); ov.y = pack_bf16(v[2], v[3]); ov.z = pack_bf16(v[4], v[5]); ov.w = pack_bf16(v[6], v[7]);
+    *(uint4*)(out + o) = ov;
 }
 
 // First convolution of the VAE encoder / UNet: Cin <= 4 (image or latent -> features), 3x3 / s1 / p1, + bias.
@@ -1019,7 +1027,7 @@ __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint
 int g_first_grid = 2048;   // persistent workgroups of the first-conv kernel (GD_NN_FIRST_GRID overrides, tuning)
 int g_num_cus = 256;       // MI355X; refreshed from the device properties at the first patch launch
 int g_patch_persistent = -1;   // GD_NN_PATCH_PERSISTENT=0: one workgroup per tile (A/B)
-int g_force_split = -1;    // tuning hook: -1 heuristic, 1 = never split, 3 / 9 = force
+int g_force_split = -1;    // tuning hook: -1 heuristic, 1 = never split, S > 1 = force S ranges of the K-step sequence
 int g_force_variant = -1;  // tuning hook: 0 = 128x128, 1 = 128x256, 2 = 256x256, -1 = heuristic
 
 // optional event timing of the conv kernel (bench.py's roofline line)
@@ -1055,12 +1063,24 @@ const char* gd_nn_conv_last_error(void) { return g_err; }
 // host side of one launch: tile variant choice, event profiling, kernel launch
 // Split-K factor for layers whose 128x128 tile grid cannot fill the chip (2 workgroups x 256 CUs): the nine taps
 // are dealt to 3 or 9 workgroups per tile, fp32 partials are combined by conv_splitk_reduce_kernel.
-static int choose_split(int64_t M, int Cout, int ntaps)
+// tools/splitk_sweep.py on MI355X (UNet maps at batch 1 and 2): the best split gives ~420 workgroups in flight while
+// every workgroup keeps >= 7-8 K-steps; beyond 24 ranges the fp32 partial traffic costs more than the idle CUs.
+static int pick_split(int64_t M, int64_t tiles, int steps)
 {
-    if (g_force_split >= 0) return (g_force_split == 3 || g_force_split == 9) && ntaps == 9 ? g_force_split : 1;
+    (void)M;
+    int s = (int)((420 + tiles / 2) / tiles);
+    const int cap = steps * 2 / 15 < 24 ? steps * 2 / 15 : 24;
+    if (s > cap) s = cap;
+    return s < 2 ? 1 : s;
+}
+
+static int choose_split(int64_t M, int Cout, int ntaps, int Cin)
+{
+    const int steps = ntaps * (Cin / BK);
+    if (g_force_split >= 0) return g_force_split > 1 && g_force_split <= steps ? g_force_split : 1;
     const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
-    if (ntaps != 9 || tiles >= 256 || Cout % 8) return 1;
-    return tiles * 3 >= 384 ? 3 : 9;
+    if (tiles >= 256 || Cout % 8 || steps < 8) return 1;
+    return pick_split(M, tiles, steps);
 }
 
 static int launch_conv(hipStream_t s, const void* x, const void* weight, const void* bias, int bias_img_stride,
@@ -1085,10 +1105,12 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
     // use it when Cout fills it and there are enough tiles for 256 CUs, else 128 channels x 256
     // pixels, else the 128x128 / 4-wave tile.
     const int64_t Mo = (int64_t)N * g.Hout * g.Wout;
-    int split = ws ? choose_split(M, Cout, g.ntaps) : 1;
-    if (split > 1 && ws_bytes < (size_t)split * Mo * Cout * sizeof(float)) split = 1;
+    int split = ws ? choose_split(M, Cout, g.ntaps, Cin) : 1;
+    if (split > 1 && ws_bytes < (size_t)split * M * Cout * sizeof(float)) split = 1;
     float* partial = split > 1 ? (float*)ws : nullptr;
-    const int tps = split > 1 ? g.ntaps / split : g.ntaps;
+    const int total_steps = g.ntaps * (Cin / BK);
+    const int tps = split > 1 ? (total_steps + split - 1) / split : total_steps;
+    if (split > 1) split = (total_steps + tps - 1) / tps;   // no empty ranges
     int variant = split > 1 ? 0 : g_force_variant;
     if (variant < 0) {
         // rules distilled from tools/conv_kernel_bench.py on MI355X: the 256x256 tile wins whenever Cout fills it
@@ -1128,10 +1150,10 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
     else GD_LAUNCH(128, 128, 2, 2);
 #undef GD_LAUNCH
     if (split > 1) {
-        const size_t MC = (size_t)Mo * Cout;
+        const size_t MC = (size_t)M * Cout;
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((MC / 8 + 255) / 256)), dim3(256), 0, s, partial,
-                           split, MC, Cout, (size_t)g.Hout * g.Wout, (const uint16_t*)bias, bias_img_stride,
-                           (const uint16_t*)residual, (uint16_t*)y);
+                           split, MC, Cout, g.Hg * g.Wg, g.Wg, g.Hout, g.Wout, g.osy, g.osx, g.ooy, g.oox,
+                           (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y);
     }
     if (ea && eb) {
         (void)hipEventRecord(eb, s);
@@ -1175,11 +1197,10 @@ static bool prefer_patch(int N, int H, int W, int Cout)
 
 size_t gd_nn_conv3x3_ws_bytes(int N, int H, int W, int Cin, int Cout)
 {
-    (void)Cin;
     if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
     if (prefer_patch(N, H, W, Cout)) return 0;
     const int64_t M = (int64_t)N * H * W;
-    const int split = choose_split(M, Cout, 9);
+    const int split = choose_split(M, Cout, 9, Cin);
     return split > 1 ? (size_t)split * M * Cout * sizeof(float) : 0;
 }
 
@@ -1330,12 +1351,8 @@ int gd_nn_conv3x3_first_forward(void* stream, const void* x, const void* weight,
     return GD_NN_OK;
 }
 
-int gd_nn_conv3x3_s2_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int Hin,
-                             int Win, int Cin, int Cout, int pad_lo)
+static ConvGeom s2_forward_geom(int Hin, int Win, int pad_lo)
 {
-    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
-    if (N <= 0 || Hin < 2 || Win < 2 || Cin % BK || Cout % 4 || Cin <= 0 || Cout <= 0 || (pad_lo != 0 && pad_lo != 1))
-        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3 s2: need Cin % 64 == 0, Cout % 4 == 0, pad_lo in {0, 1}");
     ConvGeom g = {};
     g.Hin = Hin; g.Win = Win;
     g.Hg = g.Hout = (Hin + pad_lo - 2) / 2 + 1;      // pad (pad_lo, 1): floor((Hin + pad_lo + 1 - 3) / 2) + 1
@@ -1344,39 +1361,95 @@ int gd_nn_conv3x3_s2_forward(void* stream, const void* x, const void* weight, co
     g.osy = g.osx = 1;
     for (int ky = 0; ky < 3; ky++)
         for (int kx = 0; kx < 3; kx++) add_tap(g, ky - pad_lo, kx - pad_lo, ky * 3 + kx);
-    return launch_conv((hipStream_t)stream, x, weight, bias, 0, nullptr, y, N, g, Cin, Cout);
+    return g;
+}
+
+// parity class (py, px) of the stride-2 input gradient; false if the class has no pixels
+static bool s2_dgrad_geom(ConvGeom& g, int Hin, int Win, int pad_lo, int py, int px)
+{
+    const int Ho = (Hin + pad_lo - 2) / 2 + 1, Wo = (Win + pad_lo - 2) / 2 + 1;
+    g = ConvGeom{};
+    g.Hin = Ho; g.Win = Wo;
+    g.Hg = (Hin - py + 1) / 2; g.Wg = (Win - px + 1) / 2;
+    g.sy = g.sx = 1;
+    g.Hout = Hin; g.Wout = Win;
+    g.osy = g.osx = 2; g.ooy = py; g.oox = px;
+    for (int ky = 0; ky < 3; ky++) {
+        if ((py + pad_lo - ky) & 1) continue;
+        for (int kx = 0; kx < 3; kx++) {
+            if ((px + pad_lo - kx) & 1) continue;
+            add_tap(g, (py + pad_lo - ky) / 2, (px + pad_lo - kx) / 2, 8 - (ky * 3 + kx));
+        }
+    }
+    return g.Hg > 0 && g.Wg > 0;
+}
+
+static size_t geom_ws_bytes(int N, const ConvGeom& g, int Cin, int Cout)
+{
+    const int64_t M = (int64_t)N * g.Hg * g.Wg;
+    const int split = choose_split(M, Cout, g.ntaps, Cin);
+    return split > 1 ? (size_t)split * M * Cout * sizeof(float) : 0;
+}
+
+// fp32 scratch the split-K form of the stride-2 layers wants (0: the layer fills the chip unsplit); forward, or the
+// input gradient of the same layer when dgrad != 0 (the largest of its parity classes)
+size_t gd_nn_conv3x3_s2_ws_bytes(int N, int Hin, int Win, int Cin, int Cout, int pad_lo, int dgrad)
+{
+    if (N <= 0 || Hin < 2 || Win < 2 || Cin <= 0 || Cout <= 0 || Cin % 4 || Cout % 4) return 0;
+    if (!dgrad) return Cin % BK ? 0 : geom_ws_bytes(N, s2_forward_geom(Hin, Win, pad_lo), Cin, Cout);
+    if (Cout % BK) return 0;
+    size_t need = 0;
+    for (int py = 0; py < 2; py++)
+        for (int px = 0; px < 2; px++) {
+            ConvGeom g;
+            if (!s2_dgrad_geom(g, Hin, Win, pad_lo, py, px)) continue;
+            const size_t b = geom_ws_bytes(N, g, Cout, Cin);
+            need = b > need ? b : need;
+        }
+    return need;
+}
+
+int gd_nn_conv3x3_s2_forward_ws(void* stream, const void* x, const void* weight, const void* bias, void* y, int N,
+                                int Hin, int Win, int Cin, int Cout, int pad_lo, void* ws, size_t ws_bytes)
+{
+    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || Hin < 2 || Win < 2 || Cin % BK || Cout % 4 || Cin <= 0 || Cout <= 0 || (pad_lo != 0 && pad_lo != 1))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3 s2: need Cin % 64 == 0, Cout % 4 == 0, pad_lo in {0, 1}");
+    return launch_conv((hipStream_t)stream, x, weight, bias, 0, nullptr, y, N, s2_forward_geom(Hin, Win, pad_lo), Cin, Cout,
+                       ws, ws_bytes);
+}
+
+int gd_nn_conv3x3_s2_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int Hin,
+                             int Win, int Cin, int Cout, int pad_lo)
+{
+    return gd_nn_conv3x3_s2_forward_ws(stream, x, weight, bias, y, N, Hin, Win, Cin, Cout, pad_lo, nullptr, 0);
+}
+
+int gd_nn_conv3x3_s2_dgrad_ws(void* stream, const void* dy, const void* weight_flipped, void* dx, int N, int Hin, int Win,
+                              int Cin, int Cout, int pad_lo, void* ws, size_t ws_bytes)
+{
+    if (!dy || !weight_flipped || !dx) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || Hin < 2 || Win < 2 || Cout % BK || Cin % 4 || Cin <= 0 || Cout <= 0 || (pad_lo != 0 && pad_lo != 1))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3 s2 dgrad: need Cout % 64 == 0, Cin % 4 == 0, pad_lo in {0, 1}");
+    // dx[2a+py, 2b+px] = sum over (ky, kx) with (py + pad - ky), (px + pad - kx) even of
+    //                    dy[a + (py + pad - ky)/2, b + (px + pad - kx)/2] . w[:, ky, kx, :]
+    // weight_flipped[ci][8 - (3 ky + kx)][co] = w[co][ky][kx][ci]  (gd_nn_conv3x3_flip_weights)
+    // The four classes run back to back on one stream and may share the scratch.
+    for (int py = 0; py < 2; py++)
+        for (int px = 0; px < 2; px++) {
+            ConvGeom g;
+            if (!s2_dgrad_geom(g, Hin, Win, pad_lo, py, px)) continue;
+            const int r = launch_conv((hipStream_t)stream, dy, weight_flipped, nullptr, 0, nullptr, dx, N, g, Cout, Cin, ws,
+                                      ws_bytes);
+            if (r < 0) return r;
+        }
+    return GD_NN_OK;
 }
 
 int gd_nn_conv3x3_s2_dgrad(void* stream, const void* dy, const void* weight_flipped, void* dx, int N, int Hin, int Win,
                            int Cin, int Cout, int pad_lo)
 {
-    if (!dy || !weight_flipped || !dx) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
-    if (N <= 0 || Hin < 2 || Win < 2 || Cout % BK || Cin % 4 || Cin <= 0 || Cout <= 0 || (pad_lo != 0 && pad_lo != 1))
-        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3 s2 dgrad: need Cout % 64 == 0, Cin % 4 == 0, pad_lo in {0, 1}");
-    const int Ho = (Hin + pad_lo - 2) / 2 + 1, Wo = (Win + pad_lo - 2) / 2 + 1;
-    // dx[2a+py, 2b+px] = sum over (ky, kx) with (py + pad - ky), (px + pad - kx) even of
-    //                    dy[a + (py + pad - ky)/2, b + (px + pad - kx)/2] . w[:, ky, kx, :]
-    // weight_flipped[ci][8 - (3 ky + kx)][co] = w[co][ky][kx][ci]  (gd_nn_conv3x3_flip_weights)
-    for (int py = 0; py < 2; py++)
-        for (int px = 0; px < 2; px++) {
-            ConvGeom g = {};
-            g.Hin = Ho; g.Win = Wo;
-            g.Hg = (Hin - py + 1) / 2; g.Wg = (Win - px + 1) / 2;
-            g.sy = g.sx = 1;
-            g.Hout = Hin; g.Wout = Win;
-            g.osy = g.osx = 2; g.ooy = py; g.oox = px;
-            for (int ky = 0; ky < 3; ky++) {
-                if ((py + pad_lo - ky) & 1) continue;
-                for (int kx = 0; kx < 3; kx++) {
-                    if ((px + pad_lo - kx) & 1) continue;
-                    add_tap(g, (py + pad_lo - ky) / 2, (px + pad_lo - kx) / 2, 8 - (ky * 3 + kx));
-                }
-            }
-            if (g.Hg <= 0 || g.Wg <= 0) continue;
-            const int r = launch_conv((hipStream_t)stream, dy, weight_flipped, nullptr, 0, nullptr, dx, N, g, Cout, Cin);
-            if (r < 0) return r;
-        }
-    return GD_NN_OK;
+    return gd_nn_conv3x3_s2_dgrad_ws(stream, dy, weight_flipped, dx, N, Hin, Win, Cin, Cout, pad_lo, nullptr, 0);
 }
 
 int gd_nn_conv3x3_up2_forward(void* stream, const void* x, const void* w_even_rows, const void* w_odd_rows,

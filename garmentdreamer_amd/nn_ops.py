@@ -31,6 +31,9 @@ SIGNATURES = {
     "gd_nn_conv3x3_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_s2_ws_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_s2_forward_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_size_t]),
+    "gd_nn_conv3x3_s2_dgrad_ws": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_size_t]),
     "gd_nn_conv3x3_up2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv_force_variant": (_i, [_i]),
     "gd_nn_linear_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
@@ -620,10 +623,13 @@ class _Conv3x3S2(torch.autograd.Function):
         Ho, Wo = (H + pad_lo - 2) // 2 + 1, (W + pad_lo - 2) // 2 + 1
         y = torch.empty((N, Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
         L = lib()
+        ws_bytes = L.gd_nn_conv3x3_s2_ws_bytes(N, H, W, Cin, Cout, pad_lo, 0)     # small maps: split-K scratch
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
         with torch.cuda.device(x.device):
-            ret = L.gd_nn_conv3x3_s2_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
-                                             weight.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                             N, H, W, Cin, Cout, pad_lo)
+            ret = L.gd_nn_conv3x3_s2_forward_ws(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
+                                                weight.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                y.data_ptr(), N, H, W, Cin, Cout, pad_lo,
+                                                None if ws is None else ws.data_ptr(), ws_bytes)
         if ret < 0:
             raise RuntimeError(f"gd_nn_conv3x3_s2_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
         ctx.weight, ctx.pad_lo, ctx.in_shape = weight, pad_lo, (N, Cin, H, W)
@@ -639,9 +645,12 @@ class _Conv3x3S2(torch.autograd.Function):
         dx = torch.empty((N, Cin, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
         wf = _flipped(ctx.weight)
         L = lib()
+        ws_bytes = L.gd_nn_conv3x3_s2_ws_bytes(N, H, W, Cin, Cout, ctx.pad_lo, 1)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device) if ws_bytes else None
         with torch.cuda.device(dy.device):
-            ret = L.gd_nn_conv3x3_s2_dgrad(torch.cuda.current_stream(dy.device).cuda_stream, dy.data_ptr(), wf.data_ptr(),
-                                           dx.data_ptr(), N, H, W, Cin, Cout, ctx.pad_lo)
+            ret = L.gd_nn_conv3x3_s2_dgrad_ws(torch.cuda.current_stream(dy.device).cuda_stream, dy.data_ptr(),
+                                              wf.data_ptr(), dx.data_ptr(), N, H, W, Cin, Cout, ctx.pad_lo,
+                                              None if ws is None else ws.data_ptr(), ws_bytes)
         if ret < 0:
             raise RuntimeError(f"gd_nn_conv3x3_s2_dgrad failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
         return dx, None, None, None

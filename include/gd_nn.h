@@ -128,6 +128,16 @@ int gd_nn_conv3x3_up2_forward(void* stream, const void* x, const void* w_even_ro
 int gd_nn_conv3x3_s2_dgrad(void* stream, const void* dy, const void* weight_flipped, void* dx, int N, int Hin, int Win,
                            int Cin, int Cout, int pad_lo);
 
+/* Split-K forms of the two stride-2 entry points for small maps (one or two views per GPU: a 16x16 -> 8x8 layer
+ * has 10 tiles for 256 CUs): the K-step sequence is dealt to several workgroups per tile, fp32 partials go to `ws`.
+ * gd_nn_conv3x3_s2_ws_bytes() gives the size the heuristic wants (0 = runs unsplit; dgrad != 0: for the input
+ * gradient); with ws == NULL or too small these behave exactly like the entry points above. */
+size_t gd_nn_conv3x3_s2_ws_bytes(int N, int Hin, int Win, int Cin, int Cout, int pad_lo, int dgrad);
+int gd_nn_conv3x3_s2_forward_ws(void* stream, const void* x, const void* weight, const void* bias, void* y, int N,
+                                int Hin, int Win, int Cin, int Cout, int pad_lo, void* ws, size_t ws_bytes);
+int gd_nn_conv3x3_s2_dgrad_ws(void* stream, const void* dy, const void* weight_flipped, void* dx, int N, int Hin, int Win,
+                              int Cin, int Cout, int pad_lo, void* ws, size_t ws_bytes);
+
 /* y[rows, inner] = x[rows, :inner] * gelu(x[rows, inner:])  (erf GELU, bf16, inner % 8 == 0): diffusers'
  * GEGLU activation of the transformer blocks' feed-forward (``hidden, gate = proj(x).chunk(2, -1);
  * hidden * F.gelu(gate)``; the UNet skeleton is un-vendored, call site stable_diffusion_guidance.py:153-157).

@@ -174,11 +174,12 @@ def test_unet_and_vae_bf16_hip_path_tracks_fp32_torch_path():
     (2, 64, 128, 16, 16, False, False), (1, 128, 128, 32, 40, False, True), (3, 320, 320, 16, 16, True, True),
     (2, 192, 64, 9, 13, True, False), (1, 64, 8, 16, 16, False, False), (2, 640, 320, 8, 8, False, True),
     (8, 128, 128, 64, 64, False, True), (2, 320, 320, 64, 64, True, True), (16, 1280, 1280, 8, 8, True, False)])
-@pytest.mark.parametrize("split", [-1, 1])
+@pytest.mark.parametrize("split", [-1, 1, 2, 7])
 def test_conv3x3_mfma_matches_fp32_reference(N, Cin, Cout, H, W, per_image_bias, res, split):
     """Asymmetric random data (catches operand / C-layout transposes), halo zero padding, ragged
     pixel and channel tiles, fused per-image bias and residual; plus the input gradient.  split = -1: the
-    library's heuristic (the small shapes here run split over the taps, x3 or x9); 1: never split."""
+    library's heuristic (the small shapes here run split over ranges of the (tap, channel step) sequence);
+    1: never split; 2, 7: forced range counts that cut taps in the middle and leave ragged last ranges."""
     from garmentdreamer_amd.nn_ops import conv3x3, conv3x3_supported, lib
     lib().gd_nn_conv_force_split(split)
     try:
@@ -353,7 +354,8 @@ def test_add_layernorm_matches_fp32_reference(rows, C, with_res):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,pad_lo", [(2, 128, 128, 32, 32, 0), (1, 256, 256, 17, 23, 0), (2, 320, 320, 16, 16, 1),
-                                                   (1, 64, 192, 9, 14, 1), (3, 128, 64, 6, 5, 0), (1, 512, 512, 64, 64, 0)])
+                                                   (1, 64, 192, 9, 14, 1), (3, 128, 64, 6, 5, 0), (1, 512, 512, 64, 64, 0),
+                                                   (2, 1280, 1280, 16, 16, 1), (2, 640, 640, 32, 32, 1), (1, 320, 320, 64, 64, 1)])
 def test_conv3x3_stride2_forward_and_dgrad_match_fp32_reference(N, Cin, Cout, H, W, pad_lo):
     """Downsample2D: UNet Conv2d(k3,s2,p1) (pad_lo 1) and the VAE's F.pad(0,1,0,1)+Conv2d(k3,s2,p0) (pad_lo 0)."""
     from garmentdreamer_amd.nn_ops import conv3x3_s2
