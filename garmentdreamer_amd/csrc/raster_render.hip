@@ -438,11 +438,15 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
 // render_backward_lists_kernel without any workgroup barrier.
 //
 // With the forward pass's ballots a strip knows which list entries it needs (about a fifth of the tile's list), so
-// nothing has to be staged by the tile as a whole: the wave gathers the centre / conic / colour of just those entries
-// (one group of 64 list positions ahead of the arithmetic, the ballots and Gaussian ids two groups ahead), runs the
-// passes A-C described above on them and stores ONE row of ten sums per (instance, strip) that has a contributing
-// pixel -- rows4[slot][strip][10] + a flag byte, written once, never accumulated; `slot` is where duplicate_kernel put
-// the instance, so the rows of a Gaussian are contiguous and preprocess_backward_kernel just adds the flagged ones.
+// nothing has to be staged by the tile as a whole.  The wave streams the ballots / Gaussian ids / instance slots of its
+// part of the list in chunks of 64 positions (three chunks in flight) and COMPACTS the entries with a non-zero ballot
+// into DENSE GROUPS of up to 64 (v_mbcnt ranks; a chunk that does not fit is split across two groups) -- most strips
+// have fewer than 64 such entries, i.e. exactly one group -- gathers the centre / conic / colour of just those, runs
+// the passes A-C described above on the group and stores ONE row of ten sums per (instance, strip) that has a
+// contributing pixel -- rows4[slot][strip][10] + a flag byte, written once, never accumulated; `slot` is where
+// duplicate_kernel put the instance, so the rows of a Gaussian are contiguous and instance_sum_kernel just adds the
+// flagged ones.  (Groups of 64 list POSITIONS, as first written, carried ~13 useful entries each: 4-8 % slower on
+// every workload tried -- per-group overheads and shorter per-pixel lists.)
 // No atomics, no __syncthreads, no zero filling of rows; gradients are bitwise reproducible.
 // =================================================================================================================
 template <int CAP>
@@ -459,7 +463,6 @@ __global__ __launch_bounds__(64) void render_backward_strip_kernel(
     __shared__ float4 s_co[64];
     __shared__ float4 s_fd[64];
     __shared__ uint4 s_tab[64];            // {ballot lo, hi, record base | count << 16, instance slot}
-    __shared__ uint8_t s_nz[64];           // entries of the group that have records, compacted
     __shared__ float2 s_rec[CAP];          // {alpha T, G dL/dalpha} per contributing pair, grouped by entry
     __shared__ uint8_t s_rid[CAP];         // ... and its pixel (lane)
     __shared__ float4 s_pix[64];           // per pixel: dL/dC rgb, dL/ddepth
@@ -503,10 +506,10 @@ __global__ __launch_bounds__(64) void render_backward_strip_kernel(
     float A = 0.f, last_alpha = 0.f, last_s = 0.f;   // A = sum_k accum_rec_k dL_k of the reference's five recurrences
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
-    // reverse index e = 0 is the LAST list entry; the strip's first useful one is e = total - wmax
+    // reverse index e = 0 is the LAST list entry; the strip's first useful one is e = total - wmax.
+    // Chunk stream: 64 list positions per chunk (lane = position), three chunks in flight.
     const int jstart = total - (int)wmax;
-    const int c_first = jstart & ~63;
-    auto load_ballot_id = [&](int c, uint64_t& bal, uint32_t& id, uint32_t& slot) {
+    auto load_chunk = [&](int c, uint64_t& bal, uint32_t& id, uint32_t& slot) {
         const int e = c + (int)lane;
         bal = 0; id = 0; slot = 0;
         if (e < total && e >= jstart) {
@@ -516,47 +519,63 @@ __global__ __launch_bounds__(64) void render_backward_strip_kernel(
             slot = slot_of[pos];
         }
     };
-    struct Data { float2 xy; float4 co, fd; };
-    auto load_data = [&](uint64_t bal, uint32_t id, Data& d) {
-        if (bal != 0) { d.xy = means2D[id]; d.co = conic_opacity[id]; d.fd = rgbd[id]; }
-    };
-    uint64_t bal_cur, bal_nxt = 0, bal_nn = 0;
-    uint32_t id_cur, id_nxt = 0, id_nn = 0, slot_cur, slot_nxt = 0, slot_nn = 0;
-    Data d_cur, d_nxt;
-    d_cur.xy = make_float2(0, 0); d_cur.co = d_cur.fd = make_float4(0, 0, 0, 0); d_nxt = d_cur;
-    load_ballot_id(c_first, bal_cur, id_cur, slot_cur);
-    load_data(bal_cur, id_cur, d_cur);
-    if (c_first + 64 < total) load_ballot_id(c_first + 64, bal_nxt, id_nxt, slot_nxt);
+    int c = jstart & ~63;
+    uint64_t bal_cur, bal_nxt, bal_nn;
+    uint32_t id_cur, id_nxt, id_nn, slot_cur, slot_nxt, slot_nn;
+    load_chunk(c, bal_cur, id_cur, slot_cur);
+    load_chunk(c + 64, bal_nxt, id_nxt, slot_nxt);
+    load_chunk(c + 128, bal_nn, id_nn, slot_nn);
+    uint64_t avail = ~0ull;          // lanes of the current chunk not yet handed to a group
 
-    for (int c = c_first; c < total; c += 64) {
-        // requests for the following groups go out before this group's arithmetic
-        load_data(bal_nxt, id_nxt, d_nxt);
-        if (c + 128 < total) load_ballot_id(c + 128, bal_nn, id_nn, slot_nn); else { bal_nn = 0; id_nn = 0; slot_nn = 0; }
-
-        const uint64_t bal = bal_cur;
-        const uint32_t bal_lo = (uint32_t)bal, bal_hi = (uint32_t)(bal >> 32);
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(bal);
-        const uint64_t nz = __builtin_amdgcn_ballot_w64(cnt != 0);
-        if (nz != 0) {
-            if (cnt != 0) { s_xy[lane] = d_cur.xy; s_co[lane] = d_cur.co; s_fd[lane] = d_cur.fd; }
-            // ---------------- pass A: ballots -> record offsets and per-pixel lists ----------------
+    while (c < total) {
+        // ---------------- compaction: the next (up to) 64 entries that have records, in list order ----------------
+        uint32_t fill = 0;
+        while (c < total) {
+            const uint64_t nzmask = __builtin_amdgcn_ballot_w64(bal_cur != 0) & avail;
+            const uint32_t cnt_nz = (uint32_t)__builtin_popcountll(nzmask);
+            const uint32_t room = 64u - fill;
+            const uint32_t myrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzmask, 0u));
+            const bool takeme = ((nzmask >> lane) & 1ull) != 0 && myrank < room;
+            if (takeme) s_tab[fill + myrank] = make_uint4((uint32_t)bal_cur, (uint32_t)(bal_cur >> 32), id_cur, slot_cur);
+            if (cnt_nz <= room) {
+                fill += cnt_nz;
+                c += 64;
+                bal_cur = bal_nxt; id_cur = id_nxt; slot_cur = slot_nxt;
+                bal_nxt = bal_nn; id_nxt = id_nn; slot_nxt = slot_nn;
+                load_chunk(c + 128, bal_nn, id_nn, slot_nn);
+                avail = ~0ull;
+                if (fill == 64u) break;
+            } else {
+                avail = nzmask & ~__builtin_amdgcn_ballot_w64(takeme);
+                fill = 64u;
+                break;
+            }
+        }
+        if (fill == 0) break;
+        __builtin_amdgcn_wave_barrier();
+        {
+            // ---------------- lane j = staged entry j: its data, record offsets, the per-pixel lists ----------------
+            const bool staged = lane < fill;
+            const uint4 ent = staged ? s_tab[lane] : make_uint4(0, 0, 0, 0);
+            const uint32_t bal_lo = ent.x, bal_hi = ent.y, slot_cur_e = ent.w;
+            if (staged) { s_xy[lane] = means2D[ent.z]; s_co[lane] = conic_opacity[ent.z]; s_fd[lane] = rgbd[ent.z]; }
+            const uint32_t cnt = (uint32_t)__builtin_popcount(bal_lo) + (uint32_t)__builtin_popcount(bal_hi);
             const uint32_t incl = wave_inclusive_scan_u32(cnt);
             const uint32_t base = incl - cnt;
-            uint32_t list_lo = 0, list_hi = 0;   // bit b: this pixel blended entry c + b
+            uint32_t list_lo = 0, list_hi = 0;   // bit j: this pixel blended staged entry j
             {
                 const uint32_t sh = lane & 31u;
                 const bool upper = lane >= 32u;
-                for (uint32_t t = (uint32_t)nz; t; t &= t - 1) {
-                    const int b = __builtin_ctz(t);
+                const int f0 = (int)(fill < 32u ? fill : 32u);
+                for (int b = 0; b < f0; b++) {
                     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)bal_lo, b);
                     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)bal_hi, b);
                     list_lo |= (((upper ? hi : lo) >> sh) & 1u) << b;
                 }
-                for (uint32_t t = (uint32_t)(nz >> 32); t; t &= t - 1) {
-                    const int b = __builtin_ctz(t);
-                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)bal_lo, b + 32);
-                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)bal_hi, b + 32);
-                    list_hi |= (((upper ? hi : lo) >> sh) & 1u) << b;
+                for (int b = 32; b < (int)fill; b++) {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)bal_lo, b);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)bal_hi, b);
+                    list_hi |= (((upper ? hi : lo) >> sh) & 1u) << (b - 32);
                 }
             }
             // sub-ranges [b0, b1) of entries whose records fit the record buffer (normally the whole group)
@@ -567,56 +586,57 @@ __global__ __launch_bounds__(64) void render_backward_strip_kernel(
                 fits |= (1ull << b0) - 1ull;
                 const uint32_t b1 = fits == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fits);
                 const uint64_t rmask = (b1 < 64u ? (1ull << b1) - 1ull : ~0ull) & ~((1ull << b0) - 1ull);
-                const uint64_t nzr = nz & rmask;
+                const uint32_t bs = b0;                       // staged entries [bs, min(b1, fill)) are this sub-range
                 b0 = b1;
-                if (nzr == 0) continue;
-                const bool in_range = ((rmask >> lane) & 1ull) != 0;
-                s_tab[lane] = make_uint4(bal_lo, bal_hi, ((base - start) & 0xffffu) | (cnt << 16), slot_cur);
-                if (in_range && cnt != 0) {
-                    const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzr, 0u));
-                    s_nz[k] = (uint8_t)lane;
-                }
-                const uint32_t nnz = (uint32_t)__builtin_popcountll(nzr);
+                if (bs >= fill) break;
+                const uint32_t nnz = (b1 < fill ? b1 : fill) - bs;
+                s_tab[lane] = make_uint4(bal_lo, bal_hi, ((base - start) & 0xffffu) | (cnt << 16), slot_cur_e);
                 __builtin_amdgcn_wave_barrier();
                 // ---------------- pass B: every pixel walks its own list ----------------
                 if (!(ablate & 1)) {
-                    uint64_t m = (((uint64_t)list_hi << 32) | list_lo) & rmask;
                     struct Ent { uint4 row; float2 xy; float4 co, fd; };
-                    auto fetch = [&](Ent& q) {           // pops the list's next entry and requests its data
-                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                        m &= m - 1;
-                        q.row = s_tab[b]; q.xy = s_xy[b]; q.co = s_co[b]; q.fd = s_fd[b];
-                    };
-                    auto step = [&](const Ent& q) {      // backward.cu:534-578 for one contributing (pixel, entry) pair
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(q.row.y, __builtin_amdgcn_mbcnt_lo(q.row.x, 0u));
-                        const float dx = q.xy.x - pixf_x, dy = q.xy.y - pixf_y;
-                        const float power = power_exact(mul_rn(mul_rn(q.co.x, dx), dx), mul_rn(q.co.y, dx), q.co.z, dy);
-                        const float G = __expf(power);
-                        const float alpha = fminf(0.99f, q.co.w * G);
-                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // shared by T/(1-a), T_final/(1-a)
-                        T = T * inv;
-                        const float sdot = q.fd.x * dLp0 + q.fd.y * dLp1 + q.fd.z * dLp2 + q.fd.w * dLpd + dLa;
-                        A = last_alpha * last_s + (1.f - last_alpha) * A;
-                        last_s = sdot;
-                        last_alpha = alpha;
-                        const float dL_dopa = (sdot - A) * T - inv * bgT;
-                        const uint32_t at = (q.row.z & 0xffffu) + rank;
-                        s_rec[at] = make_float2(alpha * T, G * dL_dopa);
-                        s_rid[at] = (uint8_t)lane;
-                    };
-                    // two-deep software pipeline, unrolled so that the two entry buffers never need copying
-                    if (m != 0) {
-                        Ent e0, e1;
-                        fetch(e0);
-                        while (true) {
-                            const bool more1 = m != 0;
-                            if (more1) fetch(e1);
-                            step(e0);
-                            if (!more1) break;
-                            const bool more0 = m != 0;
-                            if (more0) fetch(e0);
-                            step(e1);
-                            if (!more0) break;
+                    // the list is walked as two 32-bit halves (entries 0-31, then 32-63): one v_ffbl per pop
+                    for (uint32_t half = 0; half < 2u; half++) {
+                        uint32_t m = (half ? list_hi : list_lo) & (uint32_t)(rmask >> (32u * half));
+                        const uint32_t hoff = 32u * half;
+                        auto fetch = [&](Ent& q) {           // pops the list's next entry and requests its data
+                            const uint32_t b = (uint32_t)__builtin_ctz(m) + hoff;
+                            m &= m - 1u;
+                            q.row = s_tab[b]; q.xy = s_xy[b]; q.co = s_co[b]; q.fd = s_fd[b];
+                        };
+                        auto step = [&](const Ent& q) {      // backward.cu:534-578 for one contributing (pixel, entry) pair
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(q.row.y, __builtin_amdgcn_mbcnt_lo(q.row.x, 0u));
+                            const float dx = q.xy.x - pixf_x, dy = q.xy.y - pixf_y;
+                            // the forward pass's operation order: needle-shaped splats cancel to a few ulps here and a
+                            // re-associated power (5 fused ops: -3.5 % kernel time) fails the needle parity test
+                            const float power = power_exact(mul_rn(mul_rn(q.co.x, dx), dx), mul_rn(q.co.y, dx), q.co.z, dy);
+                            const float G = __expf(power);
+                            const float alpha = fminf(0.99f, q.co.w * G);
+                            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // shared by T/(1-a), T_final/(1-a)
+                            T = T * inv;
+                            const float sdot = q.fd.x * dLp0 + q.fd.y * dLp1 + q.fd.z * dLp2 + q.fd.w * dLpd + dLa;
+                            A = last_alpha * last_s + (1.f - last_alpha) * A;
+                            last_s = sdot;
+                            last_alpha = alpha;
+                            const float dL_dopa = (sdot - A) * T - inv * bgT;
+                            const uint32_t at = (q.row.z & 0xffffu) + rank;
+                            s_rec[at] = make_float2(alpha * T, G * dL_dopa);
+                            s_rid[at] = (uint8_t)lane;
+                        };
+                        // two-deep software pipeline, unrolled so that the two entry buffers never need copying
+                        if (m != 0) {
+                            Ent e0, e1;
+                            fetch(e0);
+                            while (true) {
+                                const bool more1 = m != 0;
+                                if (more1) fetch(e1);
+                                step(e0);
+                                if (!more1) break;
+                                const bool more0 = m != 0;
+                                if (more0) fetch(e0);
+                                step(e1);
+                                if (!more0) break;
+                            }
                         }
                     }
                 }
@@ -626,7 +646,7 @@ __global__ __launch_bounds__(64) void render_backward_strip_kernel(
                     for (uint32_t it0 = 0; it0 < 4u * nnz; it0 += 64u) {     // whole quads: 4 nnz is a multiple of 4
                         const uint32_t it = it0 + lane;
                         const bool active = it < 4u * nnz;
-                        const uint32_t b = active ? s_nz[it >> 2] : 0u;
+                        const uint32_t b = active ? bs + (it >> 2) : 0u;
                         const uint4 row = s_tab[b];
                         const uint32_t rcnt = row.z >> 16, rbase = row.z & 0xffffu;
                         const uint32_t qlen = (rcnt + 3u) >> 2;
@@ -697,8 +717,6 @@ __global__ __launch_bounds__(64) void render_backward_strip_kernel(
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        bal_cur = bal_nxt; id_cur = id_nxt; slot_cur = slot_nxt; d_cur = d_nxt;
-        bal_nxt = bal_nn; id_nxt = id_nn; slot_nxt = slot_nn;
     }
 }
 
@@ -739,6 +757,7 @@ void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int
                        (uint32_t)tiles_x, (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D,
                        g.conic_opacity, g.rgbd, bg, alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, rows4,
                        flags, ballots, slot_of, ablate);
+
 }
 
 }  // namespace gd
