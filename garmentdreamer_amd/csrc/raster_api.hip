@@ -132,7 +132,7 @@ BinningState carve_binning(char* chunk, size_t R, size_t* used)
     obtain(p, b.keys, R);
     obtain(p, b.keys_alt, R);
     const size_t nblk = (R + kSortTile - 1) / kSortTile;
-    obtain(p, b.sort_hist, ((size_t)1 << kMaxDigitBits) * (nblk + 1));
+    obtain(p, b.sort_hist, ((size_t)1 << kSortHistBits) * (nblk + 1));
     obtain(p, b.ballots, 4 * R);
     if (used) *used = (size_t)(p - chunk);
     return b;

@@ -57,11 +57,12 @@ ImageState carve_image(char* chunk, size_t tiles_total, size_t pixels_total, siz
 BinningState carve_binning(char* chunk, size_t R, size_t* used);
 
 uint32_t higher_msb(uint32_t n);
-struct SortPlan { int total_bits, passes, digit_bits; };
+struct SortPlan { int total_bits, live_bits, passes, digit_bits; };
 SortPlan plan_sort(uint32_t tiles_total);
 constexpr int kSortItems = 8;                      // keys per thread
 constexpr int kSortTile = 256 * kSortItems;        // keys per workgroup
-constexpr int kMaxDigitBits = 11;
+constexpr int kSortHistBits = 10;   // widest digit any caller sorts with (the 30-bit Morton codes: 3 x 10): sizes sort_hist
+constexpr int kMaxDigitBits = 9;    // wider digits cost more per pass than they save in passes (raster_binning.hip)
 
 // getRect (DGR/cuda_rasterizer/auxiliary.h:46-56): tile rectangle of a splat, clamped to the grid.
 __device__ __forceinline__ void tile_rect(float px, float py, int max_radius, uint32_t gx, uint32_t gy,

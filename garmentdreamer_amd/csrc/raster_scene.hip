@@ -370,7 +370,7 @@ int gd_scene_dist2(void* stream, int P, const float* points, float* mean_dists, 
     hipLaunchKernelGGL(knn_morton_kernel, dim3(nblk), dim3(256), 0, s, P, points, k.mm, k.bin.keys_alt,
                        k.bin.point_list_alt);
     SortPlan plan;
-    plan.total_bits = 30; plan.digit_bits = 10; plan.passes = 3;
+    plan.total_bits = plan.live_bits = 30; plan.digit_bits = 10; plan.passes = 3;
     launch_radix_sort(s, k.bin, (uint32_t)P, plan, true);
     const int nboxes = (P + kBox - 1) / kBox;
     hipLaunchKernelGGL(knn_gather_box_kernel, dim3(nboxes), dim3(256), 0, s, P, points, k.bin.point_list, k.spts,
