@@ -385,41 +385,32 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
 
 constexpr int kAcc = 10;  // colour rgb, depth, mean2D xy, conic x/y/w, opacity
 
-// The backward blend kernels write ONE row of kAcc floats per list position (inst[position][kAcc], position =
-// range.x ... range.y - 1 of the tile) and never accumulate across workgroups: every row of every tile is stored
-// exactly once -- zeros for the entries no pixel reaches -- and preprocess_backward_kernel gathers the rows of a
-// Gaussian.  zero_rows: rows [first, first + count) <- 0 by the whole workgroup.
-__device__ __forceinline__ void zero_rows(float* __restrict__ inst, uint32_t first, uint32_t count, uint32_t tid,
-                                          uint32_t threads)
-{
-    float2* p = reinterpret_cast<float2*>(inst + (size_t)first * kAcc);
-    for (uint32_t i = tid; i < count * (kAcc / 2); i += threads) p[i] = make_float2(0.f, 0.f);
-}
-
 // =================================================================================================================
-// The reverse-order gradient pass, re-organised around PER-PIXEL LISTS (implemented by render_backward_strip_kernel).
+// The reverse-order gradient pass, organised around PER-PIXEL LISTS (render_backward_strip_kernel below).
 //
-// The wave-uniform walk above executes its ~60-instruction body for all 64 lanes of a strip although on the
-// benchmark scene only a third of the 64 pixels blend a given (strip, entry) pair -- and for half of the pairs the
-// strip culling lets through, none does -- and then pays a 38-instruction cross-lane reduction per pair: VALU-issue
-// bound at 7 % of the fp32 roof.  Here nothing is evaluated for a pair that does not contribute:
+// A wave-uniform walk of the tile's list (the reference's organisation, and round 1's) executes its ~60-instruction
+// body for all 64 lanes of a strip although on the benchmark scene only a third of the 64 pixels blend a given (strip,
+// entry) pair -- and for half of the pairs a strip-level culling lets through, none does -- and then pays a
+// 38-instruction cross-lane reduction per pair: VALU-issue bound at 7 % of the fp32 roof.  Here nothing is evaluated
+// for a pair that does not contribute:
 //
 //   *  the forward pass leaves, per (strip, list position), the 64-bit ballot of the pixels that blended the entry
 //      (render_forward_kernel, `ballots`): exactly the pairs backward.cu:517-533 lets through, so the reverse pass
 //      needs neither the contribution test nor the strip culling;
-//   A  per group of 64 list entries a wave loads its 64 ballots (lane = entry), turns their popcounts into record
-//      offsets with one DPP scan and transposes the non-zero ones into a per-PIXEL list (lane = pixel, bit = entry);
+//   A  per dense group (up to 64 entries that HAVE records, compacted from the strip's part of the list) a wave turns
+//      the ballots' popcounts into record offsets with one DPP scan and transposes the ballots into a per-PIXEL list
+//      (lane = pixel, bit = entry);
 //   B  (lane = pixel, each lane walks ITS OWN list)  the sequential part of backward.cu:517-578 -- exp, alpha,
-//      T /= (1 - alpha), the accumulated-colour recurrence, dL/dalpha.  Lanes advance independently, so a step keeps
-//      about half of the lanes busy instead of a third, and the five recurrences of the reference (3 colours, depth,
-//      alpha) collapse into ONE because only their dot product with the pixel's (dL/dC, dL/ddepth, dL/dalpha) is ever
-//      used.  Output: a record {alpha T, G dL/dalpha, pixel} per contributing pair at slot base[entry] +
-//      rank-of-the-pixel-in-the-entry's-ballot (v_mbcnt), i.e. grouped by entry;
+//      T /= (1 - alpha), the accumulated-colour recurrence, dL/dalpha.  Lanes advance independently, and the five
+//      recurrences of the reference (3 colours, depth, alpha) collapse into ONE because only their dot product with
+//      the pixel's (dL/dC, dL/ddepth, dL/dalpha) is ever used.  Output: a record {alpha T, G dL/dalpha, pixel} per
+//      contributing pair at slot base[entry] + rank-of-the-pixel-in-the-entry's-ballot (v_mbcnt): grouped by entry;
 //   C  (lane = quarter of an entry's records)  gathers the records and accumulates the ten sums of
 //      backward.cu:555-598 in registers -- colour / depth gradients and the moments sum w, sum w d, sum w d d^T of
 //      the pixel offsets d, from which dL/dmean2D, dL/dconic and dL/dopacity follow by one multiplication per entry.
-//      No cross-lane reduction; LDS atomics combine the quarters and the tile's four strips; the flush to
-//      acc[vp][10] is unchanged.
+//      Two DPP adds per value combine the quad; its first lane stores the row rows4[slot][strip][kAcc] and the flag.
+//      Rows are written once and never accumulated: instance_sum_kernel (raster_preprocess.hip) adds the flagged rows
+//      of each (view, Gaussian).
 // =================================================================================================================
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
 {
@@ -434,8 +425,8 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
 }
 
 // =================================================================================================================
-// render_backward_strip_kernel -- one INDEPENDENT wave per (tile, 16x4 strip): the list-based reverse pass of
-// render_backward_lists_kernel without any workgroup barrier.
+// render_backward_strip_kernel -- one INDEPENDENT wave per (tile, 16x4 strip): the list-based reverse pass described
+// above, without any workgroup barrier.
 //
 // With the forward pass's ballots a strip knows which list entries it needs (about a fifth of the tile's list), so
 // nothing has to be staged by the tile as a whole.  The wave streams the ballots / Gaussian ids / instance slots of its
