@@ -407,6 +407,12 @@ def main():
                     if k.startswith("render_backward") and "hbm_bytes_per_launch" in v:
                         roofline["traffic"] = v["hbm_bytes_per_launch"]
                         roofline["traffic_source"] = "profiles/r02_pmc.json"
+                        if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_BUSY_CYCLES"):
+                            # quad-cycles with a VALU instruction executing (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count
+                            # quad-cycles) over the SIMD-cycles of the launch (SQ_BUSY_CYCLES is summed over the 32
+                            # shader engines; 1024 SIMDs): how busy the vector ALUs were, whatever they executed
+                            roofline["valu_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
+                            roofline["valu_insts_per_launch"] = v.get("SQ_INSTS_VALU")
         except Exception:
             pass
     steady = os.path.join(ROOT, "profiles", "r02_bench_N1_kernel_stats_steady.csv")
