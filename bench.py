@@ -407,12 +407,17 @@ def main():
                     if k.startswith("render_backward") and "hbm_bytes_per_launch" in v:
                         roofline["traffic"] = v["hbm_bytes_per_launch"]
                         roofline["traffic_source"] = "profiles/r02_pmc.json"
-                        if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_BUSY_CYCLES"):
-                            # quad-cycles with a VALU instruction executing (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count
-                            # quad-cycles) over the SIMD-cycles of the launch (SQ_BUSY_CYCLES is summed over the 32
-                            # shader engines; 1024 SIMDs): how busy the vector ALUs were, whatever they executed
-                            roofline["valu_busy"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
-                            roofline["valu_insts_per_launch"] = v.get("SQ_INSTS_VALU")
+                        if v.get("SQ_INSTS_VALU") and v.get("SQ_BUSY_CYCLES"):
+                            # SIMD-cycles of the launch: SQ_BUSY_CYCLES is summed over the 32 shader engines; 1024 SIMDs
+                            simd_cycles = v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
+                            # lower bound of the VALU issue utilisation: every wave64 VALU instruction holds the SIMD-32
+                            # for >= 2 cycles (v_fma_f32; transcendental / DPP / 64-bit ops longer)
+                            roofline["valu_issue_util_min"] = 2.0 * v["SQ_INSTS_VALU"] / simd_cycles
+                            roofline["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
+                            if v.get("SQ_ACTIVE_INST_VALU"):
+                                # SQ_ACTIVE_INST_* count quad-cycles per wave (MI355X_MICROARCH.md): average number of
+                                # waves per SIMD with a VALU instruction in flight
+                                roofline["valu_active_waves_per_simd"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / simd_cycles
         except Exception:
             pass
     steady = os.path.join(ROOT, "profiles", "r02_bench_N1_kernel_stats_steady.csv")
