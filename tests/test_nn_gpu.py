@@ -760,3 +760,24 @@ def test_attention_d64_with_a_key_count_that_is_not_a_multiple_of_64(B, H, S, Sk
     err = (out.float() - ref).abs().max().item()
     assert err <= 2e-2 * ref.abs().max().item() + 2e-3, err
     assert F.cosine_similarity(out.float().flatten(), ref.flatten(), dim=0).item() > 0.9995
+
+
+@pytest.mark.parametrize("M,K,N,res", [(4096, 320, 320, True), (1000, 640, 1920, False), (77, 1024, 640, False),
+                                       (65536, 320, 2560, False), (513, 1280, 1284, True)])
+def test_linear_one_tap_gemm_matches_fp32_reference(M, K, N, res):
+    """gd_nn_linear_forward: nn.Linear (+ residual) as a one-tap launch of the implicit-GEMM convolution kernel
+    (ragged M and N tiles, bias, residual).  An option, not the default path: hipBLASLt is faster on these shapes."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(M + K)
+    x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV, generator=g).to(torch.bfloat16)
+    r = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16) if res else None
+    with torch.no_grad():
+        assert nn_ops.linear_supported(x, w)
+        y = nn_ops.linear(x, w, b, r).float()
+    ref = x.float() @ w.float().t() + b.float() + (r.float() if res else 0.0)
+    assert y.shape == ref.shape
+    err = (y - ref).abs().max().item()
+    assert err <= 1e-2 * ref.abs().max().item() + 1e-2, err
+    assert F.cosine_similarity(y.flatten(), ref.flatten(), dim=0).item() > 0.9999
