@@ -10,9 +10,12 @@ from garmentdreamer_amd import nn_ops
 from garmentdreamer_amd.nn_ops import conv3x3
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+MID = len(sys.argv) > 2 and sys.argv[2] == "mid"   # the 256..511-tile layers of two views per GPU
 SHAPES = [(320, 320, 64), (640, 320, 64), (960, 320, 64), (320, 640, 32), (640, 640, 32), (1280, 640, 32), (960, 640, 32),
           (1920, 640, 32), (640, 1280, 16), (1280, 1280, 16), (2560, 1280, 16), (1920, 1280, 16), (1280, 1280, 8),
           (2560, 1280, 8)]
+if MID:
+    SHAPES = [(512, 512, 64), (1280, 1280, 32), (320, 320, 64), (640, 320, 64), (960, 320, 64), (2560, 1280, 32), (640, 640, 64)]
 L = nn_ops.lib()
 
 
