@@ -213,6 +213,13 @@ def vsd_main(args):
     gdist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # health (untimed): a replayed graph that went wrong shows up as non-finite adapters / image gradient
+    with torch.no_grad():
+        health = {"lora_params_finite": all(bool(torch.isfinite(p).all()) for p in train),
+                  "image_grad_finite": bool(img.grad is not None and torch.isfinite(img.grad).all()),
+                  "image_grad_nonzero": bool(img.grad is not None and float(img.grad.abs().sum()) > 0)}
+    if not all(health.values()):
+        raise SystemExit(f"bench.py --vsd: unhealthy run {health}")
     if rk == 0:
         tfl = 3 * UNET_TFLOP_PER_SAMPLE + 2 * VAE_TFLOP_PER_IMAGE + 3 * UNET_TFLOP_PER_SAMPLE
         print(json.dumps({"metric": "NeTF VSD iters/sec (VAE + 3 UNet fwd + LoRA-UNet fwd/bwd), 512^2, 1 view/GPU",
@@ -221,6 +228,7 @@ def vsd_main(args):
                           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                           "config": {"workload": "VSD step, SD-2.1 UNet + LoRA UNet (rank 4) random-init, batch 1",
                                      "hip_graphs": bool(gd.use_hip_graphs)},
+                          "health": health,
                           "roofline_dense": {"bound": "mfma", "achieved": tfl / (el / args.steps),
                                              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                              "frac": tfl / (el / args.steps) / PEAK_BF16_TFLOPS}}), flush=True)
