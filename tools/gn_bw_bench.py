@@ -15,7 +15,10 @@ def ev_time(fn, n=10):
     return e0.elapsed_time(e1) * 1e-3 / n
 
 L = nn_ops.lib()
-for (N, C, H) in [(8, 128, 512), (8, 256, 256), (8, 128, 256), (8, 512, 128), (8, 256, 128), (8, 512, 64), (16, 320, 64), (16, 640, 32), (16, 1280, 16)]:
+SHAPES = [(8, 128, 512), (8, 256, 256), (8, 128, 256), (8, 512, 128), (8, 256, 128), (8, 512, 64), (16, 320, 64), (16, 640, 32), (16, 1280, 16)]
+if os.environ.get("GN_SHAPE"):
+    SHAPES = [SHAPES[int(os.environ["GN_SHAPE"])]]
+for (N, C, H) in SHAPES:
     cl = torch.channels_last
     x = torch.randn(N, C, H, H, device="cuda").to(torch.bfloat16).contiguous(memory_format=cl)
     dy = torch.randn(N, C, H, H, device="cuda").to(torch.bfloat16).contiguous(memory_format=cl)
