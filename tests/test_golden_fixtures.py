@@ -104,3 +104,57 @@ def test_python_op_marshals_like_the_reference(monkeypatch):
     got = {n: float(leaves[n].grad.flatten()[0]) for n in leaves}
     assert got == gold["grad_sentinel_by_input"]
     assert color.shape == (3, H, W) and radii.dtype == torch.int32 and depth.shape == (1, H, W)
+
+
+def _pins():
+    return np.load(os.path.join(G, "raster_pins.npz"))
+
+
+def test_oracle_cov3D_matches_reference_build_covariance():
+    """computeCov3D of the C oracle (forward.cu:118-152) vs the reference's Python
+    ``build_covariance_from_scaling_rotation`` (scene/gaussian_model.py:27-31), fp32 tolerance: pins the
+    S·R / GLM-transposition order and the (xx, xy, xz, yy, yz, zz) packing."""
+    d = _pins()
+    s, q = d["cov_scales"], d["cov_quats"]
+    N = s.shape[0]
+    for mi, mod in enumerate(d["cov_mods"]):
+        inp = h.raster_inputs(P=N, H=64, W=64)
+        # spread the Gaussians on a small sphere in front of the default camera so that none is culled
+        inp["means3D"] = (d["ndc_points"][:N] * 0.3).astype(np.float32)
+        inp["scales"], inp["rotations"], inp["scale_modifier"] = s, q, float(mod)
+        st = h.oracle_forward(inp)
+        vis = st.radii > 0
+        assert vis.sum() >= N - 4, vis.sum()
+        ref = d["cov3D"][mi]
+        scale = np.abs(ref).max(axis=1, keepdims=True)
+        err = np.abs(st.cov3D[vis] - ref[vis]) / scale[vis]
+        assert err.max() < 4e-6, err.max()   # a few fp32 ulps of the largest entry (different summation order)
+
+
+def test_oracle_projection_matches_reference_geom_transform_points():
+    """transformPoint4x4 + 1/(w + 1e-7) + ndc2Pix of the C oracle (forward.cu:193-196, auxiliary.h:41-44) vs the
+    reference's ``geom_transform_points`` (utils/graphics_utils.py:22-29) on the 20 fixture cameras."""
+    d = _pins()
+    cams = np.load(os.path.join(G, "cameras.npz"))
+    pts = d["ndc_points"]
+    N = pts.shape[0]
+    checked = 0
+    for i, (az, el, dist, fovy, H, W, fovx) in enumerate(cams["params"]):
+        H, W = int(H), int(W)
+        inp = h.raster_inputs(P=N, H=H, W=W)
+        inp["means3D"] = pts
+        inp["viewmatrix"], inp["projmatrix"] = cams["wvt"][i], cams["full"][i]
+        inp["tanfovx"], inp["tanfovy"] = float(np.tan(fovx * 0.5)), float(np.tan(fovy * 0.5))
+        inp["campos"] = cams["center"][i]
+        st = h.oracle_forward(inp)
+        vis = st.radii > 0
+        ndc = d["ndc"][i].astype(np.float64)
+        pix = np.stack([((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5], 1)
+        err = np.abs(st.means2D[vis] - pix[vis])
+        # |ndc| <= ~1.3 -> one fp32 ulp of ndc is 1.2e-7, times S/2 pixels
+        assert err.max() <= 4e-7 * max(H, W) + 1e-5, (i, err.max())
+        # depth the keys are built from = view-space z = w of the projection (row-vector convention)
+        w = (np.concatenate([pts, np.ones((N, 1), np.float32)], 1).astype(np.float64) @ cams["full"][i].astype(np.float64))[:, 3]
+        np.testing.assert_allclose(st.depths[vis], w[vis], rtol=2e-6, atol=1e-6)
+        checked += int(vis.sum())
+    assert checked > 10 * N
