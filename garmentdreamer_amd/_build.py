@@ -22,7 +22,10 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 RASTER_SOURCES = [
     ("raster_preprocess.hip", ["-ffp-contract=off"]),
     ("raster_binning.hip", []),
-    ("raster_render.hip", ["-munsafe-fp-atomics"]),
+    ("raster_render.hip", []),
+    # the SLP vectoriser pairs scalar fp32 adds into v_pk_add_f32, which keeps the DPP moves of the row scans from
+    # being fused into their adds; the packed math of this file is written out as float2
+    ("raster_render_bwd.hip", ["-fno-slp-vectorize"]),
     ("raster_api.hip", []),
     ("raster_scene.hip", ["-ffp-contract=off"]),
 ]

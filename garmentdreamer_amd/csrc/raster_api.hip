@@ -118,6 +118,7 @@ ImageState carve_image(char* chunk, size_t tiles_total, size_t pixels_total, siz
     obtain(p, im.ranges, tiles_total);
     obtain(p, im.n_contrib, pixels_total);
     obtain(p, im.pair_counts, pixels_total);
+    obtain(p, im.strip_count, tiles_total * 4);
     if (used) *used = (size_t)(p - chunk);
     return im;
 }
@@ -133,7 +134,7 @@ BinningState carve_binning(char* chunk, size_t R, size_t* used)
     obtain(p, b.keys_alt, R);
     const size_t nblk = (R + kSortTile - 1) / kSortTile;
     obtain(p, b.sort_hist, ((size_t)1 << kSortHistBits) * (nblk + 1));
-    obtain(p, b.ballots, 4 * R);
+    obtain(p, b.clist, 4 * R);
     if (used) *used = (size_t)(p - chunk);
     return b;
 }
@@ -240,7 +241,8 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     if (int e = check_debug(stream, debug, "ranges")) return e;
     { ProfScope ps(stream, GD_K_RENDER_FWD);
     launch_render_forward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
-                          out_color, out_depth, out_alpha, img.n_contrib, img.pair_counts, bin.ballots, num_rendered); }
+                          out_color, out_depth, out_alpha, img.n_contrib, img.pair_counts, bin.point_list_alt /* slot_of */,
+                          bin.clist, img.strip_count); }
     if (int e = check_debug(stream, debug, "render")) return e;
     GD_HIP(hipGetLastError());
     return (int)num_rendered;
@@ -285,9 +287,8 @@ int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const f
     GD_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));
     if (R > 0) {
         { ProfScope ps(stream, GD_K_RENDER_BWD);
-        launch_render_backward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
-                               alphas, img.n_contrib, dL_dpix, dL_dpix_depth, dL_dalphas, inst, flags, bin.ballots,
-                               bin.point_list_alt /* slot_of */); }
+        launch_render_backward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, geom, background, alphas, dL_dpix,
+                               dL_dpix_depth, dL_dalphas, inst, flags, bin.clist, img.strip_count); }
     }
     if (int e = check_debug(stream, debug, "render backward")) return e;
 
@@ -508,7 +509,7 @@ const char* gd_raster_profile_kernel_name(int kernel_id)
 {
     static const char* names[GD_K_COUNT] = {"preprocess_kernel", "scan_block_sums_kernel", "duplicate_kernel",
                                             "radix_sort(all passes)", "tile_ranges_kernel", "render_forward_kernel",
-                                            "render_backward_strip_kernel", "instance_sum_kernel + preprocess_backward_kernel"};
+                                            "render_backward_block_kernel", "instance_sum_kernel + preprocess_backward_kernel"};
     return (kernel_id >= 0 && kernel_id < GD_K_COUNT) ? names[kernel_id] : "";
 }
 

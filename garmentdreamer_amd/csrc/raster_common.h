@@ -38,6 +38,7 @@ struct ImageState {
     uint2* ranges;        // [V*tiles]
     uint32_t* n_contrib;  // [V*H*W]
     uint2* pair_counts;   // [V*H*W] {visited, blended} per pixel (work accounting for the roofline)
+    uint32_t* strip_count;  // [V*tiles*4] entries of each 16x4 strip's compact list (see BinningState::clist)
 };
 struct BinningState {
     uint32_t* point_list;      // [R] sort payload = instance SLOT (see slot_vp); after tile_ranges: the Gaussian (vp) ids
@@ -47,9 +48,12 @@ struct BinningState {
     uint64_t* keys;            // [R] sorted keys
     uint64_t* keys_alt;        // [R]
     uint32_t* sort_hist;       // [bins * nblk + bins]
-    uint64_t* ballots;         // [R][4] per (list position, 16x4 strip of its tile): which of the strip's 64 pixels
-                               // BLENDED the entry in the forward pass (written by render_forward, read by the
-                               // backward blend: the reverse pass never repeats the contribution test)
+    uint4* clist;              // [4R] compact per-strip lists written by render_forward, read by the backward blend:
+                               // strip s of a tile with list range [x, y) owns entries [4x + s (y - x), + (y - x));
+                               // an entry = {64-bit ballot of the strip's pixels that BLENDED it (lane = 16 * 4x4
+                               // block + 4 * row + column), Gaussian (vp) id, instance slot}, in list order, only
+                               // for entries with a non-zero ballot: the reverse pass never repeats the
+                               // contribution test and never sees the pairs nobody blended
 };
 
 GeomState carve_geom(char* chunk, size_t VP, size_t* used);
@@ -104,14 +108,13 @@ void launch_blend_exp(hipStream_t s, const float* x, float* y, int n);   // y = 
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
                            float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts,
-                           uint64_t* ballots, uint32_t R);
+                           const uint32_t* slot_of, uint4* clist, uint32_t* strip_count);
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
-                            const uint32_t* point_list, const GeomState& g, const float* bg, const float* alphas,
-                            const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                            const float* dL_dalphas,
-                            float* rows4 /*[R][4][10] by instance SLOT: one row per (slot, strip) with a non-zero ballot*/,
-                            uint8_t* flags /*[R][4], zeroed: 1 where a row was stored*/, const uint64_t* ballots,
-                            const uint32_t* slot_of);
+                            const GeomState& g, const float* bg, const float* alphas, const float* dL_dpix,
+                            const float* dL_dpix_depth, const float* dL_dalphas,
+                            float* rows4 /*[R][4][10] by instance SLOT: one row per (slot, strip) with a listed entry*/,
+                            uint8_t* flags /*[R][4], zeroed: 1 where a row was stored*/, const uint4* clist,
+                            const uint32_t* strip_count);
 
 
 }  // namespace gd

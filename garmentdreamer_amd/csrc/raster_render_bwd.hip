@@ -1,0 +1,301 @@
+// raster_render_bwd.hip -- the reverse-order gradient pass of the alpha blend for gfx950.
+//
+//   render_backward_block_kernel  <- renderCUDA backward (DGR/cuda_rasterizer/backward.cu:415-601)
+//
+// What the reference does per contributing (pixel, Gaussian) pair, back to front (backward.cu:517-598):
+//     T     <- T / (1 - alpha)                                   transmittance in front of the pair
+//     A     <- blend of everything behind the pair               (five recurrences: 3 colours, depth, alpha)
+//     dL/dalpha = T (s - A) - T_final / (1 - alpha) (bg . dL/dC)      s = colour . dL/dC + depth dL/dD + dL/dalpha_img
+//     ten atomicAdd per pair: colour / depth gradients (alpha T dL/dpixel), mean2D, conic, opacity (via G dL/dalpha)
+// The two recurrences are prefix operations over the pixel's list:
+//     T_i = T_final * prod_{j <= i} 1 / (1 - alpha_j)            (j, i count from the BACK of the list)
+//     T_i A_i (1 - alpha_i) = sum_{j < i} alpha_j T_j s_j        so with  U_i = bg-term + sum_{j < i} alpha_j T_j s_j :
+//     dL/dalpha_i = T_i s_i - U_i / (1 - alpha_i)
+// i.e. one product scan and one sum scan per pixel -- everything else is local to the pair.
+//
+// Mapping to CDNA4 (measured on MI355X, tools/probes/valu_rate_probe.hip: a wave64 VALU instruction occupies its SIMD
+// for ~4.5 cycles, v_pk_*_f32 ~5.3 for twice the work, v_exp / v_rcp ~8.5, DPP modifiers are free; the kernel is
+// VALU-issue bound, so the design minimises VALU instructions per contributing pair):
+//   * one wave per (tile, 16x4 strip); the strip is four 4x4 pixel BLOCKS, one per row of 16 lanes;
+//   * lane = (block b, entry i): row b of the wave holds 16 consecutive entries of block b's own list (the entries
+//     with a non-zero 16-bit quarter of the forward pass's ballot), back to front.  The entry's centre, conic, colour
+//     and the per-block tables of dx, dy, (a dx) dx, b dx, (c dy) dy live in registers;
+//   * the 16 pixels of the block are walked wave-uniformly, TWO per step in packed fp32 (v_pk_fma_f32 ...): 61 % of
+//     the (entry, pixel) cells of a 4x4 block contribute (34 % for a 16x4 strip, 19 % for a tile), no cross-lane
+//     reduction is needed for the ten sums (lane = entry: they accumulate in registers), and the two scans run
+//     across the 16 lanes of a row as four DPP row_shr steps each;
+//   * pixel data (dL/dpixel, and the T / U carries between chunks of 16 entries) are broadcast LDS reads (one
+//     address per row), the only LDS traffic of the inner loop;
+//   * per window of 64 strip entries the (entry, block) rows are added up in an LDS table [entry][10] -- the four
+//     rows of the wave take turns (plain read-add-write, one row of lanes at a time: ds_add_f32 costs far more) -- and
+//     stored ONCE as rows4[slot][strip][10] (+ flag byte); instance_sum_kernel adds the rows of a Gaussian.
+//     No atomics, no workgroup barriers; gradients are bitwise reproducible.
+//   * 8.5 KB of LDS and <= 128 VGPRs per wave: four waves per SIMD (a lone wave issues a VALU instruction every ~9
+//     cycles, two every 5.8, four every 5.0).
+#include "raster_common.h"
+
+namespace gd {
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kAcc = 10;   // colour rgb, depth, mean2D xy, conic x/y/w, opacity
+constexpr int kWin = 64;   // strip entries per window (one per lane when the window is loaded)
+
+struct PixPair {           // per (block, pixel pair): 64 B, read as broadcast by the 16 lanes of the block's row
+    f2 g0, g1, g2, gd;     // dL/dC r, g, b and dL/ddepth of the two pixels
+    f2 ga, pad;            // dL/dalpha_image
+    f2 Tc, Uc;             // carries of the two scans (start: T_final and the background term)
+};
+struct EntryRow {          // one strip entry of the current window: 48 B
+    float x, y, a, b;      // centre (pixels), conic xx, xy
+    float c, o, f0, f1;    // conic yy, opacity, colour r, g
+    float f2_, f3, pad0, pad1;   // colour b, depth
+};
+
+// inclusive prefix sum over the 16 lanes of a row (lane 0 of the row first); zero fill for the shifted-in lanes
+__device__ __forceinline__ float row_scan_add(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));   // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));   // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));   // row_shr:8
+    return v;
+}
+// inclusive prefix PRODUCT over the 16 lanes of a row.  v_mul_f32_dpp without bound_ctrl leaves the lanes whose
+// source is shifted in from outside the row unwritten, i.e. multiplied by one.  (The compiler fuses a DPP move into
+// an fp multiply only for zero fill, so this step is written out; s_nop 1 = the two wait states a DPP read of a
+// freshly written VGPR needs, which the hazard recogniser cannot insert inside an asm.)
+__device__ __forceinline__ float row_scan_mul(float v)
+{
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ float and_mask(float v, int m) { return __int_as_float(__float_as_int(v) & m); }
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_backward_block_kernel(
+    int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
+    const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd,
+    const float* __restrict__ bg_color, const float* __restrict__ alphas, const float* __restrict__ dL_dpixels,
+    const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ rows4,
+    uint8_t* __restrict__ flags, const uint4* __restrict__ clist, const uint32_t* __restrict__ strip_count)
+{
+    __shared__ PixPair s_px[4][8];              //  2 KB
+    __shared__ EntryRow s_ent[kWin];            //  3 KB
+    __shared__ uint32_t s_sub[4][kWin];         //  1 KB  per block: (entry index in the window) | (16-bit pixel mask << 8)
+    __shared__ float s_acc[kWin][kAcc];         //  2.5 KB the ten sums of each entry of the window, over its blocks
+
+    // workgroup u runs on XCD u % 8: the four strips of a tile and neighbouring tiles share an XCD (and its L2)
+    const uint32_t nblk = tiles_total * 4u;
+    uint32_t unit = blockIdx.x;
+    if ((nblk & 7u) == 0) unit = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    const uint32_t n_listed = strip_count[unit];     // strip_count[tile * 4 + strip]
+    if (n_listed == 0) return;                       // nobody in this strip blended anything: no rows
+    const uint32_t tile = unit >> 2;
+    const uint32_t strip = unit & 3u;
+    const uint32_t tpv = gx * gy;
+    const uint32_t view = tile / tpv;
+    const uint32_t lt = tile - view * tpv;
+    const uint32_t ty_ = lt / gx, tx_ = lt - ty_ * gx;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t blk = lane >> 4, li = lane & 15u;
+    const size_t HW = (size_t)H * W;
+    const uint2 range = ranges[tile];
+    const uint4* const my_list = clist + ((size_t)range.x * 4u + (size_t)strip * (range.y - range.x));
+
+    // ---- lane = pixel (16 * block + 4 * y + x): gradients of the image, T_final, the background term ----
+    {
+        const uint32_t px = tx_ * kTile + 4u * blk + (li & 3u), py = ty_ * kTile + 4u * strip + (li >> 2);
+        const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+        const size_t pix_id = (size_t)view * HW + (size_t)W * py + px;
+        float d0 = 0, d1 = 0, d2 = 0, dd = 0, da = 0, T_final = 0;
+        if (inside) {
+            const float* dp = dL_dpixels + (size_t)view * 3 * HW + ((size_t)W * py + px);
+            d0 = dp[0]; d1 = dp[HW]; d2 = dp[2 * HW];
+            dd = dL_dpixel_depths[pix_id];
+            da = dL_dalphas[pix_id];
+            T_final = 1.f - alphas[pix_id];          // this fork: reconstructed from the OUTPUT alpha (backward.cu:463)
+        }
+        const float bgT = T_final * (bg_color[0] * d0 + bg_color[1] * d1 + bg_color[2] * d2);
+        float* q = reinterpret_cast<float*>(&s_px[blk][li >> 1]) + (li & 1u);
+        q[0] = d0; q[2] = d1; q[4] = d2; q[6] = dd; q[8] = da; q[12] = T_final; q[14] = bgT;
+    }
+    const float fx0 = (float)(tx_ * kTile + 4u * blk), fy0 = (float)(ty_ * kTile + 4u * strip);   // the row's block origin
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    PixPair* const pp = &s_px[blk][0];
+
+    // ---- windows of 64 strip entries, from the back of the list ----
+    for (uint32_t w0 = 0; w0 < n_listed; w0 += kWin) {
+        const bool have = w0 + lane < n_listed;                    // lane 0 = the backmost entry of the window
+        uint4 ent = make_uint4(0, 0, 0, 0);
+        if (have) ent = my_list[n_listed - 1u - (w0 + lane)];
+        const uint32_t nwin = min((uint32_t)kWin, n_listed - w0);
+        if (have) {
+            const float2 xy = means2D[ent.z];
+            const float4 co = conic_opacity[ent.z];
+            const float4 fd = rgbd[ent.z];
+            float4* e4 = reinterpret_cast<float4*>(&s_ent[lane]);
+            e4[0] = make_float4(xy.x, xy.y, co.x, co.y);
+            e4[1] = make_float4(co.z, co.w, fd.x, fd.y);
+            e4[2] = make_float4(fd.z, fd.w, 0.f, 0.f);
+        }
+        // per-block lists of the window (ranked by lane: still back to front)
+        uint32_t nb[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t sub = ((b < 2 ? ent.x : ent.y) >> (16 * (b & 1))) & 0xffffu;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(sub != 0u);
+            if (sub != 0u) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                s_sub[b][rank] = lane | (sub << 8);
+            }
+            nb[b] = (uint32_t)__builtin_popcountll(m);
+        }
+        const uint32_t nmax = max(max(nb[0], nb[1]), max(nb[2], nb[3]));
+        const uint32_t my_n = blk == 0 ? nb[0] : blk == 1 ? nb[1] : blk == 2 ? nb[2] : nb[3];
+        {
+            float2* z = reinterpret_cast<float2*>(&s_acc[lane][0]);
+#pragma unroll
+            for (int k = 0; k < 5; k++) z[k] = make_float2(0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        for (uint32_t k0 = 0; k0 < nmax; k0 += 16u) {
+            // ---- lane (block, i): entry k0 + i of the block's list; an empty lane is an entry nobody blended ----
+            uint32_t sub = 0, e = 0;
+            if (k0 + li < my_n) {
+                const uint32_t q = s_sub[blk][k0 + li];
+                e = q & 63u;
+                sub = q >> 8;
+            }
+            const float4* e4 = reinterpret_cast<const float4*>(&s_ent[e]);
+            const float4 r0 = e4[0], r1 = e4[1], r2 = e4[2];
+            const float ca = r0.z, cb = r0.w, cc = r1.x, op = r1.y;
+            const float c0 = r1.z, c1 = r1.w, c2 = r2.x, c3 = r2.y;
+            // tables of the 4x4 block in the forward pass's operation order (forward.cu:341): d = centre - pixel,
+            // t1 = (a dx) dx, bdx = b dx, t2 = (c dy) dy, each product rounded on its own
+            f2 dxp[2], t1p[2], bdxp[2];
+            {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    dxp[h] = f2{r0.x - (fx0 + (float)(2 * h)), r0.x - (fx0 + (float)(2 * h + 1))};
+                    t1p[h] = (ca * dxp[h]) * dxp[h];
+                    bdxp[h] = cb * dxp[h];
+                }
+            }
+            f2 A0 = {0.f, 0.f}, A1 = A0, A2 = A0, A3 = A0, A6 = A0, A7 = A0, A8 = A0, A9 = A0, Sx = A0, Sy = A0;
+
+            // one block row (4 pixels = 2 packed pairs) per trip; not unrolled further: the four scans of a trip and
+            // the other waves of the SIMD cover the DPP latencies, and the body stays within 128 VGPRs
+#pragma unroll 1
+            for (int y = 0; y < 4; y++) {
+                float dy, t2;
+                {
+#pragma clang fp contract(off)
+                    dy = r0.y - (fy0 + (float)y);
+                    t2 = (cc * dy) * dy;
+                }
+                const uint32_t sub4 = sub >> (4 * y);      // this row's four pixel bits
+#pragma unroll
+                for (int h = 0; h < 2; h++) {               // pixels (2h, y), (2h + 1, y)
+                    PixPair* const ppq = pp + (2 * y + h);
+                    const PixPair P = *ppq;
+                    f2 mm;
+                    {
+#pragma clang fp contract(off)
+                        mm = bdxp[h] * dy;
+                    }
+                    const f2 power = __builtin_elementwise_fma(f2{-0.5f, -0.5f}, t1p[h] + t2, -mm);
+                    const f2 ex = power * 1.44269504088896341f;
+                    const int m0 = (int)(sub4 << (31 - 2 * h)) >> 31, m1 = (int)(sub4 << (30 - 2 * h)) >> 31;
+                    const f2 G = {and_mask(__builtin_amdgcn_exp2f(ex.x), m0), and_mask(__builtin_amdgcn_exp2f(ex.y), m1)};
+                    const f2 ar = op * G;
+                    const f2 al = {fminf(0.99f, ar.x), fminf(0.99f, ar.y)};   // 0 for a pair that did not blend
+                    const f2 om = 1.0f - al;
+                    const f2 inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                    const f2 Ti = P.Tc * f2{row_scan_mul(inv.x), row_scan_mul(inv.y)};      // T / (1 - alpha), backward.cu:534
+                    const f2 s = c0 * P.g0 + (c1 * P.g1 + (c2 * P.g2 + (c3 * P.gd + P.ga)));
+                    const f2 wgt = al * Ti;                                                 // dchannel_dcolor
+                    const f2 ws = wgt * s;
+                    const f2 incl = {row_scan_add(ws.x), row_scan_add(ws.y)};
+                    const f2 Ui = (incl - ws) + P.Uc;
+                    const f2 dLda = Ti * s - Ui * inv;                                      // backward.cu:547-578
+                    const f2 gdl = G * dLda;                                                // G dL/dalpha
+                    A0 += wgt * P.g0; A1 += wgt * P.g1; A2 += wgt * P.g2; A3 += wgt * P.gd;
+                    A9 += gdl;
+                    const f2 gdx = gdl * dxp[h], gdy = gdl * dy;
+                    Sx += gdx; Sy += gdy;
+                    A6 += gdx * dxp[h]; A7 += gdx * dy; A8 += gdy * dy;
+                    if (li == 15u) {                 // the row's last lane holds the totals: carries of the next chunk
+                        ppq->Tc = Ti;
+                        ppq->Uc = Ui + ws;
+                    }
+                }
+            }
+            {
+                // dL_dG G = opacity (G dL/dalpha): the common factor of the geometric terms (backward.cu:580-598)
+                const float sx = Sx.x + Sx.y, sy = Sy.x + Sy.y;
+                float v[kAcc];
+                v[0] = A0.x + A0.y; v[1] = A1.x + A1.y; v[2] = A2.x + A2.y; v[3] = A3.x + A3.y;
+                v[4] = -ddelx_dx * op * (ca * sx + cb * sy);
+                v[5] = -ddely_dy * op * (cc * sy + cb * sx);
+                v[6] = -0.5f * op * (A6.x + A6.y); v[7] = -0.5f * op * (A7.x + A7.y); v[8] = -0.5f * op * (A8.x + A8.y);
+                v[9] = A9.x + A9.y;
+                float2* dst = reinterpret_cast<float2*>(&s_acc[e][0]);
+                // an entry can sit in several rows of the wave (one per block it touches): the rows take turns
+#pragma unroll 1
+                for (uint32_t b = 0; b < 4u; b++) {
+                    if (blk == b && sub != 0u) {
+#pragma unroll
+                        for (int k = 0; k < 5; k++) {
+                            float2 t = dst[k];
+                            t.x += v[2 * k]; t.y += v[2 * k + 1];
+                            dst[k] = t;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lane = entry of the window: add its blocks' rows, store the (slot, strip) row once ----
+        if (lane < nwin) {
+            float v[kAcc];
+            {
+                const float2* src = reinterpret_cast<const float2*>(&s_acc[lane][0]);
+#pragma unroll
+                for (int k = 0; k < 5; k++) { const float2 t = src[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+            }
+            const size_t at = (size_t)ent.w * 4u + strip;     // (instance slot, strip)
+            flags[at] = 1;
+            float2* dst = reinterpret_cast<float2*>(rows4 + at * kAcc);
+            dst[0] = make_float2(v[0], v[1]);
+            dst[1] = make_float2(v[2], v[3]);
+            dst[2] = make_float2(v[4], v[5]);
+            dst[3] = make_float2(v[6], v[7]);
+            dst[4] = make_float2(v[8], v[9]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
+                            const GeomState& g, const float* bg, const float* alphas, const float* dL_dpix,
+                            const float* dL_dpix_depth, const float* dL_dalphas, float* rows4, uint8_t* flags,
+                            const uint4* clist, const uint32_t* strip_count)
+{
+    const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
+    hipLaunchKernelGGL(render_backward_block_kernel, dim3(tiles_total * 4u), dim3(64), 0, s, W, H, (uint32_t)tiles_x,
+                       (uint32_t)tiles_y, tiles_total, ranges, g.means2D, g.conic_opacity, g.rgbd, bg, alphas, dL_dpix,
+                       dL_dpix_depth, dL_dalphas, rows4, flags, clist, strip_count);
+}
+
+}  // namespace gd
