@@ -382,18 +382,20 @@ def main():
         avg_s = bwd_ms / bwd_n * 1e-3
         ach = flops_launch / avg_s / 1e12
         V_ = counts["views"]
-        # ballots 32 B + id / slot 8 B per list position, 44 B per (strip, entry) with a contribution gathered and 40 B
-        # stored (about 0.83 per position on this scene -> counted as 1), 20 B per pixel
-        alg_bytes = (40.0 + 84.0) * counts["num_rendered"] + 20.0 * V_ * args.res * args.res
+        # per (strip, entry) with a contribution (about 0.83 per list position on this scene -> counted as 1): the 16-byte
+        # compact-list record, 40 B of centre / conic / colour gathered, one 40-byte row stored; 20 B per pixel
+        alg_bytes = (16.0 + 40.0 + 40.0) * counts["num_rendered"] + 20.0 * V_ * args.res * args.res
         roofline = {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
-                    "kernel": "render_backward_strip_kernel", "avg_launch_us": avg_s * 1e6, "launches": bwd_n,
+                    "kernel": "render_backward_block_kernel", "avg_launch_us": avg_s * 1e6, "launches": bwd_n,
                     "flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": ("fp32 VALU roof: 157.3 TF/s (4 SIMD-32 per CU, v_fma_f32 every 2 cycles) == the f32-input "
-                             "MFMA rate on gfx950; no MFMA is issued.  FLOPs are the REFERENCE algorithm's (14 per pair "
-                             "its backward visits + 87 per contributing pair, backward.cu:517-598); this kernel visits "
-                             "only the contributing pairs (the forward pass hands it their ballots), so its executed "
-                             "work is smaller than the algorithmic count")}
+                    "note": ("fp32 VALU roof: 157.3 TF/s = the datasheet figure, which needs PACKED fp32 (v_pk_fma_f32) in "
+                             "every slot: measured on this chip a wave64 v_fma_f32 holds its SIMD ~4.5 cycles, a "
+                             "v_pk_fma_f32 ~5.3 (tools/probes/valu_rate_probe.hip), so plain-fp32 code tops out at "
+                             "~70 TF/s and fully packed code at ~120; no MFMA is issued.  FLOPs are the REFERENCE "
+                             "algorithm's (14 per pair its backward visits + 87 per contributing pair, "
+                             "backward.cu:517-598); this kernel evaluates only the (entry, 4x4 block) cells the "
+                             "forward pass's ballots name, two pixels per packed instruction")}
 
     # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/pmc_all.sh -> profiles/):
     # bench.py cannot read hardware counters itself, so `traffic` quotes the committed counter file
@@ -418,9 +420,9 @@ def main():
                         if v.get("SQ_INSTS_VALU") and v.get("SQ_BUSY_CYCLES"):
                             # SIMD-cycles of the launch: SQ_BUSY_CYCLES is summed over the 32 shader engines; 1024 SIMDs
                             simd_cycles = v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
-                            # lower bound of the VALU issue utilisation: every wave64 VALU instruction holds the SIMD-32
-                            # for >= 2 cycles (v_fma_f32; transcendental / DPP / 64-bit ops longer)
-                            roofline["valu_issue_util_min"] = 2.0 * v["SQ_INSTS_VALU"] / simd_cycles
+                            # VALU issue utilisation: a wave64 VALU instruction holds its SIMD for ~4.5 cycles (measured,
+                            # tools/probes/valu_rate_probe.hip; packed / transcendental ones longer)
+                            roofline["valu_issue_util_min"] = 4.5 * v["SQ_INSTS_VALU"] / simd_cycles
                             roofline["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
                             if v.get("SQ_ACTIVE_INST_VALU"):
                                 # SQ_ACTIVE_INST_* count quad-cycles per wave (MI355X_MICROARCH.md): average number of

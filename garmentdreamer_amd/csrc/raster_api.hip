@@ -135,6 +135,7 @@ BinningState carve_binning(char* chunk, size_t R, size_t* used)
     const size_t nblk = (R + kSortTile - 1) / kSortTile;
     obtain(p, b.sort_hist, ((size_t)1 << kSortHistBits) * (nblk + 1));
     obtain(p, b.clist, 4 * R);
+    obtain(p, b.rowpos, R);
     if (used) *used = (size_t)(p - chunk);
     return b;
 }
@@ -232,7 +233,8 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     const bool start_in_alt = (plan.passes & 1) != 0;
     { ProfScope ps(stream, GD_K_DUPLICATE);
     launch_duplicate(stream, (int)VP, P, radii, geom, start_in_alt ? bin.keys_alt : bin.keys,
-                     start_in_alt ? bin.point_list_alt : bin.point_list, bin.slot_vp, dm.tiles_x, dm.tiles_y); }
+                     start_in_alt ? bin.point_list_alt : bin.point_list, bin.slot_vp, nullptr, dm.tiles_x, dm.tiles_y); }
+    GD_HIP(hipMemsetAsync(bin.rowpos, 0, sizeof(uint4) * (size_t)num_rendered, stream));
     if (int e = check_debug(stream, debug, "duplicate")) return e;
     { ProfScope ps(stream, GD_K_SORT); launch_radix_sort(stream, bin, num_rendered, plan, start_in_alt); }
     if (int e = check_debug(stream, debug, "sort")) return e;
@@ -242,7 +244,7 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     { ProfScope ps(stream, GD_K_RENDER_FWD);
     launch_render_forward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
                           out_color, out_depth, out_alpha, img.n_contrib, img.pair_counts, bin.point_list_alt /* slot_of */,
-                          bin.clist, img.strip_count); }
+                          bin.clist, img.strip_count, reinterpret_cast<uint32_t*>(bin.rowpos)); }
     if (int e = check_debug(stream, debug, "render")) return e;
     GD_HIP(hipGetLastError());
     return (int)num_rendered;
@@ -273,22 +275,19 @@ int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const f
     ImageState img = carve_image(image_buffer, dm.tiles_total, dm.pixels_total, nullptr);
     if (radii == nullptr) radii = geom.radii;
 
-    // backward scratch: one 10-float row per (instance slot, strip) -- stored where the strip's ballot is non-zero,
-    // never accumulated -- and a flag byte per row
-    float* inst = nullptr;
-    uint8_t* flags = nullptr;
-    float* acc = nullptr;     // [VP][10]: the rows of each (view, Gaussian) added up (instance_sum_kernel)
+    // backward scratch: one 10-float row per entry of the forward pass's compact strip lists (same indexing as
+    // bin.clist, at most 4R), written once and never accumulated, and the rows of each (view, Gaussian) added up
+    float* rows = nullptr;
+    float* acc = nullptr;     // [VP][10] (instance_sum_kernel)
     {
         char* p = bwd_scratch;
-        obtain(p, inst, (size_t)R * 40);
-        obtain(p, flags, (size_t)R * 4);
+        obtain(p, rows, (size_t)R * 40);
         obtain(p, acc, VP * 10);
     }
-    GD_HIP(hipMemsetAsync(flags, 0, (size_t)R * 4, stream));
     if (R > 0) {
         { ProfScope ps(stream, GD_K_RENDER_BWD);
         launch_render_backward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, geom, background, alphas, dL_dpix,
-                               dL_dpix_depth, dL_dalphas, inst, flags, bin.clist, img.strip_count); }
+                               dL_dpix_depth, dL_dalphas, rows, bin.clist, img.strip_count); }
     }
     if (int e = check_debug(stream, debug, "render backward")) return e;
 
@@ -296,7 +295,7 @@ int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const f
     const size_t cov_stride = cov3D_precomp ? 0 : (size_t)P * 6;
     { ProfScope ps(stream, GD_K_PREPROCESS_BWD);
     launch_preprocess_backward(stream, P, D, M, V, means3D, radii, shs, geom.clamped, scales, rotations,
-                               scale_modifier, cov3D, cov_stride, viewmatrix, projmatrix, campos, vs, inst, flags,
+                               scale_modifier, cov3D, cov_stride, viewmatrix, projmatrix, campos, vs, rows, bin.rowpos,
                                geom.point_offsets, geom.tiles_touched, acc, colors_precomp != nullptr, dL_dmean2D, dL_dconic,
                                dL_dopacity, dL_dcolor, dL_ddepth,
                                dL_dmean3D, dL_dcov3D, shs ? dL_dsh : nullptr, scales ? dL_dscale : nullptr,
@@ -336,7 +335,7 @@ size_t gd_raster_binning_bytes(int64_t R)
 size_t gd_raster_backward_scratch_bytes(int P, int V, int64_t R)
 {
     const size_t r = (size_t)(R < 0 ? 0 : R);
-    return r * 40 * sizeof(float) + r * 4 + (size_t)P * (size_t)(V < 1 ? 1 : V) * 10 * sizeof(float) + 512;
+    return r * 40 * sizeof(float) + (size_t)P * (size_t)(V < 1 ? 1 : V) * 10 * sizeof(float) + 512;
 }
 
 int gd_raster_forward(void* stream, gd_alloc_fn geom_alloc, void* geom_user, gd_alloc_fn binning_alloc,

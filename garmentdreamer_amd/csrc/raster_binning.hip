@@ -83,7 +83,8 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
 __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, const int* __restrict__ radii,
                                                                 GeomState gs, uint64_t* __restrict__ keys_out,
                                                                 uint32_t* __restrict__ vals_out,
-                                                                uint32_t* __restrict__ slot_vp, uint32_t gx, uint32_t gy)
+                                                                uint32_t* __restrict__ slot_vp,
+                                                                uint4* __restrict__ rowpos, uint32_t gx, uint32_t gy)
 {
     __shared__ uint32_t wave_incl[kGaussBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, c
                 // the Gaussian of a slot is kept in slot_vp (tile_ranges_kernel turns point_list into Gaussian ids)
                 vals_out[off] = off;
                 if (slot_vp) slot_vp[off] = (uint32_t)vp;
+                if (rowpos) rowpos[off] = make_uint4(0, 0, 0, 0);   // "no strip blended this instance" until render_forward says otherwise
                 off++;
             }
     }
@@ -326,11 +328,11 @@ void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblock
 }
 
 void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* keys_out,
-                      uint32_t* vals_out, uint32_t* slot_vp, int tiles_x, int tiles_y)
+                      uint32_t* vals_out, uint32_t* slot_vp, uint4* rowpos, int tiles_x, int tiles_y)
 {
     const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
     hipLaunchKernelGGL(duplicate_kernel, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, keys_out, vals_out,
-                       slot_vp, (uint32_t)tiles_x, (uint32_t)tiles_y);
+                       slot_vp, rowpos, (uint32_t)tiles_x, (uint32_t)tiles_y);
 }
 
 // Sorts (keys, vals) of length R on the low plan.total_bits bits.  The unsorted input sits in

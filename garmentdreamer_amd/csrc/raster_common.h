@@ -54,6 +54,10 @@ struct BinningState {
                                // block + 4 * row + column), Gaussian (vp) id, instance slot}, in list order, only
                                // for entries with a non-zero ballot: the reverse pass never repeats the
                                // contribution test and never sees the pairs nobody blended
+    uint4* rowpos;             // [R] per instance slot, per strip: 1 + the clist index of the slot's entry in that strip's
+                               // list (0 = the strip blended nothing of it).  Zeroed by duplicate_kernel, written by
+                               // render_forward; the backward blend stores its row of sums at that index (coalesced,
+                               // in list order) and instance_sum_kernel finds a Gaussian's rows through it
 };
 
 GeomState carve_geom(char* chunk, size_t VP, size_t* used);
@@ -89,8 +93,8 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
                                 const float* shs, const uint8_t* clamped, const float* scales,
                                 const float* rotations, float scale_modifier, const float* cov3D,
                                 size_t cov3D_view_stride, const float* viewmatrix, const float* projmatrix,
-                                const float* campos, const ViewScalars& vs, const float* rows4 /*[R][4][10] by slot*/,
-                                const uint8_t* flags /*[R][4]*/, const uint32_t* point_offsets,
+                                const float* campos, const ViewScalars& vs, const float* rows /*[4R][10] by clist index*/,
+                                const uint4* rowpos /*[R]*/, const uint32_t* point_offsets,
                                 const uint32_t* tiles_touched, float* acc /*[VP][10] scratch, fully written*/,
                                 bool colors_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                                 float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
@@ -98,7 +102,7 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
 
 void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks);
 void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* keys_out,
-                      uint32_t* vals_out, uint32_t* slot_vp, int tiles_x, int tiles_y);
+                      uint32_t* vals_out, uint32_t* slot_vp, uint4* rowpos, int tiles_x, int tiles_y);
 void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan, bool start_in_alt);
 // identifyTileRanges + the sort's epilogue: slot_of[s] = point_list[s] (the slot), point_list[s] = its Gaussian id
 void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total,
@@ -108,12 +112,11 @@ void launch_blend_exp(hipStream_t s, const float* x, float* y, int n);   // y = 
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
                            float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts,
-                           const uint32_t* slot_of, uint4* clist, uint32_t* strip_count);
+                           const uint32_t* slot_of, uint4* clist, uint32_t* strip_count, uint32_t* rowpos);
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const GeomState& g, const float* bg, const float* alphas, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
-                            float* rows4 /*[R][4][10] by instance SLOT: one row per (slot, strip) with a listed entry*/,
-                            uint8_t* flags /*[R][4], zeroed: 1 where a row was stored*/, const uint4* clist,
+                            float* rows /*[4R][10]: the row of sums of clist entry i at index i*/, const uint4* clist,
                             const uint32_t* strip_count);
 
 

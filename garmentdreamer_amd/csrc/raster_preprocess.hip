@@ -326,21 +326,22 @@ __device__ void sh_backward(int g, size_t vp, int deg, int M, const float* __res
     dmean[2] = (-v[0] * v[2] * ddir[0] - v[1] * v[2] * ddir[1] + (sum2 - v[2] * v[2]) * ddir[2]) * invsum32;
 }
 
-// acc[vp][10] = sum of the rows rows4[slot][strip][10] the backward blend stored for the instance slots of (view,
-// Gaussian) vp -- one slot per tile the splat touches, contiguous: point_offsets[vp] - tiles_touched[vp] ... -- where
-// flags[slot][strip] is set, added in (slot, strip) order: deterministic, no atomics.  One thread per vp takes up to
+// acc[vp][10] = sum of the rows the backward blend stored for the instance slots of (view, Gaussian) vp -- one slot per
+// tile the splat touches, contiguous: point_offsets[vp] - tiles_touched[vp] ... ; rowpos[slot][strip] = 1 + the row's
+// index (0: that strip blended nothing of the instance): deterministic, no atomics.  A quad of lanes per vp takes up to
 // kOwnSlots slots itself; the few splats that cover more tiles are finished by the whole wave (64 slots per step +
 // a butterfly sum), so that one large splat does not hold 63 idle lanes for hundreds of dependent loads.
-constexpr uint32_t kOwnSlots = 8;
+constexpr uint32_t kOwnSlots = 32;   // per quad of lanes
 
-__device__ __forceinline__ void add_slot_rows(const float* __restrict__ rows4, const uint8_t* __restrict__ flags,
+__device__ __forceinline__ void add_slot_rows(const float* __restrict__ rows, const uint4* __restrict__ rowpos,
                                               uint32_t o, float a[10])
 {
-    const uint32_t f4 = *reinterpret_cast<const uint32_t*>(flags + 4 * (size_t)o);
+    const uint4 rp = rowpos[o];
+    const uint32_t at[4] = {rp.x, rp.y, rp.z, rp.w};
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        if (!((f4 >> (8 * w)) & 0xffu)) continue;
-        const float2* row = reinterpret_cast<const float2*>(rows4 + 10 * (4 * (size_t)o + w));
+        if (at[w] == 0u) continue;
+        const float2* row = reinterpret_cast<const float2*>(rows + 10 * (size_t)(at[w] - 1u));
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const float2 t = row[k];
@@ -352,10 +353,13 @@ __device__ __forceinline__ void add_slot_rows(const float* __restrict__ rows4, c
 __global__ __launch_bounds__(256) void instance_sum_kernel(uint32_t VP, const int* __restrict__ radii,
                                                            const uint32_t* __restrict__ point_offsets,
                                                            const uint32_t* __restrict__ tiles_touched,
-                                                           const float* __restrict__ rows4,
-                                                           const uint8_t* __restrict__ flags, float* __restrict__ acc)
+                                                           const float* __restrict__ rows,
+                                                           const uint4* __restrict__ rowpos, float* __restrict__ acc)
 {
-    const uint32_t vp = blockIdx.x * 256u + threadIdx.x;
+    // a QUAD of lanes per (view, Gaussian): lane q takes the slots first + q, first + q + 4, ... -- four independent
+    // chains of (rowpos -> row) gathers per splat instead of one -- and two DPP adds per value combine the quad
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t vp = gid >> 2, q = gid & 3u;
     const uint32_t lane = threadIdx.x & 63u;
     const bool vis = vp < VP && radii[vp] > 0;
     const uint32_t end = vis ? point_offsets[vp] : 0u;
@@ -363,13 +367,19 @@ __global__ __launch_bounds__(256) void instance_sum_kernel(uint32_t VP, const in
     const uint32_t first = end - n;
     float a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t own_end = first + min(n, kOwnSlots);
-    for (uint32_t o = first; o < own_end; o++) add_slot_rows(rows4, flags, o, a);
-    for (uint64_t big = __builtin_amdgcn_ballot_w64(n > kOwnSlots); big; big &= big - 1) {
+    for (uint32_t o = first + q; o < own_end; o += 4u) add_slot_rows(rows, rowpos, o, a);
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        a[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[k]), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+        a[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[k]), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    }
+    // the few splats that cover more tiles are finished by the whole wave (64 slots per step + a butterfly sum)
+    for (uint64_t big = __builtin_amdgcn_ballot_w64(n > kOwnSlots && q == 0u); big; big &= big - 1) {
         const int src = (int)__builtin_ctzll(big);
         const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)own_end, src);
         const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)end, src);
         float part[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t o = f + lane; o < e; o += 64u) add_slot_rows(rows4, flags, o, part);
+        for (uint32_t o = f + lane; o < e; o += 64u) add_slot_rows(rows, rowpos, o, part);
 #pragma unroll
         for (int k = 0; k < 10; k++) {
 #pragma unroll
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(256) void instance_sum_kernel(uint32_t VP, const in
             if ((int)lane == src) a[k] += part[k];
         }
     }
-    if (vp < VP) {
+    if (vp < VP && q == 0u) {
         float2* dst = reinterpret_cast<float2*>(acc + 10 * (size_t)vp);
 #pragma unroll
         for (int k = 0; k < 5; k++) dst[k] = make_float2(a[2 * k], a[2 * k + 1]);
@@ -596,7 +606,7 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
                                 const float* shs, const uint8_t* clamped, const float* scales,
                                 const float* rotations, float scale_modifier, const float* cov3D,
                                 size_t cov3D_view_stride, const float* viewmatrix, const float* projmatrix,
-                                const float* campos, const ViewScalars& vs, const float* rows4, const uint8_t* flags,
+                                const float* campos, const ViewScalars& vs, const float* rows, const uint4* rowpos,
                                 const uint32_t* point_offsets, const uint32_t* tiles_touched, float* acc,
                                 bool colors_precomp,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
@@ -604,8 +614,8 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
                                 float* dL_dscale, float* dL_drot, float* /*unused*/)
 {
     const uint32_t VP = (uint32_t)V * (uint32_t)P;
-    hipLaunchKernelGGL(instance_sum_kernel, dim3((VP + 255u) / 256u), dim3(256), 0, s, VP, radii, point_offsets,
-                       tiles_touched, rows4, flags, acc);
+    hipLaunchKernelGGL(instance_sum_kernel, dim3((4u * VP + 255u) / 256u), dim3(256), 0, s, VP, radii, point_offsets,
+                       tiles_touched, rows, rowpos, acc);
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((P + kGaussBlock - 1) / kGaussBlock), dim3(kGaussBlock), 0,
                        s, P, D, M, means3D, radii, shs, clamped, scales, rotations, scale_modifier, cov3D,
                        cov3D_view_stride, viewmatrix, projmatrix, campos, vs, acc, colors_precomp, dL_dmean2D,

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     uint32_t* __restrict__ n_contrib, uint2* __restrict__ pair_counts, const uint32_t* __restrict__ slot_of,
-    uint4* __restrict__ clist, uint32_t* __restrict__ strip_count)
+    uint4* __restrict__ clist, uint32_t* __restrict__ strip_count, uint32_t* __restrict__ rowpos)
 {
     // every blend operation is rounded on its own, like the oracle's (-ffp-contract=off): images match it bit for bit
 #pragma clang fp contract(off)
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     uint32_t contributor = (uint32_t)total, last_contributor = 0, blended = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f;
     // compact list of this wave's strip: region [4 range.x + wave * total, + total) of clist, filled in list order
-    uint4* const my_list = clist + ((size_t)range.x * 4u + (size_t)wave * (uint32_t)total);
+    const uint32_t my_base = range.x * 4u + wave * (uint32_t)total;
+    uint4* const my_list = clist + my_base;
     uint32_t n_listed = 0;
 
     for (int i = 0; i < rounds; i++, toDo -= kTilePix) {
@@ -282,7 +283,9 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
             if (nz) {
                 const uint32_t pos = range.x + cbase + (uint32_t)c + lane;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
-                my_list[n_listed + rank] = make_uint4(wb_lo, wb_hi, point_list[pos], slot_of[pos]);
+                const uint32_t slot = slot_of[pos];
+                my_list[n_listed + rank] = make_uint4(wb_lo, wb_hi, point_list[pos], slot);
+                rowpos[(size_t)slot * 4u + wave] = my_base + n_listed + rank + 1u;   // where the backward pass puts the row
             }
             n_listed += (uint32_t)__builtin_popcountll(nzm);
         }
@@ -316,12 +319,12 @@ void launch_blend_exp(hipStream_t s, const float* x, float* y, int n)
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
                            float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts,
-                           const uint32_t* slot_of, uint4* clist, uint32_t* strip_count)
+                           const uint32_t* slot_of, uint4* clist, uint32_t* strip_count, uint32_t* rowpos)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
     hipLaunchKernelGGL(render_forward_kernel, dim3(tiles_total), dim3(kTilePix), 0, s, W, H, (uint32_t)tiles_x,
                        (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D, g.conic_opacity, g.rgbd, bg,
-                       out_color, out_depth, out_alpha, n_contrib, pair_counts, slot_of, clist, strip_count);
+                       out_color, out_depth, out_alpha, n_contrib, pair_counts, slot_of, clist, strip_count, rowpos);
 }
 
 }  // namespace gd

@@ -26,13 +26,19 @@
 //     across the 16 lanes of a row as four DPP row_shr steps each;
 //   * pixel data (dL/dpixel, and the T / U carries between chunks of 16 entries) are broadcast LDS reads (one
 //     address per row), the only LDS traffic of the inner loop;
-//   * per window of 64 strip entries the (entry, block) rows are added up in an LDS table [entry][10] -- the four
-//     rows of the wave take turns (plain read-add-write, one row of lanes at a time: ds_add_f32 costs far more) -- and
-//     stored ONCE as rows4[slot][strip][10] (+ flag byte); instance_sum_kernel adds the rows of a Gaussian.
+//   * per window of 64 strip entries the (entry, block) rows are added up in an LDS table [entry][2][10] (blocks 0/1
+//     and 2/3 own a half each, so two plain read-add-write turns per chunk suffice: ds_add_f32 costs far more) and
+//     stored ONCE, in list order (coalesced: scattered 40-byte rows by instance slot cost 90 us per launch);
+//     instance_sum_kernel finds the rows of a Gaussian through rowpos[slot][strip], which the forward pass wrote.
 //     No atomics, no workgroup barriers; gradients are bitwise reproducible.
-//   * 8.5 KB of LDS and <= 128 VGPRs per wave: four waves per SIMD (a lone wave issues a VALU instruction every ~9
+//   * 10 KB of LDS and <= 128 VGPRs per wave: four waves per SIMD (a lone wave issues a VALU instruction every ~9
 //     cycles, two every 5.8, four every 5.0).
 #include "raster_common.h"
+
+#ifndef GD_BWD_ABLATE
+#define GD_BWD_ABLATE 0   // tools/raster_ab.sh builds only (wrong results): 1 = no chunk loop, 2 = no pixel loop, 3 = no row adds,
+                          // 4 = 1 + no gathers, 5 = 1 + no row stores, 6 = 4 + 5
+#endif
 
 namespace gd {
 
@@ -43,15 +49,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kAcc = 10;   // colour rgb, depth, mean2D xy, conic x/y/w, opacity
 constexpr int kWin = 64;   // strip entries per window (one per lane when the window is loaded)
 
-struct PixPair {           // per (block, pixel pair): 64 B, read as broadcast by the 16 lanes of the block's row
+struct PixPair {           // per (block, pixel pair): 48 B, read as broadcast by the 16 lanes of the block's row
     f2 g0, g1, g2, gd;     // dL/dC r, g, b and dL/ddepth of the two pixels
-    f2 ga, pad;            // dL/dalpha_image
     f2 Tc, Uc;             // carries of the two scans (start: T_final and the background term)
-};
-struct EntryRow {          // one strip entry of the current window: 48 B
-    float x, y, a, b;      // centre (pixels), conic xx, xy
-    float c, o, f0, f1;    // conic yy, opacity, colour r, g
-    float f2_, f3, pad0, pad1;   // colour b, depth
 };
 
 // inclusive prefix sum over the 16 lanes of a row (lane 0 of the row first); zero fill for the shifted-in lanes
@@ -82,13 +82,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
     const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd,
     const float* __restrict__ bg_color, const float* __restrict__ alphas, const float* __restrict__ dL_dpixels,
-    const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ rows4,
-    uint8_t* __restrict__ flags, const uint4* __restrict__ clist, const uint32_t* __restrict__ strip_count)
+    const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ rows,
+    const uint4* __restrict__ clist, const uint32_t* __restrict__ strip_count)
 {
-    __shared__ PixPair s_px[4][8];              //  2 KB
-    __shared__ EntryRow s_ent[kWin];            //  3 KB
-    __shared__ uint32_t s_sub[4][kWin];         //  1 KB  per block: (entry index in the window) | (16-bit pixel mask << 8)
-    __shared__ float s_acc[kWin][kAcc];         //  2.5 KB the ten sums of each entry of the window, over its blocks
+    __shared__ PixPair s_px[4][8];              //  1.5 KB
+    __shared__ f2 s_ga[4][8];                   //  256 B  dL/dalpha_image of the pixel pairs
+    __shared__ float s_ent[kWin][12];           //  3 KB   x, y, conic a b c, opacity, colour r g b, depth, ballot lo, hi
+    __shared__ uint8_t s_sub[4][kWin];          //  256 B  per block: its entries' indices in the window, back to front
+    __shared__ float s_acc[kWin][2][kAcc];      //  5 KB   the ten sums of each entry of the window: blocks 0/1 | 2/3
 
     // workgroup u runs on XCD u % 8: the four strips of a tile and neighbouring tiles share an XCD (and its L2)
     const uint32_t nblk = tiles_total * 4u;
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint32_t blk = lane >> 4, li = lane & 15u;
     const size_t HW = (size_t)H * W;
     const uint2 range = ranges[tile];
-    const uint4* const my_list = clist + ((size_t)range.x * 4u + (size_t)strip * (range.y - range.x));
+    const size_t my_base = (size_t)range.x * 4u + (size_t)strip * (range.y - range.x);
+    const uint4* const my_list = clist + my_base;
+    float* const my_rows = rows + my_base * kAcc;     // row of sums of list entry i at my_rows[i]: coalesced stores
 
     // ---- lane = pixel (16 * block + 4 * y + x): gradients of the image, T_final, the background term ----
     {
@@ -123,27 +126,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         const float bgT = T_final * (bg_color[0] * d0 + bg_color[1] * d1 + bg_color[2] * d2);
         float* q = reinterpret_cast<float*>(&s_px[blk][li >> 1]) + (li & 1u);
-        q[0] = d0; q[2] = d1; q[4] = d2; q[6] = dd; q[8] = da; q[12] = T_final; q[14] = bgT;
+        q[0] = d0; q[2] = d1; q[4] = d2; q[6] = dd; q[8] = T_final; q[10] = bgT;
+        reinterpret_cast<float*>(&s_ga[blk][li >> 1])[li & 1u] = da;
     }
     const float fx0 = (float)(tx_ * kTile + 4u * blk), fy0 = (float)(ty_ * kTile + 4u * strip);   // the row's block origin
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     PixPair* const pp = &s_px[blk][0];
+    const f2* const pga = &s_ga[blk][0];
 
-    // ---- windows of 64 strip entries, from the back of the list ----
+    // ---- windows of 64 strip entries, from the back of the list; the next window's entries are in flight while the
+    //      current one is processed ----
+    auto load_entries = [&](uint32_t w0) {
+        uint4 e = make_uint4(0, 0, 0, 0);
+        if (w0 + lane < n_listed) e = my_list[n_listed - 1u - (w0 + lane)];     // lane 0 = the backmost entry of the window
+        return e;
+    };
+    uint4 ent_next = load_entries(0);
     for (uint32_t w0 = 0; w0 < n_listed; w0 += kWin) {
-        const bool have = w0 + lane < n_listed;                    // lane 0 = the backmost entry of the window
-        uint4 ent = make_uint4(0, 0, 0, 0);
-        if (have) ent = my_list[n_listed - 1u - (w0 + lane)];
+        const uint4 ent = ent_next;
+        const bool have = w0 + lane < n_listed;
         const uint32_t nwin = min((uint32_t)kWin, n_listed - w0);
         if (have) {
-            const float2 xy = means2D[ent.z];
-            const float4 co = conic_opacity[ent.z];
-            const float4 fd = rgbd[ent.z];
-            float4* e4 = reinterpret_cast<float4*>(&s_ent[lane]);
-            e4[0] = make_float4(xy.x, xy.y, co.x, co.y);
-            e4[1] = make_float4(co.z, co.w, fd.x, fd.y);
-            e4[2] = make_float4(fd.z, fd.w, 0.f, 0.f);
+            const bool gather = !(GD_BWD_ABLATE == 4 || GD_BWD_ABLATE == 6);
+            const float2 xy = gather ? means2D[ent.z] : make_float2(1.f, 2.f);
+            const float4 co = gather ? conic_opacity[ent.z] : make_float4(1.f, 0.f, 1.f, 0.5f);
+            const float4 fd = gather ? rgbd[ent.z] : make_float4(1.f, 0.f, 1.f, 0.5f);
+            float* er = &s_ent[lane][0];
+            reinterpret_cast<float4*>(er)[0] = make_float4(xy.x, xy.y, co.x, co.y);
+            reinterpret_cast<float4*>(er)[1] = make_float4(co.z, co.w, fd.x, fd.y);
+            reinterpret_cast<float4*>(er)[2] = make_float4(fd.z, fd.w, __uint_as_float(ent.x), __uint_as_float(ent.y));
         }
+        ent_next = load_entries(w0 + kWin);
         // per-block lists of the window (ranked by lane: still back to front)
         uint32_t nb[4];
 #pragma unroll
@@ -152,29 +165,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint64_t m = __builtin_amdgcn_ballot_w64(sub != 0u);
             if (sub != 0u) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                s_sub[b][rank] = lane | (sub << 8);
+                s_sub[b][rank] = (uint8_t)lane;
             }
             nb[b] = (uint32_t)__builtin_popcountll(m);
         }
         const uint32_t nmax = max(max(nb[0], nb[1]), max(nb[2], nb[3]));
         const uint32_t my_n = blk == 0 ? nb[0] : blk == 1 ? nb[1] : blk == 2 ? nb[2] : nb[3];
         {
-            float2* z = reinterpret_cast<float2*>(&s_acc[lane][0]);
+            float2* z = reinterpret_cast<float2*>(&s_acc[lane][0][0]);
 #pragma unroll
-            for (int k = 0; k < 5; k++) z[k] = make_float2(0.f, 0.f);
+            for (int k = 0; k < 10; k++) z[k] = make_float2(0.f, 0.f);
         }
         __builtin_amdgcn_wave_barrier();
 
-        for (uint32_t k0 = 0; k0 < nmax; k0 += 16u) {
+        uint32_t e_next = (li < my_n) ? s_sub[blk][li] : 0xffu;
+        for (uint32_t k0 = 0; k0 < ((GD_BWD_ABLATE == 1 || GD_BWD_ABLATE >= 4) ? 0u : nmax); k0 += 16u) {
             // ---- lane (block, i): entry k0 + i of the block's list; an empty lane is an entry nobody blended ----
-            uint32_t sub = 0, e = 0;
-            if (k0 + li < my_n) {
-                const uint32_t q = s_sub[blk][k0 + li];
-                e = q & 63u;
-                sub = q >> 8;
-            }
-            const float4* e4 = reinterpret_cast<const float4*>(&s_ent[e]);
-            const float4 r0 = e4[0], r1 = e4[1], r2 = e4[2];
+            const uint32_t e = e_next & 63u;
+            const bool filled = e_next != 0xffu;
+            const float* er = &s_ent[e][0];
+            const float4 r0 = reinterpret_cast<const float4*>(er)[0], r1 = reinterpret_cast<const float4*>(er)[1],
+                         r2 = reinterpret_cast<const float4*>(er)[2];
+            e_next = (k0 + 16u + li < my_n) ? s_sub[blk][k0 + 16u + li] : 0xffu;
+            const uint32_t bal = __float_as_uint(blk < 2u ? r2.z : r2.w);
+            const uint32_t sub = filled ? (bal >> (16u * (blk & 1u))) & 0xffffu : 0u;
             const float ca = r0.z, cb = r0.w, cc = r1.x, op = r1.y;
             const float c0 = r1.z, c1 = r1.w, c2 = r2.x, c3 = r2.y;
             // tables of the 4x4 block in the forward pass's operation order (forward.cu:341): d = centre - pixel,
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             // one block row (4 pixels = 2 packed pairs) per trip; not unrolled further: the four scans of a trip and
             // the other waves of the SIMD cover the DPP latencies, and the body stays within 128 VGPRs
 #pragma unroll 1
-            for (int y = 0; y < 4; y++) {
+            for (int y = 0; y < (GD_BWD_ABLATE == 2 ? 0 : 4); y++) {
                 float dy, t2;
                 {
 #pragma clang fp contract(off)
@@ -206,6 +220,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 for (int h = 0; h < 2; h++) {               // pixels (2h, y), (2h + 1, y)
                     PixPair* const ppq = pp + (2 * y + h);
                     const PixPair P = *ppq;
+                    const f2 Pga = pga[2 * y + h];
                     f2 mm;
                     {
 #pragma clang fp contract(off)
@@ -213,14 +228,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     }
                     const f2 power = __builtin_elementwise_fma(f2{-0.5f, -0.5f}, t1p[h] + t2, -mm);
                     const f2 ex = power * 1.44269504088896341f;
-                    const int m0 = (int)(sub4 << (31 - 2 * h)) >> 31, m1 = (int)(sub4 << (30 - 2 * h)) >> 31;
+                    int m0, m1;     // all ones where the pixel blended the entry (v_bfe_i32: one instruction per pixel)
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(sub4), "n"(2 * h));
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(sub4), "n"(2 * h + 1));
                     const f2 G = {and_mask(__builtin_amdgcn_exp2f(ex.x), m0), and_mask(__builtin_amdgcn_exp2f(ex.y), m1)};
                     const f2 ar = op * G;
                     const f2 al = {fminf(0.99f, ar.x), fminf(0.99f, ar.y)};   // 0 for a pair that did not blend
                     const f2 om = 1.0f - al;
                     const f2 inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
                     const f2 Ti = P.Tc * f2{row_scan_mul(inv.x), row_scan_mul(inv.y)};      // T / (1 - alpha), backward.cu:534
-                    const f2 s = c0 * P.g0 + (c1 * P.g1 + (c2 * P.g2 + (c3 * P.gd + P.ga)));
+                    const f2 s = c0 * P.g0 + (c1 * P.g1 + (c2 * P.g2 + (c3 * P.gd + Pga)));
                     const f2 wgt = al * Ti;                                                 // dchannel_dcolor
                     const f2 ws = wgt * s;
                     const f2 incl = {row_scan_add(ws.x), row_scan_add(ws.y)};
@@ -247,11 +264,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 v[5] = -ddely_dy * op * (cc * sy + cb * sx);
                 v[6] = -0.5f * op * (A6.x + A6.y); v[7] = -0.5f * op * (A7.x + A7.y); v[8] = -0.5f * op * (A8.x + A8.y);
                 v[9] = A9.x + A9.y;
-                float2* dst = reinterpret_cast<float2*>(&s_acc[e][0]);
-                // an entry can sit in several rows of the wave (one per block it touches): the rows take turns
+                // an entry can sit in several rows of the wave (one per block it touches).  Rows 0/1 add into half 0 of
+                // the entry's table row, rows 2/3 into half 1, even rows first: two plain read-add-write turns
+                float2* dst = reinterpret_cast<float2*>(&s_acc[e][blk >> 1][0]);
 #pragma unroll 1
-                for (uint32_t b = 0; b < 4u; b++) {
-                    if (blk == b && sub != 0u) {
+                for (uint32_t turn = 0; turn < (GD_BWD_ABLATE == 3 ? 0u : 2u); turn++) {
+                    if ((blk & 1u) == turn && sub != 0u) {
 #pragma unroll
                         for (int k = 0; k < 5; k++) {
                             float2 t = dst[k];
@@ -264,17 +282,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- lane = entry of the window: add its blocks' rows, store the (slot, strip) row once ----
-        if (lane < nwin) {
+        // ---- lane = entry of the window: add the two halves, store the entry's row once ----
+        if (lane < nwin && (!(GD_BWD_ABLATE == 5 || GD_BWD_ABLATE == 6) || W < 0)) {
             float v[kAcc];
             {
-                const float2* src = reinterpret_cast<const float2*>(&s_acc[lane][0]);
+                const float2* src = reinterpret_cast<const float2*>(&s_acc[lane][0][0]);
 #pragma unroll
-                for (int k = 0; k < 5; k++) { const float2 t = src[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+                for (int k = 0; k < 5; k++) { const float2 t = src[k], u = src[k + 5]; v[2 * k] = t.x + u.x; v[2 * k + 1] = t.y + u.y; }
             }
-            const size_t at = (size_t)ent.w * 4u + strip;     // (instance slot, strip)
-            flags[at] = 1;
-            float2* dst = reinterpret_cast<float2*>(rows4 + at * kAcc);
+            float2* dst = reinterpret_cast<float2*>(my_rows + (size_t)(n_listed - 1u - (w0 + lane)) * kAcc);
             dst[0] = make_float2(v[0], v[1]);
             dst[1] = make_float2(v[2], v[3]);
             dst[2] = make_float2(v[4], v[5]);
@@ -289,13 +305,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const GeomState& g, const float* bg, const float* alphas, const float* dL_dpix,
-                            const float* dL_dpix_depth, const float* dL_dalphas, float* rows4, uint8_t* flags,
-                            const uint4* clist, const uint32_t* strip_count)
+                            const float* dL_dpix_depth, const float* dL_dalphas, float* rows, const uint4* clist,
+                            const uint32_t* strip_count)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
     hipLaunchKernelGGL(render_backward_block_kernel, dim3(tiles_total * 4u), dim3(64), 0, s, W, H, (uint32_t)tiles_x,
                        (uint32_t)tiles_y, tiles_total, ranges, g.means2D, g.conic_opacity, g.rgbd, bg, alphas, dL_dpix,
-                       dL_dpix_depth, dL_dalphas, rows4, flags, clist, strip_count);
+                       dL_dpix_depth, dL_dalphas, rows, clist, strip_count);
 }
 
 }  // namespace gd

@@ -17,7 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("out")
-    ap.add_argument("--marker", default="render_backward_strip_kernel")
+    ap.add_argument("--marker", default="render_backward_block_kernel")
     ap.add_argument("--skip", type=int, default=2)
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))

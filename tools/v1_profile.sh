@@ -20,7 +20,7 @@ python - "$tr" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "render_backward_strip_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "render_backward_block_kernel" in r["Kernel_Name"]]
 rows = rows[marks[3]:marks[-1]]; steps = len(marks) - 4
 for pat in ("conv3x3_nhwc_bf16_kernel<128, 128", "gn_stats_kernel", "Cijk"):
     agg = collections.OrderedDict()
