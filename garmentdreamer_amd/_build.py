@@ -28,6 +28,7 @@ RASTER_SOURCES = [
     ("raster_render_bwd.hip", ["-fno-slp-vectorize"]),
     ("raster_api.hip", []),
     ("raster_scene.hip", ["-ffp-contract=off"]),
+    ("raster_densify.hip", ["-ffp-contract=off"]),
 ]
 
 

@@ -73,6 +73,11 @@ SCENE_SIGNATURES = {
     "gd_scene_densify_stats": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "gd_scene_activate_forward": (_i, [_vp, _i, _i] + [_vp] * 9),
     "gd_scene_activate_backward": (_i, [_vp, _i, _i] + [_vp] * 12),
+    "gd_scene_densify_scratch_bytes": (C.c_size_t, [_i]),
+    "gd_scene_densify_plan": (_i, [_vp, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp,
+                                   C.POINTER(C.c_uint32)]),
+    "gd_scene_densify_apply": (_i, [_vp, _i, _i, C.POINTER(C.c_int), _i, _i, _i, C.POINTER(C.c_uint32)] + [_vp] * 8),
+    "gd_scene_densify_last_error": (C.c_char_p, []),
     "gd_scene_last_error": (C.c_char_p, []),
 }
 
@@ -117,9 +122,9 @@ def check(ret: int, what: str) -> int:
     return ret
 
 
-def check_scene(ret: int, what: str) -> int:
+def check_scene(ret: int, what: str, err: str = "gd_scene_last_error") -> int:
     if ret < 0:
-        raise RuntimeError(f"{what} failed ({ret}): {lib().gd_scene_last_error().decode('utf-8', 'replace')}")
+        raise RuntimeError(f"{what} failed ({ret}): {getattr(lib(), err)().decode('utf-8', 'replace')}")
     return ret
 
 

@@ -158,6 +158,7 @@ class GaussianModel(GaussianParams):
         self.optimizer_step = 0
         self.lrs: Dict[str, float] = {}
         self._flat = self._grad = self._exp_avg = self._exp_avg_sq = None
+        self.generation = -1          # bumped whenever the parameter objects are replaced (_adopt)
         self.xyz_gradient_accum = self.denom = self.max_radii2D = None
         self.xyz_scheduler_args = None
 
@@ -185,19 +186,28 @@ class GaussianModel(GaussianParams):
     def _pack(self, tensors: Dict[str, torch.Tensor], exp_avg=None, exp_avg_sq=None):
         """(Re)build the flat buffers from per-group [P, ...] tensors (+ optional Adam moments)."""
         P = tensors["xyz"].shape[0]
+        dev = self.device
+        flat = torch.cat([tensors[n].reshape(-1).to(dev, torch.float32) for n in GROUPS])
+        m = torch.zeros_like(flat) if exp_avg is None else torch.cat([exp_avg[n].reshape(-1) for n in GROUPS])
+        v = torch.zeros_like(flat) if exp_avg_sq is None else torch.cat([exp_avg_sq[n].reshape(-1) for n in GROUPS])
+        self._adopt(flat, m, v, P)
+
+    def _adopt(self, flat: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, P: int):
+        """Install group-major flat buffers of P points: parameters become views of ``flat``, their ``.grad`` views of
+        the (zeroed) gradient bucket.  Every parameter OBJECT is new afterwards: ``generation`` counts these events so
+        that a caller holding ``gaussians._xyz`` (or a P-sized buffer) across steps can notice."""
         w = self._widths()
         self._ends = np.cumsum([P * k for k in w]).astype(np.int64)
         dev = self.device
-        flat = torch.cat([tensors[n].reshape(-1).to(dev, torch.float32) for n in GROUPS])
+        assert flat.numel() == int(self._ends[-1])
         self._flat = flat
         # [parameter gradients | viewspace gradient summed over views (3 P)]: ONE buffer, so the view-sharded
         # all-reduce (dist.all_reduce_mean_) sends it in place -- no staging copy
         self._bucket = torch.zeros(flat.numel() + 3 * P, dtype=torch.float32, device=dev)
         self._grad = self._bucket[:flat.numel()]
         self.viewspace_grad = self._bucket[flat.numel():].view(P, 3)
-        self._exp_avg = torch.zeros_like(flat) if exp_avg is None else torch.cat([exp_avg[n].reshape(-1) for n in GROUPS])
-        self._exp_avg_sq = torch.zeros_like(flat) if exp_avg_sq is None else \
-            torch.cat([exp_avg_sq[n].reshape(-1) for n in GROUPS])
+        self._exp_avg, self._exp_avg_sq = exp_avg, exp_avg_sq
+        self.generation = getattr(self, "generation", -1) + 1
         M = (self.max_sh_degree + 1) ** 2
         shapes = {"xyz": (P, 3), "f_dc": (P, 1, 3), "f_rest": (P, M - 1, 3), "opacity": (P, 1), "scaling": (P, 3),
                   "rotation": (P, 4)}
@@ -374,7 +384,10 @@ class GaussianModel(GaussianParams):
                                    self._features_rest[sel].detach(), self._opacity[sel].detach(),
                                    self._scaling[sel].detach(), self._rotation[sel].detach())
 
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+    def densify_and_prune_torch(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """The reference's sequence op for op (clone, split, prune through torch indexing; :398-413).  Kept as the
+        statement the native path is tested against (tests/test_scene_gpu.py); the training loop calls
+        ``densify_and_prune``."""
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
         self.densify_and_clone(grads, max_grad, extent)
@@ -385,6 +398,47 @@ class GaussianModel(GaussianParams):
             big_points_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
             prune_mask = torch.logical_or(torch.logical_or(prune_mask, big_points_vs), big_points_ws)
         self.prune_points(prune_mask)
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """``densify_and_prune`` (:398-413) as two HIP passes over the flat buffers (gd_scene_densify_plan / _apply,
+        csrc/raster_densify.hip): classification + stream offsets, one host read of the four totals, the seeded normal
+        samples of the split (``torch.randn`` = the stream ``torch.normal(mean, std)`` consumes), and one sweep that
+        writes parameters and Adam moments of the new point set in the reference's order."""
+        if not self._flat.is_cuda:
+            raise RuntimeError("GaussianModel.densify_and_prune: the HIP kernels have no CPU path")
+        P = self._xyz.shape[0]
+        dev = self._flat.device
+        L = _native.lib()
+        scratch = torch.empty(L.gd_scene_densify_scratch_bytes(P), dtype=torch.uint8, device=dev)
+        totals = (C.c_uint32 * 4)()
+        dense = float(np.float32(self.percent_dense * extent))
+        max_ws = float(np.float32(0.1 * extent)) if max_screen_size else -1.0
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _native.check_scene(L.gd_scene_densify_plan(
+                stream, P, self.xyz_gradient_accum.data_ptr(), self.denom.data_ptr(), self._opacity.data_ptr(),
+                self._scaling.data_ptr(), float(max_grad), dense, float(min_opacity), max_ws, scratch.data_ptr(), totals),
+                "gd_scene_densify_plan", "gd_scene_densify_last_error")
+            n_orig, n_clone, n_split, n_child = (int(t) for t in totals)
+            newP = n_orig + n_clone + 2 * n_child
+            z = None
+            if n_split > 0:
+                z = torch.randn((2 * n_split, 3), device=dev, dtype=torch.float32, generator=generator)
+            w = self._widths()
+            per_point = int(sum(w))
+            nflat = torch.empty(per_point * newP, dtype=torch.float32, device=dev)
+            nm = torch.empty_like(nflat)
+            nv = torch.empty_like(nflat)
+            widths = (C.c_int * len(w))(*w)
+            _native.check_scene(L.gd_scene_densify_apply(
+                stream, P, len(w), widths, GROUPS.index("xyz"), GROUPS.index("scaling"), GROUPS.index("rotation"), totals,
+                scratch.data_ptr(), z.data_ptr() if z is not None else None, self._flat.data_ptr(),
+                self._exp_avg.data_ptr(), self._exp_avg_sq.data_ptr(), nflat.data_ptr(), nm.data_ptr(), nv.data_ptr()),
+                "gd_scene_densify_apply", "gd_scene_densify_last_error")
+        self._adopt(nflat, nm, nv, newP)
+        self.xyz_gradient_accum = torch.zeros((newP, 1), device=dev)
+        self.denom = torch.zeros((newP, 1), device=dev)
+        self.max_radii2D = torch.zeros((newP,), device=dev)
 
     def reset_opacity(self):
         """:227-230: clamp opacities to <= 0.01 and zero the opacity group's Adam moments."""

@@ -77,9 +77,11 @@ def lib():
     return _lib
 
 
-def _check(ret, what):
+def _check(ret, what, err="gd_nn_last_error"):
+    """``err`` names the error-text getter of the translation unit ``what`` lives in (each csrc file keeps its own
+    thread-local buffer: gd_nn_last_error is the GroupNorm file's)."""
     if ret < 0:
-        raise RuntimeError(f"{what} failed ({ret}): {lib().gd_nn_last_error().decode()}")
+        raise RuntimeError(f"{what} failed ({ret}): {getattr(lib(), err)().decode()}")
 
 
 _gn_ws_cache = {}
@@ -771,7 +773,7 @@ class _VaePrologue(torch.autograd.Function):
         L = lib()
         with torch.cuda.device(x.device):
             _check(L.gd_nn_vae_prologue_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(),
-                                                N, H, W, OH, OW), "gd_nn_vae_prologue_forward")
+                                                N, H, W, OH, OW), "gd_nn_vae_prologue_forward", "gd_nn_prologue_last_error")
         ctx.shape = (N, H, W, OH, OW)
         return y
 
@@ -783,8 +785,10 @@ class _VaePrologue(torch.autograd.Function):
         # the first convolution's input gradient comes on 4 zero-padded channels (a [:, :3] slice of an NHWC tensor):
         # read it in place, pixel stride CG
         base = dy._base if dy._base is not None and dy.storage_offset() == 0 else None
-        if (base is not None and base.dim() == 4 and base.shape[0] == N and base.shape[2:] == dy.shape[2:]
-                and base.is_contiguous(memory_format=torch.channels_last) and dy.stride() == base.stride()):
+        if (base is not None and base.dtype == torch.bfloat16 and base.dim() == 4 and dy.shape[1] == 3
+                and base.shape[0] == N and base.shape[1] >= 3 and base.shape[2:] == dy.shape[2:]
+                and base.is_contiguous(memory_format=torch.channels_last) and dy.stride() == base.stride()
+                and dy.data_ptr() == base.data_ptr()):     # dy is exactly base[:, :3]
             src, CG = base, base.shape[1]
         else:
             src, CG = dy.contiguous(memory_format=torch.channels_last), 3
@@ -792,7 +796,7 @@ class _VaePrologue(torch.autograd.Function):
         L = lib()
         with torch.cuda.device(dy.device):
             _check(L.gd_nn_vae_prologue_backward(torch.cuda.current_stream(dy.device).cuda_stream, src.data_ptr(),
-                                                 dx.data_ptr(), N, H, W, OH, OW, CG), "gd_nn_vae_prologue_backward")
+                                                 dx.data_ptr(), N, H, W, OH, OW, CG), "gd_nn_vae_prologue_backward", "gd_nn_prologue_last_error")
         return dx, None, None
 
 
@@ -818,7 +822,7 @@ class _SparsityHead(torch.autograd.Function):
         L = lib()
         with torch.cuda.device(d.device):
             _check(L.gd_nn_sparsity_forward(torch.cuda.current_stream(d.device).cuda_stream, d.data_ptr(), m.data_ptr(), n,
-                                            sums.data_ptr()), "gd_nn_sparsity_forward")
+                                            sums.data_ptr()), "gd_nn_sparsity_forward", "gd_nn_prologue_last_error")
         ctx.save_for_backward(d, m, sums)
         return (sums[0] / n).to(torch.float32)
 
@@ -831,7 +835,7 @@ class _SparsityHead(torch.autograd.Function):
         L = lib()
         with torch.cuda.device(d.device):
             _check(L.gd_nn_sparsity_backward(torch.cuda.current_stream(d.device).cuda_stream, d.data_ptr(), m.data_ptr(),
-                                             g32.data_ptr(), n, dd.data_ptr()), "gd_nn_sparsity_backward")
+                                             g32.data_ptr(), n, dd.data_ptr()), "gd_nn_sparsity_backward", "gd_nn_prologue_last_error")
         dmax_grad = (-(sums[1] / n).to(torch.float32) / (m[0] + 1e-5)) * g32[0]
         return dd, dmax_grad.reshape(())
 

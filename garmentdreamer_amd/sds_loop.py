@@ -39,6 +39,32 @@ class _RenderOut(dict):
             return v
         raise KeyError(key)
 
+    # the lazy key behaves like a stored one for every read path of a dict
+    def __contains__(self, key):
+        return key == "opacity" or dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def keys(self):
+        self["opacity"]
+        return dict.keys(self)
+
+    def items(self):
+        self["opacity"]
+        return dict.items(self)
+
+    def values(self):
+        self["opacity"]
+        return dict.values(self)
+
+    def __iter__(self):
+        self["opacity"]
+        return dict.__iter__(self)
+
 
 class SDSLoop:
     def __init__(self, gaussians, guidance, prompt_utils, bg_color: torch.Tensor,

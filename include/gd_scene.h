@@ -16,7 +16,12 @@
  *                            (Garment_3DGS/threestudio/systems/GaussianDreamer.py:268-279,
  *                             scene/gaussian_model.py:415-419): max_radii2D / xyz_gradient_accum / denom update.
  *
- * Return 0 on success, negative on error (gd_scene_last_error()).
+ *   gd_scene_densify_plan / _apply <- GaussianModel.densify_and_prune = densify_and_clone + densify_and_split +
+ *                            prune_points with their optimizer-state surgery (scene/gaussian_model.py:283-413): the whole
+ *                            event as a classification pass and ONE sweep that writes the new flat parameter /
+ *                            exp_avg / exp_avg_sq buffers (csrc/raster_densify.hip).
+ *
+ * Return 0 on success, negative on error (gd_scene_last_error(); gd_scene_densify_last_error() for the last two).
  */
 #ifndef GD_SCENE_H_INCLUDED
 #define GD_SCENE_H_INCLUDED
@@ -70,6 +75,32 @@ int gd_scene_activate_backward(void* stream, int P, int M, const float* opacity,
                                const float* rotation_raw, const float* d_shs, const float* d_opacity,
                                const float* d_scales, const float* d_rotations, float* g_f_dc, float* g_f_rest,
                                float* g_opacity, float* g_scaling, float* g_rotation);
+
+/* ---- densify_and_prune (scene/gaussian_model.py:398-413) --------------------------------------------------------
+ * With g = xyz_gradient_accum / denom (NaN -> 0), s = max exp(scaling_raw), o = sigmoid(opacity_raw):
+ *   clone  sqrt(g g) >= grad_threshold and s <= dense_extent   (dense_extent = percent_dense * scene_extent)
+ *   split  g >= grad_threshold and s > dense_extent            (two children, N = 2; the original is removed)
+ *   prune  o < min_opacity or (max_world_scale >= 0 and s > max_world_scale), evaluated on the new point set
+ *          (max_world_scale = 0.1 * extent when the caller passes a max_screen_size, negative otherwise; the reference's
+ *          max_radii2D > max_screen_size test never fires: densification_postfix has zeroed max_radii2D by then).
+ * plan: classifies the P points, leaves the plan in `scratch` (gd_scene_densify_scratch_bytes(P) bytes) and returns
+ *   totals_host[4] = {originals kept, clones kept, points selected for splitting, children kept PER COPY}
+ *   (one stream synchronisation; new P = totals[0] + totals[1] + 2 totals[3]).
+ * apply: writes the new buffers.  The flat layout is group-major: group g holds width[g] floats per point, groups
+ *   back to back (P points in the old buffers, new P in the new ones); g_xyz / g_scaling / g_rotation name the groups
+ *   the split transform rewrites (widths 3 / 3 / 4).  normals: float [2 * totals[2]][3] standard-normal samples (row
+ *   n * totals[2] + j belongs to copy n of the j-th selected point, the order torch.normal(mean, std) fills
+ *   stds.repeat(2, 1)); children get xyz = R(q) (normal * exp(scaling)) + xyz, scaling = log(exp(scaling) * (1/1.6)),
+ *   clones and children zero Adam moments.  New point order: originals, clones, first children, second children.  */
+size_t gd_scene_densify_scratch_bytes(int P);
+int gd_scene_densify_plan(void* stream, int P, const float* xyz_gradient_accum, const float* denom,
+                          const float* opacity_raw, const float* scaling_raw, float grad_threshold, float dense_extent,
+                          float min_opacity, float max_world_scale, void* scratch, uint32_t* totals_host);
+int gd_scene_densify_apply(void* stream, int P, int ngroups, const int* width, int g_xyz, int g_scaling, int g_rotation,
+                           const uint32_t* totals_host, const void* scratch, const float* normals, const float* flat,
+                           const float* exp_avg, const float* exp_avg_sq, float* new_flat, float* new_exp_avg,
+                           float* new_exp_avg_sq);
+const char* gd_scene_densify_last_error(void);
 
 const char* gd_scene_last_error(void);
 

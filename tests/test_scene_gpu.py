@@ -182,3 +182,49 @@ def test_fused_activations_match_torch_accessors_and_their_gradients(sh_degree):
         o2 = gm.activated()
         sum((o * w).sum() for o, w in zip(o2, ws)).backward()
     torch.testing.assert_close(gm.flat_grad[ok], 2 * fused[ok], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("P,sh_degree,screen", [(5000, 0, None), (30000, 0, 20), (7777, 2, 20), (257, 0, None)])
+def test_native_densify_and_prune_matches_the_torch_sequence(P, sh_degree, screen):
+    """gd_scene_densify_plan / _apply vs the reference's op-for-op sequence (``densify_and_prune_torch``: clone, split,
+    prune with torch indexing, scene/gaussian_model.py:283-413) on the same scene, statistics and generator seed: same
+    point count and order, parameters and Adam moments bit-identical except the children's positions (R(q) . sample
+    is a bmm in the reference: summation order unspecified -> 1e-6)."""
+    from garmentdreamer_amd import gaussian_model as gm
+    from garmentdreamer_amd.scene import synthetic_gaussians
+    models = []
+    for _ in range(2):
+        sc = synthetic_gaussians(P, seed=3, sh_degree=sh_degree)
+        rng = np.random.default_rng(5)
+        sc["scales"] = (sc["scales"] * rng.uniform(0.5, 6.0, size=(P, 1))).astype(np.float32)   # both sides of percent_dense * extent
+        sc["opacities"] = rng.uniform(0.001, 0.9, size=(P, 1)).astype(np.float32)              # some below min_opacity
+        m = gm.GaussianModel.from_activated(sc, sh_degree=sh_degree, device=DEV)
+        g = torch.Generator(device="cpu").manual_seed(11)
+        m._exp_avg.copy_(torch.randn(m._exp_avg.shape, generator=g))
+        m._exp_avg_sq.copy_(torch.rand(m._exp_avg_sq.shape, generator=g))
+        acc = torch.rand((P, 1), generator=g) * 6e-4
+        den = torch.randint(0, 4, (P, 1), generator=g).float()       # zeros -> NaN / inf gradients
+        m.xyz_gradient_accum.copy_(acc * den)
+        m.denom.copy_(den)
+        m.max_radii2D.copy_(torch.rand(P, generator=g) * 40)
+        models.append(m)
+    a, b = models
+    ga = torch.Generator(device=DEV).manual_seed(77)
+    gb = torch.Generator(device=DEV).manual_seed(77)
+    gen0 = b.generation
+    a.densify_and_prune_torch(0.0002, 0.05, 4.0, screen, generator=ga)
+    b.densify_and_prune(0.0002, 0.05, 4.0, screen, generator=gb)
+    assert b.generation == gen0 + 1
+    Pa, Pb = a._xyz.shape[0], b._xyz.shape[0]
+    assert Pa == Pb and Pa != P
+    for n in ("_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(getattr(a, n).data, getattr(b, n).data), n
+    assert torch.allclose(a._xyz.data, b._xyz.data, rtol=1e-6, atol=1e-6)
+    same = (a._xyz.data == b._xyz.data).all(dim=1)
+    assert same.float().mean() > 0.3          # originals and clones are copies
+    assert torch.equal(a._exp_avg, b._exp_avg) and torch.equal(a._exp_avg_sq, b._exp_avg_sq)
+    for t in (b.xyz_gradient_accum, b.denom, b.max_radii2D):
+        assert t.shape[0] == Pb and float(t.abs().sum()) == 0.0
+    assert b.viewspace_grad.shape == (Pb, 3) and b._xyz.grad.data_ptr() == b._grad.data_ptr()
+    # the two generators consumed the same amount of the stream
+    assert torch.equal(torch.rand(4, device=DEV, generator=ga), torch.rand(4, device=DEV, generator=gb))
