@@ -242,7 +242,8 @@ __global__ __launch_bounds__(64 * WN * WM) void gemm_taps_fp8_kernel(
 }
 
 // ---- quantisation --------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float clamp448(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
+// saturate to the e4m3 range; a NaN stays a NaN (fminf / fmaxf would turn it into -448 and hide a diverged activation)
+__device__ __forceinline__ float clamp448(float v) { return v < -448.f ? -448.f : (v > 448.f ? 448.f : v); }
 
 // y8[i] = e4m3(sat(x[i] * inv_scale)), 8 bf16 -> 8 bytes per thread step
 __global__ __launch_bounds__(256) void quantize_fp8_kernel(const uint4* __restrict__ x, uint2* __restrict__ y, int64_t nvec,

@@ -225,7 +225,8 @@ __global__ void gn_apply_fp8_kernel(const bf16x8* __restrict__ x, uint2* __restr
             float t = bf2f(v.v[k]) * a[k] + b[k];
             if (apply_silu) t = silu_f(t);
             // the bf16 rounding of the unfused path first (same values as gn_apply_kernel), then scale + saturate
-            z[k] = fminf(fmaxf(bf2f(f2bf(t)) * inv_scale, -448.f), 448.f);
+            const float zz = bf2f(f2bf(t)) * inv_scale;
+            z[k] = zz < -448.f ? -448.f : (zz > 448.f ? 448.f : zz);   // saturate; a NaN stays a NaN (fminf / fmaxf would hide it)
         }
         int o0 = 0, o1 = 0;
         o0 = __builtin_amdgcn_cvt_pk_fp8_f32(z[0], z[1], o0, false);

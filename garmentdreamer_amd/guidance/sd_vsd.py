@@ -45,8 +45,16 @@ class SpecifyGradient(torch.autograd.Function):
 
 class StableDiffusionVSD(nn.Module):
     def __init__(self, device, fp16: bool = True, t_range=(0.02, 0.5), unet: Optional[nn.Module] = None,
-                 vae: Optional[nn.Module] = None, init_seed: int = 0, use_hip_graphs: bool = False):
+                 vae: Optional[nn.Module] = None, init_seed: int = 0, use_hip_graphs: bool = False,
+                 fp8_unet: bool = False, fp8_calibration_steps: int = 3):
         super().__init__()
+        # e4m3 MFMA convolutions in the iteration's three no-grad UNet forwards (BASELINE configs[4]; the reference is
+        # fp32, sd_vsd_utils.py:35): the frozen UNet's two (cond / uncond, one batch) and the LoRA UNet's no-grad
+        # forward; the LoRA UNet's TRAINING forward/backward stays bf16.  The first ``fp8_calibration_steps`` forwards
+        # of each network run eagerly in bf16 and record the activation ranges (nn_ops.Fp8State).
+        self.fp8_unet = bool(fp8_unet) and fp16 and torch.device(device).type == "cuda"
+        self.fp8_calibration_steps = max(1, int(fp8_calibration_steps))
+        self._fp8_calib = {}     # id(network) -> calibration forwards done
         # MI355X-side option (the reference has none): at batch 1 the iteration is ~5500 kernels of ~10 us and the
         # host cannot issue them fast enough; with it the frozen UNet forward, the LoRA UNet's no-grad forward, the
         # VAE encoder forward/backward and the LoRA UNet's training forward/backward replay as hipGraphs.
@@ -65,6 +73,8 @@ class StableDiffusionVSD(nn.Module):
         self.vae = vae.to(device=self.device, dtype=self.dtype).to(memory_format=torch.channels_last).eval()
         for p in list(self.unet.parameters()) + list(self.vae.parameters()):
             p.requires_grad_(False)
+        if self.fp8_unet:
+            self.unet.enable_fp8()
         self.scheduler = sd21.DDIMScheduler()
         self.num_train_timesteps = self.scheduler.config.num_train_timesteps
         self.min_step = int(self.num_train_timesteps * t_range[0])
@@ -140,8 +150,22 @@ class StableDiffusionVSD(nn.Module):
             posterior = self.vae.encode(x).latent_dist
         return posterior.sample(vae_noise) * self.vae.config.scaling_factor
 
+    def _fp8_calibrating(self, net) -> bool:
+        """True while ``net`` (a UNet with an Fp8State) still has to run eager bf16 calibration forwards; counts one."""
+        st = getattr(net, "fp8", None)
+        if st is None or st.mode == "run":
+            return False
+        n = self._fp8_calib.get(id(net), 0) + 1
+        self._fp8_calib[id(net)] = n
+        if n > self.fp8_calibration_steps:
+            st.mode = "run"
+            return False
+        return True
+
     def _frozen_unet(self, x, t, ctx):
         x, ctx = x.to(self.dtype), ctx.to(self.dtype)
+        if self._fp8_calibrating(self.unet):
+            return self.unet(x, t, encoder_hidden_states=ctx)
         if self.use_hip_graphs and x.is_cuda:
             try:
                 return self._replay_nograd("unet", lambda a, b, c: self.unet(a, b, encoder_hidden_states=c), x, t, ctx)
@@ -150,6 +174,12 @@ class StableDiffusionVSD(nn.Module):
         return self.unet(x, t, encoder_hidden_states=ctx)
 
     def _q_nograd(self, q_unet, x, t, text, pose, shading):
+        inner = getattr(q_unet, "unet", None)
+        if self.fp8_unet and inner is not None and hasattr(inner, "enable_fp8"):
+            if inner.fp8 is None and x.is_cuda and next(inner.parameters()).dtype == torch.bfloat16:
+                inner.enable_fp8()
+            if self._fp8_calibrating(inner):
+                return q_unet(x, t, text, c=pose, shading=shading)
         if self.use_hip_graphs and x.is_cuda:
             try:
                 return self._replay_nograd(("q", id(q_unet), shading),

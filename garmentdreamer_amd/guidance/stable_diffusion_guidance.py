@@ -77,6 +77,9 @@ class StableDiffusionGuidance(nn.Module):
         # e4m3 3x3 convolutions in the no-grad UNet forward (BASELINE configs[4], nn_ops.Fp8State): the first
         # forward_unet call calibrates the activation ranges in bf16, later calls run fp8.  bf16 stays the default.
         fp8_unet: bool = False
+        # eager bf16 forwards that record the activation ranges before the e4m3 path (and the graph capture) starts:
+        # each draws its own timesteps, so several of them span the t range the static scales have to cover
+        fp8_calibration_steps: int = 3
 
     def __init__(self, cfg: Optional[dict] = None, device="cuda", unet: Optional[nn.Module] = None,
                  vae: Optional[nn.Module] = None):
@@ -119,6 +122,7 @@ class StableDiffusionGuidance(nn.Module):
         self._unet_graphs = {}
         self._vae_graphs = {}
         self._fp8_calibrated = False
+        self._fp8_calib_done = 0
         if self.cfg.fp8_unet and self.weights_dtype == torch.bfloat16 and self.device.type == "cuda":
             self.unet.enable_fp8()
         if self.cfg.use_hip_graphs and not _runtime_env.graph_replay_safe():
@@ -142,8 +146,10 @@ class StableDiffusionGuidance(nn.Module):
         if fp8 is not None and not self._fp8_calibrated and not torch.is_grad_enabled():
             # one eager bf16 forward on the real inputs records every fp8 site's activation range
             out = self.unet(x, tt, encoder_hidden_states=ctx).to(input_dtype)
-            fp8.mode = "run"
-            self._fp8_calibrated = True
+            self._fp8_calib_done += 1
+            if self._fp8_calib_done >= max(1, int(self.cfg.fp8_calibration_steps)):
+                fp8.mode = "run"
+                self._fp8_calibrated = True
             return out
         if self.cfg.use_hip_graphs and x.is_cuda and not torch.is_grad_enabled():
             try:

@@ -194,23 +194,25 @@ def test_config3_two_ranks_share_one_gpu_real_rasterizer_matches_single_rank(tmp
     assert float(d.max()) < 0.11
 
 
-def _vsd_objects(kw_unet, kw_vae, dtype, graphs=False):
+def _vsd_objects(kw_unet, kw_vae, dtype, graphs=False, **gd_kw):
     from garmentdreamer_amd.guidance import sd21
     from garmentdreamer_amd.guidance.sd_vsd import LoraUnet, StableDiffusionVSD
     with torch.device(DEV):
         unet = sd21.init_random_(sd21.UNet2DConditionModel(**kw_unet))
         vae = sd21.init_random_(sd21.AutoencoderKLEncoder(**kw_vae), 1)
         lora = sd21.init_random_(sd21.LoraUNet2DConditionModel(**kw_unet), 2)
-    gd = StableDiffusionVSD(DEV, fp16=dtype == torch.bfloat16, unet=unet, vae=vae, use_hip_graphs=graphs)
+    gd = StableDiffusionVSD(DEV, fp16=dtype == torch.bfloat16, unet=unet, vae=vae, use_hip_graphs=graphs, **gd_kw)
     lora = lora.to(dtype).to(memory_format=torch.channels_last)
     train = lora.freeze_base()
     return gd, lora, train, LoraUnet(lora)
 
 
-def _vsd_step(gd, q, train, seed):
+def _vsd_step(gd, q, train, seed, res=512):
     g = torch.Generator(DEV).manual_seed(seed)
     gd.set_text_embeds(torch.randn(1, 77, 1024, device=DEV, generator=g), torch.randn(1, 77, 1024, device=DEV, generator=g))
-    img = torch.rand(1, 3, 512, 512, device=DEV, generator=g).requires_grad_(True)
+    leaf = torch.rand(1, 3, res, res, device=DEV, generator=g).requires_grad_(True)
+    # a 1024^2 render is reduced to the 512^2 the NeTF guidance asserts (sd_vsd_utils.py:146), the Garment_3DGS way
+    img = leaf if res == 512 else torch.nn.functional.interpolate(leaf, (512, 512), mode="bilinear", align_corners=False)
     pose = torch.randn(1, 16, device=DEV, generator=g)
     noise = torch.randn(1, 4, 64, 64, device=DEV, generator=g)
     vn = torch.randn(1, 4, 64, 64, device=DEV, generator=g)
@@ -225,7 +227,7 @@ def _vsd_step(gd, q, train, seed):
         p.grad = None
     lu.backward()
     torch.cuda.synchronize()
-    return img.grad.detach().float(), latents.detach().float(), float(lu), \
+    return leaf.grad.detach().float(), latents.detach().float(), float(lu), \
         {i: p.grad.detach().float().clone() for i, p in enumerate(train) if p.grad is not None}
 
 
@@ -243,6 +245,36 @@ def test_config4_vsd_iteration_full_size():
     names = [n for n, p in lora.named_parameters() if p.requires_grad]
     assert any("lora" in n for n in names) and any(n.startswith("camera_emb") for n in names)
     assert sum(float(v.abs().sum()) > 0 for v in grads.values()) > 0.5 * len(grads)
+
+
+def test_config4_vsd_iteration_full_size_fp8_on_1024_render():
+    """BASELINE configs[4] as stated: 1024^2 render (reduced to the 512^2 the NeTF guidance asserts), full-size SD-2.1 +
+    LoRA UNets, the three no-grad UNet forwards with e4m3 MFMA convolutions (StableDiffusionVSD(fp8_unet=True)).
+    Checked against the bf16 iteration on the same weights and inputs: the calibration step IS the bf16 step; on the
+    next step the SDS gradient that reaches the image keeps its direction (cosine bar) and the LoRA loss its value."""
+    res = {}
+    for fp8 in (False, True):
+        gd, lora, train, q = _vsd_objects({}, {}, torch.bfloat16, fp8_unet=fp8, fp8_calibration_steps=1)
+        res[fp8] = [_vsd_step(gd, q, train, seed=sd, res=1024) for sd in (3, 4)]
+        if fp8:
+            assert gd.unet.fp8.mode == "run" and lora.fp8 is not None and lora.fp8.mode == "run"
+            sites = gd.unet.fp8.sites_run + lora.fp8.sites_run
+            # one step in "run" mode: the frozen UNet (batch 2) runs its 64^2 and 32^2 ResnetBlock convolutions in e4m3 (20),
+            # the LoRA UNet (batch 1) its 64^2 ones (10); smaller maps stay bf16 (Fp8State.min_pixels: no gain there)
+            assert sites >= 30, sites
+        del gd, lora, train, q
+        torch.cuda.empty_cache()
+    (d0b, l0b, u0b, _), (d1b, l1b, u1b, g1b) = res[False]
+    (d0f, l0f, u0f, _), (d1f, l1f, u1f, g1f) = res[True]
+    assert d0b.shape == (1, 3, 1024, 1024)
+    assert torch.equal(l0b, l0f) and _cos(d0b, d0f) > 0.9999     # calibration forward = the bf16 kernels
+    c_img, c_lat = _cos(d1b, d1f), _cos(l1b, l1f)
+    parity_report.record("configs[4] VSD step, full size, 1024^2 leaf: fp8 vs bf16 no-grad UNet forwards", "step",
+                         cos_dL_dimage=c_img, cos_latents=c_lat, rel_dlora_loss=abs(u1b - u1f) / abs(u1b))
+    assert torch.isfinite(d1f).all() and float(d1f.abs().sum()) > 0
+    assert c_lat > 0.99999 and c_img > 0.99, (c_lat, c_img)
+    assert abs(u1b - u1f) <= 2e-2 * abs(u1b)
+    assert all(torch.isfinite(v).all() for v in g1f.values())
 
 
 def test_config4_vsd_step_reduced_width_matches_eager_fp32():
