@@ -23,20 +23,31 @@ from garmentdreamer_amd.scene import synthetic_gaussians  # noqa: E402
 from garmentdreamer_amd.sds_loop import SDSLoop  # noqa: E402
 
 V_TOTAL, P, HW, FIRST_STEP, N_STEPS = 4, 20000, 128, 399, 4
+FULL = os.environ.get("GD_TEST_CFG") == "full"      # configs[3] at its stated shape: 8 views x 100k @512^2, full bf16 nets
+if FULL:
+    V_TOTAL, P, HW, FIRST_STEP, N_STEPS = 8, 100000, 512, 10, 2
 
 
 def main():
     rk, _lr, ws = gdist.init_from_env()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    with torch.device(dev):
-        unet = sd21.init_random_(sd21.UNet2DConditionModel(block_out_channels=(64, 128, 256, 256),
-                                                           attention_head_dim=(1, 2, 4, 4)))
-        vae = sd21.init_random_(sd21.AutoencoderKLEncoder(block_out_channels=(32, 64, 128, 128)), 1)
-    # fp32 UNet / VAE (torch ops): bf16 results depend on the batch composition (4 vs 8 UNet samples pick different
-    # GEMM / conv tiles), which would blur a test whose subject is the sharded rasterizer + collectives + Adam path
-    guidance = StableDiffusionGuidance({"guidance_scale": 7.5, "grad_clip": [0, 1.5, 2.0, 1000],
-                                        "half_precision_weights": False}, device=dev, unet=unet, vae=vae)
+    if FULL:
+        # guidance_scale: the classifier-free term multiplies (eps_text - eps_uncond), which at random-init weights is
+        # bf16 rounding noise of the UNet -- and a UNet call on 8 latents picks other tiles than one on 16.  With the
+        # reference's 100 the 2x4-view and 1x8-view buckets agree only to cosine 0.92 for that reason (measured);
+        # GD_TEST_CFG_SCALE keeps the amplification at the level the comparison is about
+        guidance = StableDiffusionGuidance({"guidance_scale": float(os.environ.get("GD_TEST_CFG_SCALE", "7.5")),
+                                            "grad_clip": [0, 1.5, 2.0, 1000], "use_hip_graphs": True}, device=dev)
+    else:
+        with torch.device(dev):
+            unet = sd21.init_random_(sd21.UNet2DConditionModel(block_out_channels=(64, 128, 256, 256),
+                                                               attention_head_dim=(1, 2, 4, 4)))
+            vae = sd21.init_random_(sd21.AutoencoderKLEncoder(block_out_channels=(32, 64, 128, 128)), 1)
+        # fp32 UNet / VAE (torch ops): bf16 results depend on the batch composition (4 vs 8 UNet samples pick different
+        # GEMM / conv tiles), which would blur a test whose subject is the sharded rasterizer + collectives + Adam path
+        guidance = StableDiffusionGuidance({"guidance_scale": 7.5, "grad_clip": [0, 1.5, 2.0, 1000],
+                                            "half_precision_weights": False}, device=dev, unet=unet, vae=vae)
     gm = GaussianModel.from_activated(synthetic_gaussians(P, seed=2), device=dev)
     loop = SDSLoop(gm, guidance, PromptEmbeddings.random(dev), torch.ones(3, device=dev), densify_seed=123)
     loop.global_step = FIRST_STEP
