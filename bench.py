@@ -50,6 +50,26 @@ PEAK_BF16_TFLOPS = 2500.0                 # dense bf16 MFMA
 METRIC = "SDS iters/sec (rasterize+UNet+bwd), 100k Gaussians ×8 views @512², 1/2/4/8 GPU"
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources + headers of both libraries: identifies WHICH kernels a counter file measured
+    (.git does not travel to the GPU box, so a commit id cannot be read there)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "garmentdreamer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def latest_profile(pattern: str):
+    """Newest profiles/rNN_<pattern> (by round number), or None."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    return c[-1] if c else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,7 +152,6 @@ def cpu_baseline(args):
     gc, gd, ga = h.random_image_grads(args.res, args.res)
     t_raster = {}
     for omp in (False, True):
-        os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
         t0 = time.perf_counter()
         st = gd_oracle.forward(inp["bg"], inp["means3D"], inp["colors_precomp"], inp["opacities"], inp["scales"],
                                inp["rotations"], inp["scale_modifier"], inp["cov3D_precomp"], inp["viewmatrix"],
@@ -266,6 +285,11 @@ def main():
     torch.cuda.set_device(device)
     _native.lib()  # fail loudly right here if the HIP library is missing
     torch.backends.cuda.matmul.allow_tf32 = False
+    from garmentdreamer_amd import _runtime_env
+    if not args.no_graphs and not args.raster_only and not _runtime_env.graph_replay_safe():
+        raise SystemExit("bench.py: hipGraph replay is not available in this process (" + _runtime_env.FLAG + "=0 was not in "
+                         "place before the HIP runtime started) -- the headline configuration replays the UNet / VAE as "
+                         "graphs; fix the environment or pass --no-graphs to measure the eager path explicitly")
 
     view_ids = gdist.shard_views(args.views, rk, ws)
     scene = synthetic_gaussians(args.gaussians, seed=0, sh_degree=0)
@@ -411,38 +435,48 @@ def main():
     # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/pmc_all.sh -> profiles/):
     # bench.py cannot read hardware counters itself, so `traffic` quotes the committed counter file
     kernels_per_step = None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc.json")
-    if os.path.exists(pmc_file):
+    pmc_file = latest_profile("pmc.json")
+    pmc_note = None
+    workload = {"gaussians": args.gaussians, "views": args.views, "res": args.res}
+    if pmc_file is not None:
         try:
-            ks = json.load(open(pmc_file))["kernels"]
-            if roofline_conv is not None:
-                fam = {k: v for k, v in ks.items() if k.startswith("conv3x3_") and "hbm_bytes_per_launch" in v
-                       and "first" not in k and "flip" not in k}
-                n = sum(v["launches_sampled"] for v in fam.values())
-                if n:
-                    roofline_conv["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in fam.values()) / n
-                    roofline_conv["traffic_per_kernel"] = {k: v["hbm_bytes_per_launch"] for k, v in fam.items()}
-                    roofline_conv["traffic_source"] = "profiles/r02_pmc.json (launch-weighted mean over the family)"
-            if roofline is not None:
-                for k, v in ks.items():
-                    if k.startswith("render_backward") and "hbm_bytes_per_launch" in v:
-                        roofline["traffic"] = v["hbm_bytes_per_launch"]
-                        roofline["traffic_source"] = "profiles/r02_pmc.json"
-                        if v.get("SQ_INSTS_VALU") and v.get("SQ_BUSY_CYCLES"):
-                            # SIMD-cycles of the launch: SQ_BUSY_CYCLES is summed over the 32 shader engines; 1024 SIMDs
-                            simd_cycles = v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
-                            # VALU issue utilisation: a wave64 VALU instruction holds its SIMD for ~4.5 cycles (measured,
-                            # tools/probes/valu_rate_probe.hip; packed / transcendental ones longer)
-                            roofline["valu_issue_util_min"] = 4.5 * v["SQ_INSTS_VALU"] / simd_cycles
-                            roofline["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
-                            if v.get("SQ_ACTIVE_INST_VALU"):
-                                # SQ_ACTIVE_INST_* count quad-cycles per wave (MI355X_MICROARCH.md): average number of
-                                # waves per SIMD with a VALU instruction in flight
-                                roofline["valu_active_waves_per_simd"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / simd_cycles
-        except Exception:
-            pass
-    steady = os.path.join(ROOT, "profiles", "r02_bench_N1_kernel_stats_steady.csv")
-    if os.path.exists(steady) and args.views == 8 and ws == 1:
+            pmc = json.load(open(pmc_file))
+            rel = os.path.relpath(pmc_file, ROOT)
+            if pmc.get("kernel_source_hash") != kernel_source_hash():
+                pmc_note = f"{rel} was collected on other kernel sources (hash {pmc.get('kernel_source_hash')}): not quoted"
+            elif pmc.get("workload") != workload:
+                pmc_note = f"{rel} was collected on another workload ({pmc.get('workload')}): not quoted"
+            else:
+                ks = pmc["kernels"]
+                if roofline_conv is not None:
+                    fam = {k: v for k, v in ks.items() if k.startswith("conv3x3_") and "hbm_bytes_per_launch" in v
+                           and "first" not in k and "flip" not in k}
+                    n = sum(v["launches_sampled"] for v in fam.values())
+                    if n:
+                        roofline_conv["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in fam.values()) / n
+                        roofline_conv["traffic_per_kernel"] = {k: v["hbm_bytes_per_launch"] for k, v in fam.items()}
+                        roofline_conv["traffic_source"] = rel + " (launch-weighted mean over the family)"
+                if roofline is not None:
+                    for k, v in ks.items():
+                        if k.startswith("render_backward") and "hbm_bytes_per_launch" in v:
+                            roofline["traffic"] = v["hbm_bytes_per_launch"]
+                            roofline["traffic_source"] = rel
+                            if v.get("SQ_INSTS_VALU") and v.get("SQ_BUSY_CYCLES"):
+                                # SIMD-cycles of the launch: SQ_BUSY_CYCLES is summed over the 32 shader engines; 1024 SIMDs
+                                simd_cycles = v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
+                                # VALU issue utilisation: a wave64 VALU instruction holds its SIMD for ~4.5 cycles (measured,
+                                # tools/probes/valu_rate_probe.hip; packed / transcendental ones longer)
+                                roofline["valu_issue_util_min"] = 4.5 * v["SQ_INSTS_VALU"] / simd_cycles
+                                roofline["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
+        except Exception as e:
+            pmc_note = f"counter file unreadable: {type(e).__name__}: {e}"
+    if pmc_note is not None:
+        for r in (roofline, roofline_conv):
+            if r is not None:
+                r["traffic_source"] = pmc_note
+    steady = latest_profile("bench_N1_kernel_stats_steady.csv")
+    if (steady is not None and workload == {"gaussians": 100000, "views": 8, "res": 512} and ws == 1 and not args.fp8
+            and graphs_active and pmc_note is None and pmc_file is not None):   # the workload / tree that CSV was taken on
         try:
             import csv
             kernels_per_step = sum(float(r["CallsPerStep"]) for r in csv.DictReader(open(steady)))

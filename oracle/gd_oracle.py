@@ -15,12 +15,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 _LIB_OMP = None
+_LIB_LIBM = None
 
 _f32p = C.POINTER(C.c_float)
 
 
-def build(force: bool = False, omp: bool = False) -> str:
-    name = "libgd_oracle_omp.so" if omp else "libgd_oracle.so"
+def build(force: bool = False, omp=False) -> str:
+    """``omp``: False = the serial build, True = -fopenmp, "libm" = the blend on the C library's expf (tolerance
+    check of gd_expf, tests only)."""
+    name = {False: "libgd_oracle.so", True: "libgd_oracle_omp.so", "libm": "libgd_oracle_libm.so"}[omp]
     so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "gd_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
@@ -31,7 +34,11 @@ def build(force: bool = False, omp: bool = False) -> str:
 def lib(omp: bool = False):
     """``omp=True``: the same C file built with -fopenmp (tiles over the host cores) -- bench.py's multi-core CPU
     baseline; the parity tests use the serial, deterministic build."""
-    global _LIB, _LIB_OMP
+    global _LIB, _LIB_OMP, _LIB_LIBM
+    if omp == "libm":
+        if _LIB_LIBM is None:
+            _LIB_LIBM = _bind(C.CDLL(build(omp="libm")))
+        return _LIB_LIBM
     if omp:
         if _LIB_OMP is None:
             _LIB_OMP = _bind(C.CDLL(build(omp=True)))

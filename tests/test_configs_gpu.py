@@ -94,8 +94,8 @@ def _full_size_step_graph_vs_eager_and_oracle(V, check_view, label):
             res[name] = _one_gradient_step(loop, batch, noise, t, vn)
     assert g_graph.cfg.use_hip_graphs, "hipGraph replay was switched off (capture failed or runtime flag missing)"
     e, g = res["eager"], res["graph"]
-    # same kernels, same inputs: what differs is the order of the fp32 atomics in the rasterizer backward and of
-    # the fp64 GroupNorm partial sums, amplified by guidance_scale = 100 on bf16 noise predictions
+    # same kernels, same inputs (the rasterizer backward is atomic-free and bitwise reproducible): what can differ is
+    # the order of the fp64 GroupNorm partial sums, amplified by guidance_scale = 100 on bf16 noise predictions
     d_loss = abs(float(e["loss_sds"]) - float(g["loss_sds"])) / abs(float(e["loss_sds"]))
     cos_flat, cos_vs = _cos(e["flat_grad"], g["flat_grad"]), _cos(e["viewspace"], g["viewspace"])
     cos_img = _cos(e["d_render"], g["d_render"])

@@ -277,3 +277,25 @@ def test_blend_exp_is_within_one_ulp_of_the_exact_exponential():
     assert np.abs(got.astype(np.float64) - ref).max() / 1.0 >= 0.0
     assert (np.abs(got.astype(np.float64) - ref) <= 1.0 * ulp).all()
     assert gd_oracle.expf(-100.0) == 0.0 and gd_oracle.expf(0.0) == 1.0
+
+
+def test_defined_blend_exp_agrees_with_the_c_library_exp_end_to_end():
+    """The blend's exponential is a DEFINED function (gd_expf) shared by the oracle and the HIP kernels, so their
+    bit-equality says nothing about the definition itself.  Here the whole forward + backward of the oracle runs once
+    on gd_expf and once on the C library's expf (-DGD_ORACLE_LIBM_EXP): images within the pixel tolerance of SURVEY
+    8d, the same blended pairs up to a few threshold flips, gradients within the gradient tolerance."""
+    inp = h.raster_inputs(P=3000, H=96, W=96, seed=4)
+    a = h.oracle_forward(inp)
+    b = gd_oracle.forward(inp["bg"], inp["means3D"], inp["colors_precomp"], inp["opacities"], inp["scales"],
+                          inp["rotations"], inp["scale_modifier"], inp["cov3D_precomp"], inp["viewmatrix"],
+                          inp["projmatrix"], inp["tanfovx"], inp["tanfovy"], inp["image_height"], inp["image_width"],
+                          inp["sh"], inp["degree"], inp["campos"], omp="libm")
+    assert a.num_rendered == b.num_rendered and np.array_equal(a.point_list, b.point_list)
+    for x, y in ((a.color, b.color), (a.depth, b.depth), (a.alpha, b.alpha)):
+        assert np.all(np.abs(x - y) <= 1e-5 + 1e-4 * np.abs(y))
+    assert np.mean(a.n_contrib != b.n_contrib) < 2e-3          # a 1-ulp exp may flip a pair sitting on 1/255 or 1e-4
+    gc, gd, ga = h.random_image_grads(96, 96)
+    ga_, gb_ = gd_oracle.backward(a, gc, gd, ga), gd_oracle.backward(b, gc, gd, ga)
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drotations"):
+        s = np.abs(gb_[k]).max()
+        assert np.abs(ga_[k] - gb_[k]).max() <= 2e-3 * s, k

@@ -16,8 +16,15 @@ for g in "${groups[@]}"; do
   echo "pass $i ($g): rc $?" >&2
   i=$((i+1))
 done
-python - "$out" <<'PY'
-import csv, glob, json, re, sys, collections
+python - "$out" "$@" <<'PY'
+import argparse, csv, glob, json, os, re, sys, collections
+sys.path.insert(0, os.getcwd())
+import bench                      # kernel_source_hash(): the counter file is only quoted for the sources it measured
+_out = sys.argv[1]
+_a = argparse.ArgumentParser()
+for _n, _d in (("--gaussians", 100000), ("--views", 8), ("--res", 512)):
+    _a.add_argument(_n, type=int, default=_d)
+_w, _ = _a.parse_known_args(sys.argv[2:])
 KEEP = ("render_backward", "render_forward", "preprocess", "instance_sum", "radix_", "duplicate", "tile_ranges", "conv3x3", "conv_splitk",
         "gn_", "attn_", "geglu", "add_layernorm", "adam", "activate", "sds_", "vae_prologue", "sparsity", "gemm_", "xattn")
 def short(name):
@@ -44,13 +51,15 @@ for k, e in res.items():
     if "FETCH_SIZE" in e or "WRITE_SIZE" in e:
         e["hbm_bytes_per_launch"] = (2.0 * e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)) * 1024.0
     if "SQ_INSTS_VALU" in e and "SQ_BUSY_CYCLES" in e and e["SQ_BUSY_CYCLES"] > 0:
-        # wave64 VALU instruction = 2 issue cycles on a SIMD-32; SQ_BUSY_CYCLES is summed over the shader engines'
-        # SQ instances, so the per-launch figure below is reported raw and the utilisation is derived in DESIGN.md
+        # a wave64 VALU instruction holds its SIMD ~4.5 cycles (tools/probes/valu_rate_probe.hip); SQ_BUSY_CYCLES is summed
+        # over the shader engines' SQ instances, so the per-launch figure is reported raw, the utilisation derived in DESIGN.md
         e["valu_insts_per_launch"] = e["SQ_INSTS_VALU"]
-meta = {"method": ("rocprofv3 --kernel-trace --pmc <group> in separate passes of `python bench.py --steps 2 --warmup 1 "
+meta = {"kernel_source_hash": bench.kernel_source_hash(),
+        "workload": {"gaussians": _w.gaussians, "views": _w.views, "res": _w.res},
+        "method": ("rocprofv3 --kernel-trace --pmc <group> in separate passes of `python bench.py --steps 2 --warmup 1 "
                    "--no-graphs`; values are averages per launch over the sampled launches; FETCH_SIZE x2 (gfx950), KiB"),
         "kernels": res}
-json.dump(meta, open(sys.argv[1], "w"), indent=1)
+json.dump(meta, open(_out, "w"), indent=1)
 print(json.dumps({k: {c: v for c, v in e.items() if c in ("hbm_bytes_per_launch", "SQ_INSTS_VALU", "launches_sampled")}
                   for k, e in res.items()}, indent=1))
 PY
