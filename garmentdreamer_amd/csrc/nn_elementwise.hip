@@ -32,13 +32,15 @@ struct alignas(16) bf16x8 {
 };
 
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f)
-{
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+// Packed fp32 helpers: these row passes are VALU-bound on MI355X (a wave64 VALU instruction holds its SIMD ~4.5 cycles,
+// tools/probes/valu_rate_probe.hip; SQ_INSTS_VALU x 4.5 cycles = the whole kernel time in profiles/r02_pmc.json), so two
+// channels share every arithmetic instruction (v_pk_*_f32) and bf16 rounding is v_cvt_pk_bf16_f32 (nearest even).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+struct alignas(16) u32x4 { uint32_t w[4]; };
+__device__ __forceinline__ f2 unpack2(uint32_t w) { return f2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ __forceinline__ uint32_t pack2(f2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t)); }
+__device__ __forceinline__ f2 round_bf16(f2 v) { return unpack2(pack2(v)); }
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -49,16 +51,19 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, three orders below a bf16 ulp of the GELU): one rcp, one
 // exp and a degree-5 Horner instead of libm erff's ~40 instructions -- the kernel is VALU-bound on this function.
-__device__ __forceinline__ float erf_as(float x)
+// Two values per call: the polynomial runs on v_pk_fma_f32.
+__device__ __forceinline__ f2 erf_as2(f2 x)
 {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-ax * ax);
-    return copysignf(e, x);
+    const f2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f2 d = 0.3275911f * ax + 1.0f;
+    const f2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f2 p = 1.061405429f * t + -1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t + -0.284496736f;
+    p = p * t + 0.254829592f;
+    const f2 a = (ax * ax) * -1.44269504088896341f;
+    const f2 e = 1.0f - (p * t) * f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    return f2{copysignf(e.x, x.x), copysignf(e.y, x.y)};
 }
 
 // x: [rows][2*inner] (hidden | gate), y: [rows][inner]; one thread per 8 output channels
@@ -68,17 +73,17 @@ __global__ __launch_bounds__(256) void geglu_kernel(const bf16x8* __restrict__ x
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / vin;
         const int c = (int)(i - row * vin);
-        const bf16x8 h = x[row * 2 * vin + c];
-        const bf16x8 g = x[row * 2 * vin + vin + c];
-        bf16x8 o;
+        const u32x4 h = __builtin_bit_cast(u32x4, x[row * 2 * vin + c]);
+        const u32x4 g = __builtin_bit_cast(u32x4, x[row * 2 * vin + vin + c]);
+        u32x4 o;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float gv = bf2f(g.v[k]);
+        for (int k = 0; k < 4; k++) {
+            const f2 gv = unpack2(g.w[k]);
             // F.gelu on a bf16 tensor rounds its result to bf16 before the multiply; keep that rounding
-            const float ge = bf2f(f2bf(0.5f * gv * (1.0f + erf_as(gv * 0.70710678118654752f))));
-            o.v[k] = f2bf(bf2f(h.v[k]) * ge);
+            const f2 ge = round_bf16((0.5f * gv) * (1.0f + erf_as2(gv * 0.70710678118654752f)));
+            o.w[k] = pack2(unpack2(h.w[k]) * ge);
         }
-        y[i] = o;
+        y[i] = __builtin_bit_cast(bf16x8, o);
     }
 }
 
@@ -93,56 +98,56 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const bf16x8* __rest
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const bf16x8* xr = x + row * vpr;
-    float v[VPL][8];
-    float sum = 0.f;
+    f2 v[VPL][4];
+    f2 sum2 = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         const int c = lane + 64 * i;
         if (c < vpr) {
-            const bf16x8 a = xr[c];
+            const u32x4 a = __builtin_bit_cast(u32x4, xr[c]);
             if (r) {
-                const bf16x8 rr = r[row * vpr + c];
-                bf16x8 so;
+                const u32x4 rr = __builtin_bit_cast(u32x4, r[row * vpr + c]);
+                u32x4 so;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    so.v[k] = f2bf(bf2f(a.v[k]) + bf2f(rr.v[k]));   // the residual stream stays bf16, as in eager
-                    v[i][k] = bf2f(so.v[k]);
+                for (int k = 0; k < 4; k++) {
+                    so.w[k] = pack2(unpack2(a.w[k]) + unpack2(rr.w[k]));   // the residual stream stays bf16, as in eager
+                    v[i][k] = unpack2(so.w[k]);
                 }
-                if (s_out) s_out[row * vpr + c] = so;
+                if (s_out) s_out[row * vpr + c] = __builtin_bit_cast(bf16x8, so);
             } else {
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[i][k] = bf2f(a.v[k]);
+                for (int k = 0; k < 4; k++) v[i][k] = unpack2(a.w[k]);
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++) sum += v[i][k];
+            for (int k = 0; k < 4; k++) sum2 += v[i][k];
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[i][k] = 0.f;
+            for (int k = 0; k < 4; k++) v[i][k] = f2{0.f, 0.f};
         }
     }
     const float inv_c = 1.0f / (float)(vpr * 8);
-    const float mean = wave_sum(sum) * inv_c;
-    float sq = 0.f;
+    const float mean = wave_sum(sum2.x + sum2.y) * inv_c;
+    f2 sq2 = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         if (lane + 64 * i < vpr) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const float d = v[i][k] - mean;
-                sq += d * d;
+            for (int k = 0; k < 4; k++) {
+                const f2 d = v[i][k] - mean;
+                sq2 += d * d;
             }
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) * inv_c + eps);
+    const float rstd = rsqrtf(wave_sum(sq2.x + sq2.y) * inv_c + eps);
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         const int c = lane + 64 * i;
         if (c < vpr) {
-            const bf16x8 ww = w[c], bb = b[c];
-            bf16x8 o;
+            const u32x4 ww = __builtin_bit_cast(u32x4, w[c]), bb = __builtin_bit_cast(u32x4, b[c]);
+            u32x4 o;
 #pragma unroll
-            for (int k = 0; k < 8; k++) o.v[k] = f2bf((v[i][k] - mean) * rstd * bf2f(ww.v[k]) + bf2f(bb.v[k]));
-            y[row * vpr + c] = o;
+            for (int k = 0; k < 4; k++) o.w[k] = pack2(((v[i][k] - mean) * rstd) * unpack2(ww.w[k]) + unpack2(bb.w[k]));
+            y[row * vpr + c] = __builtin_bit_cast(bf16x8, o);
         }
     }
 }

@@ -39,6 +39,35 @@ __device__ __forceinline__ uint16_t f2bf(float f)
     return (uint16_t)(u >> 16);
 }
 
+// ---- packed fp32 helpers.  Measured on MI355X (tools/probes/valu_rate_probe.hip): a wave64 VALU instruction holds
+// its SIMD ~4.5 cycles, so these "streaming" passes were VALU-bound, not HBM-bound (SQ_INSTS_VALU x 4.5 cycles = the
+// whole kernel time, profiles/r02_pmc.json) -- with an IEEE division (12 instructions) per sigmoid, a six-instruction
+// software bf16 rounding per element and scalar fp32 arithmetic.  Here two channels share every arithmetic
+// instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), the sigmoid is exp2 + v_rcp_f32 and the rounding is
+// v_cvt_pk_bf16_f32 (round to nearest even, the same bits as f2bf for every non-NaN input).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+struct alignas(16) u32x4 { uint32_t w[4]; };
+__device__ __forceinline__ f2 unpack2(uint32_t w) { return f2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ __forceinline__ uint32_t pack2(f2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t)); }
+__device__ __forceinline__ f2 sigmoid2(f2 z)
+{
+    const f2 e = z * -1.44269504088896341f;
+    const f2 den = 1.0f + f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    return f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+}
+// group of channel 8 tv + k for k = 0..7 with ONE integer division (cg = channels per group, any value >= 1)
+__device__ __forceinline__ void groups_of_vector(int tv, int cg, int (&g)[8])
+{
+    const int base = tv * 8;
+    int q = base / cg, r = base - q * cg;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        g[k] = q;
+        if (++r == cg) { r = 0; q++; }
+    }
+}
+
 constexpr int kMaxThreads = 320;  // C = 2560 -> 320 vectors per pixel
 constexpr int kUnroll = 4;        // independent 16-byte loads per thread and loop iteration of the streaming kernels
 constexpr int kSlots = 8;         // copies of the statistics accumulators (contention, see reduce_to_groups)
@@ -127,16 +156,17 @@ __global__ void gn_stats_kernel(const bf16x8* __restrict__ x, int HW, int C, int
     const int n = blockIdx.y + n0;
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
-    float s[8], ss[8];
+    f2 s2[4], ss2[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = ss[k] = 0.f;
+    for (int k = 0; k < 4; k++) s2[k] = ss2[k] = f2{0.f, 0.f};
     const bf16x8* xn = x + (size_t)n * HW * vpp;
     auto body = [&](const bf16x8& v) {
+        const u32x4 w = __builtin_bit_cast(u32x4, v);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float f = bf2f(v.v[k]);
-            s[k] += f;
-            ss[k] += f * f;
+        for (int k = 0; k < 4; k++) {
+            const f2 f = unpack2(w.w[k]);
+            s2[k] += f;
+            ss2[k] += f * f;
         }
     };
     // kUnroll independent 16-byte loads per thread before any arithmetic: one load per iteration kept ~32 KB in
@@ -150,6 +180,9 @@ __global__ void gn_stats_kernel(const bf16x8* __restrict__ x, int HW, int C, int
         for (int u = 0; u < kUnroll; u++) body(v[u]);
     }
     for (; p < p1; p += rows) body(xn[(size_t)p * vpp + tv]);
+    float s[8], ss[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { s[2 * k] = s2[k].x; s[2 * k + 1] = s2[k].y; ss[2 * k] = ss2[k].x; ss[2 * k + 1] = ss2[k].y; }
     reduce_to_groups<0>(s, ss, vpp, rows, tv, tr, C, G, N, n, (double)HW * (C / G), eps, ws, mean_rstd, lds);
 }
 
@@ -164,26 +197,34 @@ __global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
     const int cg = C / G;
-    float a[8], b[8];
+    f2 a[4], b[4];
+    {
+        int g[8];
+        groups_of_vector(tv, cg, g);
+        float a1[8], b1[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int c = tv * 8 + k, g = c / cg;
-        const float mean = mean_rstd[((size_t)n * G + g) * 2];
-        const float rstd = mean_rstd[((size_t)n * G + g) * 2 + 1];
-        a[k] = rstd * bf2f(gamma[c]);
-        b[k] = bf2f(beta[c]) - mean * a[k];
+        for (int k = 0; k < 8; k++) {
+            const int c = tv * 8 + k;
+            const float mean = mean_rstd[((size_t)n * G + g[k]) * 2];
+            const float rstd = mean_rstd[((size_t)n * G + g[k]) * 2 + 1];
+            a1[k] = rstd * bf2f(gamma[c]);
+            b1[k] = bf2f(beta[c]) - mean * a1[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[k] = f2{a1[2 * k], a1[2 * k + 1]}; b[k] = f2{b1[2 * k], b1[2 * k + 1]}; }
     }
     const bf16x8* xn = x + (size_t)n * HW * vpp;
     bf16x8* yn = y + (size_t)n * HW * vpp;
     auto body = [&](const bf16x8& v, int p) {
-        bf16x8 o;
+        const u32x4 w = __builtin_bit_cast(u32x4, v);
+        u32x4 o;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            float z = bf2f(v.v[k]) * a[k] + b[k];
-            if (apply_silu) z = silu_f(z);
-            o.v[k] = f2bf(z);
+        for (int k = 0; k < 4; k++) {
+            f2 z = unpack2(w.w[k]) * a[k] + b[k];
+            if (apply_silu) z = z * sigmoid2(z);
+            o.w[k] = pack2(z);
         }
-        yn[(size_t)p * vpp + tv] = o;
+        yn[(size_t)p * vpp + tv] = __builtin_bit_cast(bf16x8, o);
     };
     int p = p0 + tr;
     for (; p + (kUnroll - 1) * rows < p1; p += kUnroll * rows) {      // loads first: see gn_stats_kernel
@@ -207,26 +248,35 @@ __global__ void gn_apply_fp8_kernel(const bf16x8* __restrict__ x, uint2* __restr
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
     const int cg = C / G;
-    float a[8], b[8];
+    f2 a[4], b[4];
+    {
+        int g[8];
+        groups_of_vector(tv, cg, g);
+        float a1[8], b1[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int c = tv * 8 + k, g = c / cg;
-        const float mean = mean_rstd[((size_t)n * G + g) * 2];
-        const float rstd = mean_rstd[((size_t)n * G + g) * 2 + 1];
-        a[k] = rstd * bf2f(gamma[c]);
-        b[k] = bf2f(beta[c]) - mean * a[k];
+        for (int k = 0; k < 8; k++) {
+            const int c = tv * 8 + k;
+            const float mean = mean_rstd[((size_t)n * G + g[k]) * 2];
+            const float rstd = mean_rstd[((size_t)n * G + g[k]) * 2 + 1];
+            a1[k] = rstd * bf2f(gamma[c]);
+            b1[k] = bf2f(beta[c]) - mean * a1[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[k] = f2{a1[2 * k], a1[2 * k + 1]}; b[k] = f2{b1[2 * k], b1[2 * k + 1]}; }
     }
     const bf16x8* xn = x + (size_t)n * HW * vpp;
     uint2* yn = y + (size_t)n * HW * vpp;
     auto body = [&](const bf16x8& v, int p) {
+        const u32x4 w = __builtin_bit_cast(u32x4, v);
         float z[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            float t = bf2f(v.v[k]) * a[k] + b[k];
-            if (apply_silu) t = silu_f(t);
+        for (int k = 0; k < 4; k++) {
+            f2 t = unpack2(w.w[k]) * a[k] + b[k];
+            if (apply_silu) t = t * sigmoid2(t);
             // the bf16 rounding of the unfused path first (same values as gn_apply_kernel), then scale + saturate
-            const float zz = bf2f(f2bf(t)) * inv_scale;
-            z[k] = zz < -448.f ? -448.f : (zz > 448.f ? 448.f : zz);   // saturate; a NaN stays a NaN (fminf / fmaxf would hide it)
+            const f2 zz = unpack2(pack2(t)) * inv_scale;
+            z[2 * k] = zz.x < -448.f ? -448.f : (zz.x > 448.f ? 448.f : zz.x);   // saturate; a NaN stays a NaN
+            z[2 * k + 1] = zz.y < -448.f ? -448.f : (zz.y > 448.f ? 448.f : zz.y);
         }
         int o0 = 0, o1 = 0;
         o0 = __builtin_amdgcn_cvt_pk_fp8_f32(z[0], z[1], o0, false);
@@ -258,31 +308,36 @@ __global__ void gn_bwd_stats_kernel(const bf16x8* __restrict__ x, const bf16x8* 
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
     const int cg = C / G;
-    float mean[8], rstd[8], gm[8], bt[8], s1[8], s2[8];
+    f2 mean[4], rstd[4], gm[4], bt[4], q1[4], q2[4];
+    {
+        int g[8];
+        groups_of_vector(tv, cg, g);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int c = tv * 8 + k, g = c / cg;
-        mean[k] = mean_rstd[((size_t)n * G + g) * 2];
-        rstd[k] = mean_rstd[((size_t)n * G + g) * 2 + 1];
-        gm[k] = bf2f(gamma[c]);
-        bt[k] = bf2f(beta[c]);
-        s1[k] = s2[k] = 0.f;
+        for (int k = 0; k < 4; k++) {
+            const int c = tv * 8 + 2 * k;
+            mean[k] = f2{mean_rstd[((size_t)n * G + g[2 * k]) * 2], mean_rstd[((size_t)n * G + g[2 * k + 1]) * 2]};
+            rstd[k] = f2{mean_rstd[((size_t)n * G + g[2 * k]) * 2 + 1], mean_rstd[((size_t)n * G + g[2 * k + 1]) * 2 + 1]};
+            gm[k] = f2{bf2f(gamma[c]), bf2f(gamma[c + 1])};
+            bt[k] = f2{bf2f(beta[c]), bf2f(beta[c + 1])};
+            q1[k] = q2[k] = f2{0.f, 0.f};
+        }
     }
     const bf16x8* xn = x + (size_t)n * HW * vpp;
     const bf16x8* dn = dy + (size_t)n * HW * vpp;
     auto body = [&](const bf16x8& v, const bf16x8& d) {
+        const u32x4 wv = __builtin_bit_cast(u32x4, v), wd = __builtin_bit_cast(u32x4, d);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float xh = (bf2f(v.v[k]) - mean[k]) * rstd[k];
-            float dz = bf2f(d.v[k]);
+        for (int k = 0; k < 4; k++) {
+            const f2 xh = (unpack2(wv.w[k]) - mean[k]) * rstd[k];
+            f2 dz = unpack2(wd.w[k]);
             if (apply_silu) {
-                const float z = xh * gm[k] + bt[k];
-                const float sg = 1.f / (1.f + __expf(-z));
+                const f2 z = xh * gm[k] + bt[k];
+                const f2 sg = sigmoid2(z);
                 dz *= sg * (1.f + z * (1.f - sg));
             }
-            const float t = dz * gm[k];
-            s1[k] += t;
-            s2[k] += t * xh;
+            const f2 t = dz * gm[k];
+            q1[k] += t;
+            q2[k] += t * xh;
         }
     };
     int p = p0 + tr;
@@ -293,6 +348,9 @@ __global__ void gn_bwd_stats_kernel(const bf16x8* __restrict__ x, const bf16x8* 
         body(v1, d1);
     }
     for (; p < p1; p += rows) body(xn[(size_t)p * vpp + tv], dn[(size_t)p * vpp + tv]);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { s1[2 * k] = q1[k].x; s1[2 * k + 1] = q1[k].y; s2[2 * k] = q2[k].x; s2[2 * k + 1] = q2[k].y; }
     reduce_to_groups<1>(s1, s2, vpp, rows, tv, tr, C, G, N, n, (double)HW * cg, 0.f, ws, m12, lds);
 }
 
@@ -306,37 +364,43 @@ __global__ void gn_bwd_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* 
     const int tv = threadIdx.x % vpp, tr = threadIdx.x / vpp;
     const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
     const int cg = C / G;
-    float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
+    f2 mean[4], rstd[4], gm[4], bt[4], m1[4], m2[4];
+    {
+        int g[8];
+        groups_of_vector(tv, cg, g);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int c = tv * 8 + k, g = c / cg;
-        mean[k] = mean_rstd[((size_t)n * G + g) * 2];
-        rstd[k] = mean_rstd[((size_t)n * G + g) * 2 + 1];
-        gm[k] = bf2f(gamma[c]);
-        bt[k] = bf2f(beta[c]);
-        m1[k] = m12[((size_t)n * G + g) * 2];
-        m2[k] = m12[((size_t)n * G + g) * 2 + 1];
+        for (int k = 0; k < 4; k++) {
+            const int c = tv * 8 + 2 * k;
+            const size_t i0 = ((size_t)n * G + g[2 * k]) * 2, i1 = ((size_t)n * G + g[2 * k + 1]) * 2;
+            mean[k] = f2{mean_rstd[i0], mean_rstd[i1]};
+            rstd[k] = f2{mean_rstd[i0 + 1], mean_rstd[i1 + 1]};
+            gm[k] = f2{bf2f(gamma[c]), bf2f(gamma[c + 1])};
+            bt[k] = f2{bf2f(beta[c]), bf2f(beta[c + 1])};
+            m1[k] = f2{m12[i0], m12[i1]};
+            m2[k] = f2{m12[i0 + 1], m12[i1 + 1]};
+        }
     }
     const bf16x8* xn = x + (size_t)n * HW * vpp;
     const bf16x8* dn = dy + (size_t)n * HW * vpp;
     bf16x8* on = dx + (size_t)n * HW * vpp;
     const bf16x8* an = add ? add + (size_t)n * HW * vpp : nullptr;
     auto body = [&](const bf16x8& v, const bf16x8& d, const bf16x8& a, int p) {
-        bf16x8 o;
+        const u32x4 wv = __builtin_bit_cast(u32x4, v), wd = __builtin_bit_cast(u32x4, d), wa = __builtin_bit_cast(u32x4, a);
+        u32x4 o;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float xh = (bf2f(v.v[k]) - mean[k]) * rstd[k];
-            float dz = bf2f(d.v[k]);
+        for (int k = 0; k < 4; k++) {
+            const f2 xh = (unpack2(wv.w[k]) - mean[k]) * rstd[k];
+            f2 dz = unpack2(wd.w[k]);
             if (apply_silu) {
-                const float z = xh * gm[k] + bt[k];
-                const float sg = 1.f / (1.f + __expf(-z));
+                const f2 z = xh * gm[k] + bt[k];
+                const f2 sg = sigmoid2(z);
                 dz *= sg * (1.f + z * (1.f - sg));
             }
-            float r = rstd[k] * (dz * gm[k] - m1[k] - xh * m2[k]);
-            if (an) r += bf2f(a.v[k]);   // the other gradient arriving at this tensor (a ResnetBlock's skip path)
-            o.v[k] = f2bf(r);
+            f2 r = rstd[k] * (dz * gm[k] - m1[k] - xh * m2[k]);
+            if (an) r += unpack2(wa.w[k]);   // the other gradient arriving at this tensor (a ResnetBlock's skip path)
+            o.w[k] = pack2(r);
         }
-        on[(size_t)p * vpp + tv] = o;
+        on[(size_t)p * vpp + tv] = __builtin_bit_cast(bf16x8, o);
     };
     int p = p0 + tr;
     for (; p + rows < p1; p += 2 * rows) {      // four to six independent loads in flight per thread (see gn_stats_kernel)
