@@ -35,6 +35,9 @@
 //     cycles, two every 5.8, four every 5.0).
 #include "raster_common.h"
 
+#ifndef GD_BWD_CUT
+#define GD_BWD_CUT 12     // cut a window when its fullest block list overshoots a multiple of 16 by <= this many entries (0 = never)
+#endif
 #ifndef GD_BWD_ABLATE
 #define GD_BWD_ABLATE 0   // tools/raster_ab.sh builds only (wrong results): 1 = no chunk loop, 2 = no pixel loop, 3 = no row adds,
                           // 4 = 1 + no gathers, 5 = 1 + no row stores, 6 = 4 + 5
@@ -142,10 +145,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         return e;
     };
     uint4 ent_next = load_entries(0);
-    for (uint32_t w0 = 0; w0 < n_listed; w0 += kWin) {
+    for (uint32_t w0 = 0; w0 < n_listed;) {
         const uint4 ent = ent_next;
-        const bool have = w0 + lane < n_listed;
-        const uint32_t nwin = min((uint32_t)kWin, n_listed - w0);
+        // per-block lists of the window (ranked by lane: still back to front).  The four rows run in lockstep over
+        // max_b ceil(n_b / 16) chunks of 16 entries, so a window whose fullest block spills a few entries into a new
+        // chunk is CUT where that block reaches a multiple of 16 (the rest opens the next window): chunks stay full.
+        uint32_t subs[4], ranks[4];
+        uint64_t masks[4];
+        uint32_t nfull = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            subs[b] = ((b < 2 ? ent.x : ent.y) >> (16 * (b & 1))) & 0xffffu;
+            masks[b] = __builtin_amdgcn_ballot_w64(subs[b] != 0u);
+            ranks[b] = __builtin_amdgcn_mbcnt_hi((uint32_t)(masks[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)masks[b], 0u));
+            nfull = max(nfull, (uint32_t)__builtin_popcountll(masks[b]));
+        }
+        uint32_t cut = kWin;
+        {
+            const uint32_t r = nfull & 15u;
+            if (GD_BWD_CUT && nfull > 16u && r != 0u && r <= GD_BWD_CUT) {
+                const uint32_t target = nfull - r;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint64_t over = __builtin_amdgcn_ballot_w64(subs[b] != 0u && ranks[b] >= target);
+                    if (over) cut = min(cut, (uint32_t)__builtin_ctzll(over));
+                }
+            }
+        }
+        const uint64_t keep = cut >= 64u ? ~0ull : ((1ull << cut) - 1ull);
+        const uint32_t nwin = min(cut, n_listed - w0);
+        const bool have = lane < nwin;
+        ent_next = load_entries(w0 + nwin);
         if (have) {
             const bool gather = !(GD_BWD_ABLATE == 4 || GD_BWD_ABLATE == 6);
             const float2 xy = gather ? means2D[ent.z] : make_float2(1.f, 2.f);
@@ -156,18 +186,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             reinterpret_cast<float4*>(er)[1] = make_float4(co.z, co.w, fd.x, fd.y);
             reinterpret_cast<float4*>(er)[2] = make_float4(fd.z, fd.w, __uint_as_float(ent.x), __uint_as_float(ent.y));
         }
-        ent_next = load_entries(w0 + kWin);
-        // per-block lists of the window (ranked by lane: still back to front)
         uint32_t nb[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const uint32_t sub = ((b < 2 ? ent.x : ent.y) >> (16 * (b & 1))) & 0xffffu;
-            const uint64_t m = __builtin_amdgcn_ballot_w64(sub != 0u);
-            if (sub != 0u) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                s_sub[b][rank] = (uint8_t)lane;
-            }
-            nb[b] = (uint32_t)__builtin_popcountll(m);
+            if (subs[b] != 0u && lane < cut) s_sub[b][ranks[b]] = (uint8_t)lane;
+            nb[b] = (uint32_t)__builtin_popcountll(masks[b] & keep);
         }
         const uint32_t nmax = max(max(nb[0], nb[1]), max(nb[2], nb[3]));
         const uint32_t my_n = blk == 0 ? nb[0] : blk == 1 ? nb[1] : blk == 2 ? nb[2] : nb[3];
@@ -192,7 +215,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const float ca = r0.z, cb = r0.w, cc = r1.x, op = r1.y;
             const float c0 = r1.z, c1 = r1.w, c2 = r2.x, c3 = r2.y;
             // tables of the 4x4 block in the forward pass's operation order (forward.cu:341): d = centre - pixel,
-            // t1 = (a dx) dx, bdx = b dx, t2 = (c dy) dy, each product rounded on its own
+            // t1 = (a dx) dx, bdx = b dx, t2 = (c dy) dy, each product rounded on its own.  (Folding -0.5 log2(e) into
+            // the tables saves two packed instructions per pixel pair -- 3 % of the kernel -- but re-associates power:
+            // needle-shaped splats, whose terms cancel to a few ulps, then fail the parity test.)
             f2 dxp[2], t1p[2], bdxp[2];
             {
 #pragma clang fp contract(off)
@@ -298,6 +323,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             dst[4] = make_float2(v[8], v[9]);
         }
         __builtin_amdgcn_wave_barrier();
+        w0 += nwin;
     }
 }
 
