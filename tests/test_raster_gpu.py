@@ -132,6 +132,49 @@ def test_backward_parity(P, HW, deg):
         _check_grads(n, g, ref[n], case=f"backward P={P} {HW}^2 SH{deg} (GPU alpha)")
 
 
+def _backward_vs_oracle(inp, case, seed=1, **tol):
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    from oracle import gd_oracle
+    st = h.oracle_forward(inp)
+    H, W = inp["image_height"], inp["image_width"]
+    rng = np.random.default_rng(seed)
+    gc, gd, ga = (rng.normal(size=(3, H, W)).astype(np.float32), rng.normal(size=(1, H, W)).astype(np.float32),
+                  rng.normal(size=(1, H, W)).astype(np.float32))
+    ref = gd_oracle.backward(st, gc, gd, ga)
+    args, out = _run_gpu_forward(inp)
+    _check_forward(inp, st, out)
+    R, color, depth, alpha, radii, geom, binning, img = out
+    t = lambda a: torch.as_tensor(a, device=DEV)
+    (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H_, W_, sh, degree, campos, _, _) = args
+    grads = [_C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
+                                             t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha, False)
+             for _ in range(2)]
+    torch.cuda.synchronize()
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations")
+    for n, g, g2 in zip(names, grads[0], grads[1]):
+        assert torch.equal(g, g2), f"{n}: the backward pass is not bitwise reproducible"
+        _check_grads(n, g, ref[n], case=case, **tol)
+    return st
+
+
+def test_backward_parity_ragged_image():
+    """W, H not multiples of 16: strips and 4x4 blocks that hang over both image edges (their pixels never blend and
+    must stay out of every scan and sum)."""
+    _backward_vs_oracle(h.raster_inputs(P=3000, H=75, W=117, seed=3), "backward ragged 117x75")
+
+
+def test_backward_long_lists_saturated_pixels():
+    """Large opaque splats: thousands of entries per tile, most pixels saturate -- the backward blend walks many
+    windows of 64 strip entries and chunks of 16 per block, so the T / U carries between chunks and windows, the
+    window cut and the T_final = 1 - alpha quirk of saturated pixels (backward.cu:463) all carry weight.  A saturated
+    pixel turns one ulp of alpha into 6e-4 of every term, hence the wider relative bar; the forward pass is bit-exact,
+    so the GPU's alpha image is the oracle's."""
+    inp = h.raster_inputs(P=4000, H=128, W=128, seed=5, scale_mul=8.0)
+    st = _backward_vs_oracle(inp, "backward big splats 4000 x8 scale 128^2", rtol=2e-3, atol_scale=2e-5)
+    assert st.num_rendered > 20 * 4000 / 4 and (st.n_contrib > 64).mean() > 0.2
+
+
 def _needle_inputs(P, HW, seed):
     """Strongly anisotropic splats (axis ratio up to ~60:1, random orientation) with opacities down to the
     1/255 threshold: the hard case for the render kernels' per-strip reachability test (a needle that
