@@ -555,6 +555,15 @@ class LoraUNet2DConditionModel(UNet2DConditionModel):
             if isinstance(m, Attention):
                 self.lora_layers.append(m.add_lora(rank))
 
+    def adapters_to_fp32(self):
+        """Keep the trainable rank-4 adapters (and so the whole LoRA branch: ``LoRALinearLayer.forward`` computes in its
+        weights' dtype) in fp32 while the frozen base runs bf16.  The reference trains them in fp32
+        (sd_vsd_utils.py:35); an adapter gradient is a sum over all tokens that cancels to ~1e-3 of its terms, so bf16
+        intermediates (the rank-4 activations, the gradient GEMM's output) leave mostly rounding noise in it.  The
+        branch is [tokens, C] x [C, 4]: its fp32 cost is negligible."""
+        self.lora_layers.float()
+        return self
+
     def freeze_base(self):
         for p in self.parameters():
             p.requires_grad_(False)

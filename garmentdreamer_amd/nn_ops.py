@@ -450,11 +450,16 @@ def gn_conv3x3(x, norm_weight, norm_bias, groups: int, eps: float, silu: bool, w
     return _GNConv3x3.apply(x, norm_weight, norm_bias, groups, eps, silu, w, bias, residual)
 
 
+_GN_FUSED_OVERRIDE = {"0": False, "1": True}.get(os.environ.get("GD_NN_GN_FUSED", ""))
+
+
 def gn_conv_prefers_fused(x, out_channels: int) -> bool:
     """The largest feature maps (the VAE encoder's 512^2 and 256^2 levels) run GroupNorm + SiLU inside the
     patch-staged convolution's activation loader (1.07-1.17x faster than GroupNorm kernel + convolution on MI355X,
     tools/gn_conv_bench.py); on 128^2 and smaller maps, or below ~1.5 waves of workgroups (one per image, 16x16
     patch, 128/256-channel slab), the GroupNorm kernel + the persistent plain convolution is faster (0.95x)."""
+    if _GN_FUSED_OVERRIDE is not None:      # GD_NN_GN_FUSED=0/1: A/B timing of the routing rule (tools/, never set in tests)
+        return _GN_FUSED_OVERRIDE
     bn = 256 if out_channels % 256 == 0 else 128
     wgs = x.shape[0] * -(-x.shape[2] // 16) * -(-x.shape[3] // 16) * -(-out_channels // bn)
     return x.shape[2] * x.shape[3] >= 256 * 256 and wgs >= 384

@@ -206,7 +206,7 @@ def test_config3_two_ranks_share_one_gpu_real_rasterizer_matches_single_rank(tmp
     assert float(d.max()) < 0.11
 
 
-def _vsd_objects(kw_unet, kw_vae, dtype, graphs=False, **gd_kw):
+def _vsd_objects(kw_unet, kw_vae, dtype, graphs=False, fp32_adapters=True, **gd_kw):
     from garmentdreamer_amd.guidance import sd21
     from garmentdreamer_amd.guidance.sd_vsd import LoraUnet, StableDiffusionVSD
     with torch.device(DEV):
@@ -215,6 +215,8 @@ def _vsd_objects(kw_unet, kw_vae, dtype, graphs=False, **gd_kw):
         lora = sd21.init_random_(sd21.LoraUNet2DConditionModel(**kw_unet), 2)
     gd = StableDiffusionVSD(DEV, fp16=dtype == torch.bfloat16, unet=unet, vae=vae, use_hip_graphs=graphs, **gd_kw)
     lora = lora.to(dtype).to(memory_format=torch.channels_last)
+    if dtype == torch.bfloat16 and fp32_adapters:
+        lora.adapters_to_fp32()
     train = lora.freeze_base()
     return gd, lora, train, LoraUnet(lora)
 

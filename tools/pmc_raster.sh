@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the rasterizer's render kernels on the benchmark workload (raster-only, 8 views x 512^2, 100k):
-#   tools/pmc_raster.sh <out.txt>   [env GD_RASTER_BWD_IMPL / GD_RASTER_BWD_ABLATE are passed through]
+#   tools/pmc_raster.sh <out.txt>   [GD_RASTER_LIB=<other build> is passed through]
 out=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 : > $out
