@@ -186,6 +186,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     const size_t HW = (size_t)H * W;
     const size_t pix_id = (size_t)W * py + px;
     const float pixf_x = (float)px, pixf_y = (float)py;
+    const float __attribute__((ext_vector_type(2))) pixf = {pixf_x, pixf_y};
 
     bool done = !inside;
     const uint2 range = ranges[tile];
@@ -200,7 +201,12 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     // contributor = entries walked while the pixel was live (forward.cu:336): the whole list unless the pixel
     // saturates at entry g, then g + 1
     uint32_t contributor = (uint32_t)total, last_contributor = 0, blended = 0;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f;
+    // two-wide arithmetic where the operands sit in register pairs anyway (xy, conic a|c, colour rg|bd): v_pk_mul_f32 /
+    // v_pk_add_f32 round each half exactly like the scalar instruction at ~0.6 of the issue time (the kernel is
+    // VALU-issue bound); contraction stays off, so no half is ever fused
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 C01 = {0.f, 0.f}, C2D = {0.f, 0.f};
+    float weight = 0.f;
     // compact list of this wave's strip: region [4 range.x + wave * total, + total) of clist, filled in list order
     const uint32_t my_base = range.x * 4u + wave * (uint32_t)total;
     uint4* const my_list = clist + my_base;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
             const float2 xy = means2D[id];
             s_xy[tid] = xy;
             const float4 c4 = conic_opacity[id];
-            s_co[tid] = c4;
+            s_co[tid] = make_float4(c4.x, c4.z, c4.y, c4.w);     // (a, c | b, opacity): a|c pairs with dx|dy
             const float thr = alpha_threshold_exact(c4.w);
             s_thr[tid] = thr;
             s_fd[tid] = rgbd[id];
@@ -240,9 +246,10 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
                 bool blend = false;
                 if (!done) {
                     const float2 xy = s_xy[j];
-                    const float dx = xy.x - pixf_x, dy = xy.y - pixf_y;
-                    const float4 co = s_co[j];
-                    const float power = power_exact(mul_rn(mul_rn(co.x, dx), dx), mul_rn(co.y, dx), co.z, dy);
+                    const float4 co = s_co[j];                       // a, c, b, opacity
+                    const f2 d = f2{xy.x, xy.y} - pixf;               // (dx, dy)
+                    const f2 t12 = (f2{co.x, co.y} * d) * d;          // ((a dx) dx, (c dy) dy), forward.cu:341's order
+                    const float power = fmaf(-0.5f, add_rn(t12.x, t12.y), -mul_rn(mul_rn(co.z, d.x), d.y));
                     // alpha >= 1/255  <=>  power >= s_thr (exact, alpha_threshold_exact): only contributing pairs pay
                     // for the exponential
                     if (!(power > 0.0f) && !(power < s_thr[j])) {
@@ -255,11 +262,9 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
                                 contributor = cbase + (uint32_t)j + 1u;
                             } else {
                                 const float4 fd = s_fd[j];
-                                C0 = add_rn(C0, mul_rn(mul_rn(fd.x, alpha), T));
-                                C1 = add_rn(C1, mul_rn(mul_rn(fd.y, alpha), T));
-                                C2 = add_rn(C2, mul_rn(mul_rn(fd.z, alpha), T));
+                                C01 = C01 + ((f2{fd.x, fd.y} * alpha) * T);
+                                C2D = C2D + ((f2{fd.z, fd.w} * alpha) * T);
                                 weight = add_rn(weight, mul_rn(alpha, T));
-                                Dd = add_rn(Dd, mul_rn(mul_rn(fd.w, alpha), T));
                                 T = test_T;
                                 last_contributor = cbase + (uint32_t)j + 1u;
                                 blended++;
@@ -295,11 +300,11 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
         n_contrib[(size_t)view * HW + pix_id] = last_contributor;
         pair_counts[(size_t)view * HW + pix_id] = make_uint2(contributor, blended);
         float* oc = out_color + (size_t)view * 3 * HW;
-        oc[0 * HW + pix_id] = add_rn(C0, mul_rn(T, bg_color[0]));
-        oc[1 * HW + pix_id] = add_rn(C1, mul_rn(T, bg_color[1]));
-        oc[2 * HW + pix_id] = add_rn(C2, mul_rn(T, bg_color[2]));
+        oc[0 * HW + pix_id] = add_rn(C01.x, mul_rn(T, bg_color[0]));
+        oc[1 * HW + pix_id] = add_rn(C01.y, mul_rn(T, bg_color[1]));
+        oc[2 * HW + pix_id] = add_rn(C2D.x, mul_rn(T, bg_color[2]));
         out_alpha[(size_t)view * HW + pix_id] = weight;
-        out_depth[(size_t)view * HW + pix_id] = Dd;
+        out_depth[(size_t)view * HW + pix_id] = C2D.y;
     }
 }
 
