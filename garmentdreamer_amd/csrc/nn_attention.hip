@@ -6,10 +6,11 @@
 // (double buffered, source-side XOR swizzle -> conflict-free ds_read_b128 fragments).  Scores are computed
 // TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_bf16 with K as the A operand), so a lane holds 32 scores of ONE
 // query: the row maximum / sum are in-lane loops plus a single cross-half exchange, and exp2 / rescaling never
-// leave the lane.  The same registers, packed to bf16, ARE the B operand of O^T += V^T P^T -- the PV product's
-// key order is simply defined by the accumulator layout ({0-3, 8-11} + 4*(lane>>5) within each 16 keys), and
-// the V^T tile is stored with that order baked in (attn_vt_kernel), so one ds_read_b128 yields a lane's eight
-// keys.  No shuffles, no LDS round trip for P.
+// leave the lane.  The same registers, packed to bf16, ARE the B operand of O^T += V^T P^T.  The accumulator layout
+// gives lane half fh the score rows {0-3, 8-11} + 4 fh of every 16: round 3 reads the K fragment's row
+// pi(i) = {0-3, 8-11, 4-7, 12-15}[i] instead of i (a different LDS address, nothing else), so those registers hold keys
+// 8 fh .. 8 fh + 7 in order and V^T is consumed in NATURAL key order -- it can come straight from a GEMM
+// (W_v x^T, gd_nn_attention_d64_forward_vt) instead of a transposing pre-pass.  No shuffles, no LDS round trip for P.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -53,8 +54,8 @@ __device__ __forceinline__ void bload_lds16(__amdgpu_buffer_rsrc_t rsrc, uint32_
 constexpr int kTk = 64, kD = 64;
 constexpr int kTile = kTk * kD * 2;   // 8 KB
 
-// V [B][Skv][H*64] (row stride v_rs elements)  ->  Vt [B][H][64][Skv] with the keys of every 16-group stored in
-// the order {0,1,2,3, 8,9,10,11, 4,5,6,7, 12,13,14,15} (see the header).  64 keys x 64 d per workgroup through LDS.
+// V [B][Skv][H*64] (row stride v_rs elements)  ->  Vt [B][H][64][Skv], keys in natural order, padded keys zero.
+// 64 keys x 64 d per workgroup through LDS.  (Only for callers that hold V row-major: the cross-attention's K / V.)
 __global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, int Skv,
                                                       int H, int64_t v_bs, int v_rs, int kv_len)
 {
@@ -69,9 +70,7 @@ __global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict
     uint16_t* dst = vt + (((int64_t)b * H + h) * 64) * Skv + k0;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int d = i >> 6, pos = i & 63;
-        const int p16 = pos & 15;
-        const int key16 = p16 < 4 ? p16 : (p16 < 8 ? p16 + 4 : (p16 < 12 ? p16 - 4 : p16));
-        dst[(int64_t)d * Skv + pos] = tile[(pos & ~15) + key16][d];
+        dst[(int64_t)d * Skv + pos] = tile[pos][d];
     }
 }
 
@@ -133,7 +132,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
     uint32_t krd[2], vrd[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        krd[j] = (uint32_t)swz(32 * j + fn, fh);       // K fragment of key block j, kk = 0 (kk: slot ^ 2kk)
+        // K fragment of key block j, kk = 0 (kk: slot ^ 2kk); accumulator row fn <- key pi(fn) (see the header)
+        const int p16 = fn & 15, key16 = p16 < 4 ? p16 : (p16 < 8 ? p16 + 4 : (p16 < 12 ? p16 - 4 : p16));
+        krd[j] = (uint32_t)swz(32 * j + (fn & 16) + key16, fh);
         vrd[j] = (uint32_t)swz(32 * j + fn, fh);       // V^T fragment of d block j, 16-key group 0
     }
     // S^T tile of 64 keys x 32 queries (two 32x32 accumulators) from the K stage at `pk`
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
         if ((tile + 1) * kTk > kv_len) {      // last tile of a key count that is not a multiple of 64 (cross-attention:
 #pragma unroll                                   // 77 text tokens): padded keys get no weight
             for (int r = 0; r < 16; r++) {
-                const int key = tile * kTk + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                // accumulator row (r & 3) + 8 (r >> 2) + 4 fh holds key pi(row) = 16 (r >> 3) + 8 fh + 4 ((r >> 2) & 1) + (r & 3)
+                const int key = tile * kTk + 16 * (r >> 3) + 8 * fh + 4 * ((r >> 2) & 1) + (r & 3);
                 if (key >= kv_len) s0[r] = -INFINITY;
                 if (key + 32 >= kv_len) s1[r] = -INFINITY;
             }
@@ -269,33 +271,54 @@ const char* gd_nn_attention_last_error(void) { return g_err; }
 
 size_t gd_nn_attention_ws_bytes(int B, int Skv, int H) { return (size_t)B * H * 64 * (size_t)Skv * 2; }
 
-int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, const void* v, void* o, void* vt_ws, int B, int S,
-                                int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs, int v_rs,
-                                int64_t o_bs, int o_rs, float scale, int kv_len)
+static int launch_attention(hipStream_t s, const void* q, const void* k, const void* vt, void* o, int B, int S, int Skv, int H,
+                            int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t o_bs, int o_rs, float scale, int kv_len)
 {
-    if (!q || !k || !v || !o || !vt_ws) return fail(GD_NN_ERR_INVALID_ARG, "attention: null pointer");
-    if (B <= 0 || S <= 0 || H <= 0 || Skv <= 0 || Skv % 64 || kv_len <= Skv - 64 || kv_len > Skv)
-        return fail(GD_NN_ERR_INVALID_ARG, "attention: need Skv % 64 == 0 and Skv - 64 < kv_len <= Skv (head_dim is 64)");
-    if (q_rs % 8 || k_rs % 8 || o_rs % 4 || (double)Skv * k_rs * 2.0 >= 2147483648.0)
-        return fail(GD_NN_ERR_INVALID_ARG, "attention: row strides must keep 16-byte (q, k) / 8-byte (o) alignment");
-    hipStream_t s = (hipStream_t)stream;
     if (const char* e = getenv("GD_NN_ATTN_WAVES")) g_attn_waves = atoi(e);
-    hipLaunchKernelGGL(attn_vt_kernel, dim3(Skv / 64, H, B), dim3(256), 0, s, (const uint16_t*)v, (uint16_t*)vt_ws, Skv, H,
-                       v_bs, v_rs, kv_len);
     const float c = scale * 1.4426950408889634f;
     int waves = 4;     // 8 waves per workgroup measured the same at batch 16 and worse on small grids (tools/attn_bench.py)
     if (g_attn_waves == 4 || g_attn_waves == 8) waves = g_attn_waves;
     if (waves == 8)
         hipLaunchKernelGGL(attn_fwd_d64_kernel<8>, dim3((S + 255) / 256, B * H), dim3(512), 6 * kTile, s, (const uint16_t*)q,
-                           (const uint16_t*)k, (const uint16_t*)vt_ws, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
+                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
                            o_rs, c, kv_len);
     else
         hipLaunchKernelGGL(attn_fwd_d64_kernel<4>, dim3((S + 127) / 128, B * H), dim3(256), 6 * kTile, s, (const uint16_t*)q,
-                           (const uint16_t*)k, (const uint16_t*)vt_ws, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
+                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
                            o_rs, c, kv_len);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
+}
+
+static int check_attention(const void* q, const void* k, const void* v, const void* o, int B, int S, int Skv, int H, int q_rs,
+                           int k_rs, int o_rs, int kv_len)
+{
+    if (!q || !k || !v || !o) return fail(GD_NN_ERR_INVALID_ARG, "attention: null pointer");
+    if (B <= 0 || S <= 0 || H <= 0 || Skv <= 0 || Skv % 64 || kv_len <= Skv - 64 || kv_len > Skv)
+        return fail(GD_NN_ERR_INVALID_ARG, "attention: need Skv % 64 == 0 and Skv - 64 < kv_len <= Skv (head_dim is 64)");
+    if (q_rs % 8 || k_rs % 8 || o_rs % 4 || (double)Skv * k_rs * 2.0 >= 2147483648.0)
+        return fail(GD_NN_ERR_INVALID_ARG, "attention: row strides must keep 16-byte (q, k) / 8-byte (o) alignment");
+    return GD_NN_OK;
+}
+
+int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, const void* v, void* o, void* vt_ws, int B, int S,
+                                int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs, int v_rs,
+                                int64_t o_bs, int o_rs, float scale, int kv_len)
+{
+    if (!vt_ws) return fail(GD_NN_ERR_INVALID_ARG, "attention: null pointer");
+    if (int e = check_attention(q, k, v, o, B, S, Skv, H, q_rs, k_rs, o_rs, kv_len)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_vt_kernel, dim3(Skv / 64, H, B), dim3(256), 0, s, (const uint16_t*)v, (uint16_t*)vt_ws, Skv, H,
+                       v_bs, v_rs, kv_len);
+    return launch_attention(s, q, k, vt_ws, o, B, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs, o_rs, scale, kv_len);
+}
+
+int gd_nn_attention_d64_forward_vt(void* stream, const void* q, const void* k, const void* vt, void* o, int B, int S, int Skv,
+                                   int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t o_bs, int o_rs, float scale)
+{
+    if (int e = check_attention(q, k, vt, o, B, S, Skv, H, q_rs, k_rs, o_rs, Skv)) return e;
+    return launch_attention((hipStream_t)stream, q, k, vt, o, B, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs, o_rs, scale, Skv);
 }
 
 }  // extern "C"

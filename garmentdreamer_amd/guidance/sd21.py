@@ -34,7 +34,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, conv1x1, conv3x3, conv3x3_s2, conv3x3_s2_supported, conv3x3_small_cin,
+from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, attention_d64_vt, conv1x1, conv3x3, conv3x3_s2, conv3x3_s2_supported, conv3x3_small_cin,
                       conv3x3_supported, geglu, gn_conv3x3, gn_conv3x3_supported, gn_conv_prefers_fused, group_norm_silu,
                       resnet_block_frozen, resnet_block_frozen_supported, upsample2x_conv3x3,
                       upsample2x_conv3x3_supported)
@@ -43,6 +43,7 @@ from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, co
 import os as _os
 
 _FUSED_QKV = _os.environ.get("GD_FUSED_QKV", "1") != "0"   # A/B toggle of the fused self-attention projection
+_VT_GEMM = _os.environ.get("GD_VT_GEMM", "1") != "0"         # A/B toggle: V^T from a GEMM instead of the transposing pre-pass
 _FP8_ACTIVE = [None]   # the nn_ops.Fp8State of the UNet whose no-grad forward is running (set by its forward)
 
 
@@ -201,13 +202,22 @@ class Attention(nn.Module):
             q, (k, v) = self.to_q(x), kv
         elif _FUSED_QKV and context is None and self.lora is None and x.is_cuda and self.to_q.bias is None and \
                 not self.to_q.weight.requires_grad and not torch.is_grad_enabled():
-            # frozen self-attention: ONE [C, 3C] projection; the attention kernel reads the three strided views
+            # frozen self-attention: ONE [C, 2C] projection for q | k (the attention kernel reads the two strided views)
+            # and V TRANSPOSED straight from a GEMM, W_v x^T = [B, C, N] -- the layout the kernel's P V product consumes
+            # (round 3: its K fragment rows are permuted instead of V^T's keys), so no transposing pre-pass runs
             src = (self.to_q.weight.data_ptr(), self.to_q.weight._version, self.to_k.weight._version,
                    self.to_v.weight._version, x.dtype)
             if getattr(self, "_wqkv_src", None) != src:
-                self._wqkv = torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], dim=0).detach().contiguous()
+                self._wqk = torch.cat([self.to_q.weight, self.to_k.weight], dim=0).detach().contiguous()
                 self._wqkv_src = src
-            q, k, v = F.linear(x, self._wqkv).chunk(3, dim=-1)
+            q, k = F.linear(x, self._wqk).chunk(2, dim=-1)
+            q = q.view(B, N, self.heads, -1)
+            k = k.view(B, N, self.heads, -1)
+            if _VT_GEMM and N % 64 == 0 and N >= 256 and q.shape[-1] == 64 and x.dtype == torch.bfloat16:
+                vt = torch.matmul(self.to_v.weight.detach(), x.transpose(1, 2))      # [B, C, N]
+                return self.to_out[0](attention_d64_vt(q, k, vt))
+            v = self.to_v(x)
+            q, k = q.reshape(B, N, -1), k.reshape(B, N, -1)
         else:
             q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         if self.lora is not None:

@@ -46,6 +46,8 @@ SIGNATURES = {
     "gd_nn_attention_ws_bytes": (C.c_size_t, [_i, _i, _i]),
     "gd_nn_attention_d64_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i,
                                          C.c_int64, _i, C.c_int64, _i, _f, _i]),
+    "gd_nn_attention_d64_forward_vt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i, C.c_int64, _i,
+                                            _f]),
     "gd_nn_attention_last_error": (C.c_char_p, []),
     "gd_nn_vae_prologue_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_vae_prologue_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
@@ -761,6 +763,23 @@ def attention_d64(q, k, v):
                                             64 ** -0.5, kv_len)
     if ret < 0:
         raise RuntimeError(f"gd_nn_attention_d64_forward failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
+    return o
+
+
+def attention_d64_vt(q, k, vt):
+    """The same kernel with V already transposed: ``vt`` = [B, H*64, Skv] contiguous bf16 (= W_v @ x^T), Skv % 64 == 0.
+    q, k: [B, S, H, 64] views as in ``attention_d64``."""
+    B, S, H, _ = q.shape
+    Skv = k.shape[1]
+    assert vt.shape == (B, H * 64, Skv) and vt.is_contiguous() and vt.dtype == torch.bfloat16 and Skv % 64 == 0
+    L = lib()
+    o = torch.empty((B, S, H * 64), dtype=torch.bfloat16, device=q.device)
+    with torch.cuda.device(q.device):
+        ret = L.gd_nn_attention_d64_forward_vt(torch.cuda.current_stream(q.device).cuda_stream, q.data_ptr(), k.data_ptr(),
+                                               vt.data_ptr(), o.data_ptr(), B, S, Skv, H, q.stride(0), q.stride(1),
+                                               k.stride(0), k.stride(1), o.stride(0), o.stride(1), 64 ** -0.5)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_attention_d64_forward_vt failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
     return o
 
 

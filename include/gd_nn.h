@@ -160,6 +160,11 @@ size_t gd_nn_attention_ws_bytes(int B, int Skv, int H);
 int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, const void* v, void* o, void* vt_ws, int B, int S,
                                 int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs, int v_rs,
                                 int64_t o_bs, int o_rs, float scale, int kv_len);
+/* The same kernel for a caller that already holds V TRANSPOSED: vt = [B][H][64][Skv] contiguous bf16, keys in natural
+ * order, all Skv keys valid (Skv % 64 == 0) -- e.g. the output of the GEMM  W_v x^T, which replaces the V projection
+ * AND the transposing pre-pass of the entry above. */
+int gd_nn_attention_d64_forward_vt(void* stream, const void* q, const void* k, const void* vt, void* o, int B, int S, int Skv,
+                                   int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t o_bs, int o_rs, float scale);
 const char* gd_nn_attention_last_error(void);
 
 /* The guidance's image prologue as ONE kernel each way (threestudio stable_diffusion_guidance.py:394-396 + :164):

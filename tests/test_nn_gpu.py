@@ -509,6 +509,13 @@ def test_attention_d64_matches_fp32_reference(B, H, S):
     err = (out.float() - ref).abs().max().item()
     assert err <= 2e-2 * ref.abs().max().item() + 2e-3, err          # bf16 P and bf16 output
     assert F.cosine_similarity(out.float().flatten(), ref.flatten(), dim=0).item() > 0.9995
+    if S % 64 == 0:
+        # the entry that takes V already transposed ([B, H*64, S], e.g. W_v x^T from a GEMM): the same bits
+        from garmentdreamer_amd.nn_ops import attention_d64_vt
+        vt = v.reshape(B, S, H * 64).transpose(1, 2).contiguous()
+        with torch.no_grad():
+            out_vt = attention_d64_vt(q, k, vt)
+        assert torch.equal(out_vt, out)
 
 
 def test_full_size_sds_steps_stay_finite_with_hip_graphs():
