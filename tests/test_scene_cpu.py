@@ -131,7 +131,11 @@ def test_densify_clone_split_prune_bookkeeping():
     xyz_before = m._xyz.data.clone()
     ea_before = m._group_views(m._exp_avg)["xyz"].clone()
     g = torch.Generator().manual_seed(0)
-    m.densify_and_prune(max_grad=0.5, min_opacity=0.005, extent=extent, max_screen_size=None, generator=g)
+    # CPU: the op-for-op statement of the reference's sequence (the product path is two HIP passes and has no CPU form;
+    # tests/test_scene_gpu.py holds it against this statement on the GPU)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.densify_and_prune(max_grad=0.5, min_opacity=0.005, extent=extent, max_screen_size=None, generator=g)
+    m.densify_and_prune_torch(max_grad=0.5, min_opacity=0.005, extent=extent, max_screen_size=None, generator=g)
     # 40 + 10 clones + (5 split -> 10 new - 5 removed) - 3 pruned = 52
     assert m._xyz.shape[0] == 52
     for t in (m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation):
