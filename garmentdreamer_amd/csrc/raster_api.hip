@@ -457,6 +457,12 @@ int gd_raster_blend_exp(void* stream, const float* x, float* y, int n)
     return hipGetLastError() == hipSuccess ? GD_OK : GD_ERR_HIP;
 }
 
+int gd_raster_poison_lds(void* stream)
+{
+    launch_poison_lds((hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? GD_OK : GD_ERR_HIP;
+}
+
 int gd_raster_sort_bits(int width, int height, int V)
 {
     const Dims d = make_dims(width, height, V < 1 ? 1 : V);

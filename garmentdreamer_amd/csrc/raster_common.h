@@ -109,6 +109,7 @@ void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* 
                         uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of);
 
 void launch_blend_exp(hipStream_t s, const float* x, float* y, int n);   // y = gd_expf(x): parity test hook
+void launch_poison_lds(hipStream_t s);                                   // NaN patterns into every CU's LDS: test hook
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
                            float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts,

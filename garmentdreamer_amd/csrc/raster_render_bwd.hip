@@ -204,8 +204,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uint32_t e_next = (li < my_n) ? s_sub[blk][li] : 0xffu;
         for (uint32_t k0 = 0; k0 < ((GD_BWD_ABLATE == 1 || GD_BWD_ABLATE >= 4) ? 0u : nmax); k0 += 16u) {
             // ---- lane (block, i): entry k0 + i of the block's list; an empty lane is an entry nobody blended ----
-            const uint32_t e = e_next & 63u;
+            // an empty lane computes on entry 0 of the window (always present and finite) with an all-zero pixel mask:
+            // its alpha is 0 and it adds exact zeros to both scans.  It must NOT read a table row nobody wrote -- LDS
+            // left over from another workgroup can hold NaN bit patterns, and 0 * NaN would poison the row's sum scan.
             const bool filled = e_next != 0xffu;
+#ifdef GD_BWD_TEST_UNINIT_ROW       // tools/ builds only: the defect tests/test_raster_gpu.py's LDS poisoning must catch
+            const uint32_t e = e_next & 63u;
+#else
+            const uint32_t e = filled ? (e_next & 63u) : 0u;
+#endif
             const float* er = &s_ent[e][0];
             const float4 r0 = reinterpret_cast<const float4*>(er)[0], r1 = reinterpret_cast<const float4*>(er)[1],
                          r2 = reinterpret_cast<const float4*>(er)[2];
@@ -327,7 +334,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
+// Test hook: leaves NaN bit patterns in the LDS of every CU (LDS is not cleared between workgroups), so that a
+// kernel that reads a shared-memory cell it never wrote is caught by the parity tests instead of by a rare bad step.
+__global__ __launch_bounds__(256) void poison_lds_kernel(uint32_t* __restrict__ sink)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t n = 64u * 1024u / 4u;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) lds[i] = 0x7fc00000u | i;
+    __syncthreads();
+    if (sink && lds[(threadIdx.x * 97u) % n] == 1u) sink[0] = 1u;   // keeps the stores alive
+}
+
 }  // namespace
+
+void launch_poison_lds(hipStream_t s)
+{
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(256 * 8), dim3(256), 64 * 1024, s, (uint32_t*)nullptr);
+}
 
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const GeomState& g, const float* bg, const float* alphas, const float* dL_dpix,

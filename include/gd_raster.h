@@ -141,6 +141,10 @@ int gd_raster_sort_bits(int width, int height, int V);
  * oracle/gd_oracle.c gd_expf bit for bit. */
 int gd_raster_blend_exp(void* stream, const float* x, float* y, int n);
 
+/* Test hook: fills the LDS of every CU with NaN bit patterns (LDS is not cleared between workgroups), so that a kernel
+ * reading a shared-memory cell it never wrote shows up in the parity tests rather than as a rare non-finite step. */
+int gd_raster_poison_lds(void* stream);
+
 /* ---- Per-kernel timing for bench.py's roofline line.  When enabled, every launch of the
  * listed kernels is bracketed by hipEvents on the launch stream; gd_raster_profile_collect()
  * waits for the recorded events and folds them into per-kernel totals.  Disabled by default

@@ -82,3 +82,12 @@ def random_image_grads(H, W, seed=1):
     rng = np.random.default_rng(seed)
     return (rng.normal(size=(3, H, W)).astype(np.float32), rng.normal(size=(1, H, W)).astype(np.float32),
             rng.normal(size=(1, H, W)).astype(np.float32))
+
+
+def poison_lds():
+    """NaN bit patterns into every CU's LDS (gd_raster_poison_lds): a kernel that reads a shared-memory cell it never
+    wrote then fails its parity test instead of passing on whatever the previous workgroup left there."""
+    from garmentdreamer_amd import _native
+    L = _native.lib()
+    with torch.cuda.device(0):
+        assert L.gd_raster_poison_lds(torch.cuda.current_stream().cuda_stream) == 0

@@ -21,9 +21,18 @@ DEV = "cuda:0"
 def _run_gpu_forward(inp):
     from garmentdreamer_amd.diff_gaussian_rasterization import _C
     args = h.to_torch(inp, DEV)
+    h.poison_lds()
     out = _C.rasterize_gaussians(*args)
     torch.cuda.synchronize()
     return args, out
+
+
+def _bwd(*a):
+    """_C.rasterize_gaussians_backward with every CU's LDS full of NaN patterns beforehand: the blend kernel is the first
+    launch of the backward pass, so a shared-memory cell it reads without having written it poisons the gradients."""
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    h.poison_lds()
+    return _C.rasterize_gaussians_backward(*a)
 
 
 def _check_forward(inp, st, out, exact_ncontrib=True):
@@ -122,7 +131,7 @@ def test_backward_parity(P, HW, deg):
     R, color, depth, alpha, radii, geom, binning, img = out
     t = lambda a: torch.as_tensor(a, device=DEV)
     (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, _, _) = args
-    grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
+    grads = _bwd(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
                                             t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha,
                                             False)
     torch.cuda.synchronize()
@@ -146,7 +155,7 @@ def _backward_vs_oracle(inp, case, seed=1, **tol):
     R, color, depth, alpha, radii, geom, binning, img = out
     t = lambda a: torch.as_tensor(a, device=DEV)
     (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H_, W_, sh, degree, campos, _, _) = args
-    grads = [_C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
+    grads = [_bwd(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
                                              t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha, False)
              for _ in range(2)]
     torch.cuda.synchronize()
@@ -207,7 +216,7 @@ def test_strip_culling_needles_forward_and_backward(P, HW, seed):
     R, color, depth, alpha, radii, geom, binning, img = out
     t = lambda a: torch.as_tensor(a, device=DEV)
     (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, _, _) = args
-    grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty, t(gc),
+    grads = _bwd(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty, t(gc),
                                             t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha, False)
     torch.cuda.synchronize()
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
@@ -228,7 +237,7 @@ def test_strip_culling_needles_forward_and_backward(P, HW, seed):
             a, b = g.detach().cpu().double().flatten(), torch.as_tensor(ref[n]).double().flatten()
             assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99999, n
     # the backward pass is atomic-free: same inputs -> the same bits
-    grads2 = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty, t(gc),
+    grads2 = _bwd(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty, t(gc),
                                              t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha, False)
     for a, b in zip(grads, grads2):
         assert torch.equal(a, b)
@@ -255,7 +264,7 @@ def test_colors_precomp_and_cov3d_precomp_paths():
     R, color, depth, alpha, radii, geom, binning, img = out
     t = lambda a: torch.as_tensor(a, device=DEV)
     (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, _, _) = args
-    grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
+    grads = _bwd(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
                                             t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha,
                                             False)
     for n, g in zip(("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D"), grads[:5]):
@@ -384,7 +393,7 @@ def _check_backward_dense(st, args, out, seed):
     P_ = means3D.shape[0]
     assert torch.equal(alpha.cpu(), torch.as_tensor(st.alpha).reshape(alpha.shape))   # bit-exact forward -> same T_final
     for label, alpha_img, rtol, atol in (("GPU alpha", alpha, 1e-3, 5e-6),):
-        grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
+        grads = _bwd(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
                                                 t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img,
                                                 alpha_img, False)
         torch.cuda.synchronize()
@@ -443,7 +452,7 @@ def test_inactive_sh_bands_get_exact_zero_gradient(deg):
     # poison the caching allocator's free list so that a missing write shows up as NaN, not as stale zeros
     junk = torch.full((P * 16 * 3 * 4,), float("nan"), device=DEV)
     del junk
-    grads = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
+    grads = _bwd(bg, means3D, radii, colors, scales, rots, smod, cov, vm, pm, tx, ty,
                                             t(gc), t(gd), t(ga), sh, degree, campos, geom, R, binning, img, alpha,
                                             False)
     torch.cuda.synchronize()
