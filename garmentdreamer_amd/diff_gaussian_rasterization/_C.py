@@ -16,6 +16,7 @@ Differences from the reference glue, all deliberate:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -41,6 +42,19 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
     return t.contiguous()
 
 
+# GD_RASTER_POISON_SCRATCH=1 (the GPU tests set it): every scratch buffer and output the library is handed starts as
+# 0xFF bytes -- NaN floats, -1 integers -- instead of whatever the caching allocator returns, so that a kernel relying on
+# an element it never wrote fails its parity test.  Off in production: the library writes everything it reads.
+_POISON = os.environ.get("GD_RASTER_POISON_SCRATCH") == "1"
+
+
+def _empty(shape, dtype, device):
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if _POISON and t.numel():
+        t.view(torch.uint8).fill_(0xFF)
+    return t
+
+
 class _Scratch:
     """Python side of the C-ABI allocator callback (replaces resizeFunctional,
     rasterize_points.cu:27-33)."""
@@ -51,7 +65,7 @@ class _Scratch:
         self.cb = _native.ALLOC_FN(self._alloc)
 
     def _alloc(self, _user, nbytes):
-        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self.tensor = _empty(int(nbytes), torch.uint8, self.device)
         return self.tensor.data_ptr()
 
 
@@ -73,10 +87,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     dev = means3D.device
     L = _native.lib()
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-    out_alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    out_color = _empty((NUM_CHANNELS, H, W), torch.float32, dev)
+    out_depth = _empty((1, H, W), torch.float32, dev)
+    out_alpha = _empty((1, H, W), torch.float32, dev)
+    radii = _empty((P,), torch.int32, dev)
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
     M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
     keep = [_f32c(t, dev) for t in (background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp,
@@ -105,7 +119,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
-    mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    mk = lambda *shape: _empty(shape, torch.float32, dev)
     dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk(P, 3), mk(P, 3), mk(P, NUM_CHANNELS)
     dL_dconic, dL_dopacity, dL_dcov3D = mk(P, 2, 2), mk(P, 1), mk(P, 6)
     dL_ddepths = mk(P, 1)
@@ -116,7 +130,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if not has_scales:  # outputs the kernel does not produce on this path stay defined (zeros)
         dL_dscales.zero_()
         dL_drotations.zero_()
-    scratch = torch.empty(L.gd_raster_backward_scratch_bytes(P, 1, int(R)), dtype=torch.uint8, device=dev)
+    scratch = _empty(L.gd_raster_backward_scratch_bytes(P, 1, int(R)), torch.uint8, dev)
     keep = [_f32c(t, dev) for t in (background, means3D, sh, colors, alphas, scales, rotations, cov3D_precomp,
                                     viewmatrix, projmatrix, campos, dL_dout_color, dL_dout_depth, dL_dout_alpha)]
     bg, m3, shc, col, alp, scl, rot, cov, vm, pm, cp, gcol, gdep, galp = keep
@@ -174,10 +188,10 @@ def rasterize_gaussians_batched(background, means3D, colors, opacity, scales, ro
     if not (1 <= V <= _native.GD_MAX_VIEWS) or len(tan_fovx) != V or len(tan_fovy) != V:
         raise RuntimeError(f"batched rasterizer needs 1..{_native.GD_MAX_VIEWS} views with matching tan_fov lists")
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    out_color = torch.empty((V, NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-    out_depth = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
-    out_alpha = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
-    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+    out_color = _empty((V, NUM_CHANNELS, H, W), torch.float32, dev)
+    out_depth = _empty((V, 1, H, W), torch.float32, dev)
+    out_alpha = _empty((V, 1, H, W), torch.float32, dev)
+    radii = _empty((V, P), torch.int32, dev)
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
     M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
     keep = [_f32c(t, dev) for t in (background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp,
@@ -207,7 +221,7 @@ def rasterize_gaussians_backward_batched(background, means3D, radii, colors, sca
     P = means3D.size(0)
     V, H, W = dL_dout_color.size(0), dL_dout_color.size(2), dL_dout_color.size(3)
     M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
-    mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    mk = lambda *shape: _empty(shape, torch.float32, dev)
     dL_dmeans3D, dL_dmeans2D, dL_dcolors = mk(P, 3), mk(V, P, 3), mk(P, NUM_CHANNELS)
     dL_dopacity, dL_dcov3D = mk(P, 1), mk(P, 6)
     dL_dsh, dL_dscales, dL_drotations = mk(P, M, 3), mk(P, 3), mk(P, 4)
@@ -216,7 +230,7 @@ def rasterize_gaussians_backward_batched(background, means3D, radii, colors, sca
     if scales is None or scales.numel() == 0:
         dL_dscales.zero_()
         dL_drotations.zero_()
-    scratch = torch.empty(L.gd_raster_backward_scratch_bytes(P, V, int(R)), dtype=torch.uint8, device=dev)
+    scratch = _empty(L.gd_raster_backward_scratch_bytes(P, V, int(R)), torch.uint8, dev)
     keep = [_f32c(t, dev) for t in (background, means3D, sh, colors, alphas, scales, rotations, cov3D_precomp,
                                     viewmatrix, projmatrix, campos, dL_dout_color, dL_dout_depth, dL_dout_alpha)]
     bg, m3, shc, col, alp, scl, rot, cov, vm, pm, cp, gcol, gdep, galp = keep

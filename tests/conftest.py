@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GD_RASTER_POISON_SCRATCH", "1")   # scratch / outputs of the rasterizer start as NaN / -1 (see _C.py)
+
 import garmentdreamer_amd  # noqa: E402,F401  (first: sets a HIP runtime flag before the runtime starts, _runtime_env.py)
 
 
