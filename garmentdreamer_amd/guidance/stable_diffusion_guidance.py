@@ -228,19 +228,45 @@ class StableDiffusionGuidance(nn.Module):
 
     def compute_grad_sds(self, latents, t, prompt_utils, elevation, azimuth, camera_distances,
                          noise: Optional[torch.Tensor] = None):
-        if getattr(prompt_utils, "use_perp_neg", False):
-            raise NotImplementedError("perp-neg prompting is off in GarmentDreamer's config (use_perp_neg=False)")
-        text_embeddings = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances,
-                                                           self.cfg.view_dependent_prompting)
-        with torch.no_grad():
-            if noise is None:
-                noise = torch.randn_like(latents)
-            latents_noisy = self.scheduler.add_noise(latents, noise, t)
-            latent_model_input = torch.cat([latents_noisy] * 2, dim=0)
-            noise_pred = self.forward_unet(latent_model_input, torch.cat([t] * 2),
-                                           encoder_hidden_states=text_embeddings)
-        noise_pred_text, noise_pred_uncond = noise_pred.chunk(2)
-        noise_pred = noise_pred_text + self.cfg.guidance_scale * (noise_pred_text - noise_pred_uncond)
+        use_perp_neg = bool(getattr(prompt_utils, "use_perp_neg", False))
+        batch_size = elevation.shape[0]
+        neg_guidance_weights = None
+        if use_perp_neg:
+            # perp-neg prompting (:196-228; off in GarmentDreamer's config): one UNet call on 4B samples --
+            # [interpolated positive | uncond | two negative prompts per view] -- and the negative directions enter only
+            # through their component perpendicular to the positive one (threestudio/utils/ops.py:431-441).  Note the
+            # plain classifier-free form here, uncond + s (e_pos + ...), unlike the text + s (text - uncond) below.
+            text_embeddings, neg_guidance_weights = prompt_utils.get_text_embeddings_perp_neg(
+                elevation, azimuth, camera_distances, self.cfg.view_dependent_prompting)
+            with torch.no_grad():
+                if noise is None:
+                    noise = torch.randn_like(latents)
+                latents_noisy = self.scheduler.add_noise(latents, noise, t)
+                noise_pred = self.forward_unet(torch.cat([latents_noisy] * 4, dim=0), torch.cat([t] * 4),
+                                               encoder_hidden_states=text_embeddings)
+            noise_pred_text = noise_pred[:batch_size]
+            noise_pred_uncond = noise_pred[batch_size:batch_size * 2]
+            noise_pred_neg = noise_pred[batch_size * 2:]
+            e_pos = noise_pred_text - noise_pred_uncond
+            accum_grad = 0
+            n_negative_prompts = neg_guidance_weights.shape[-1]
+            for i in range(n_negative_prompts):
+                e_i_neg = noise_pred_neg[i::n_negative_prompts] - noise_pred_uncond
+                accum_grad = accum_grad + neg_guidance_weights[:, i].view(-1, 1, 1, 1).to(e_pos) * \
+                    perpendicular_component(e_i_neg, e_pos)
+            noise_pred = noise_pred_uncond + self.cfg.guidance_scale * (e_pos + accum_grad)
+        else:
+            text_embeddings = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances,
+                                                               self.cfg.view_dependent_prompting)
+            with torch.no_grad():
+                if noise is None:
+                    noise = torch.randn_like(latents)
+                latents_noisy = self.scheduler.add_noise(latents, noise, t)
+                latent_model_input = torch.cat([latents_noisy] * 2, dim=0)
+                noise_pred = self.forward_unet(latent_model_input, torch.cat([t] * 2),
+                                               encoder_hidden_states=text_embeddings)
+            noise_pred_text, noise_pred_uncond = noise_pred.chunk(2)
+            noise_pred = noise_pred_text + self.cfg.guidance_scale * (noise_pred_text - noise_pred_uncond)
 
         if self.cfg.weighting_strategy == "sds":
             w = (1 - self.alphas[t]).view(-1, 1, 1, 1)
@@ -251,7 +277,7 @@ class StableDiffusionGuidance(nn.Module):
         else:
             raise ValueError(f"Unknown weighting strategy: {self.cfg.weighting_strategy}")
         grad = w * (noise_pred - noise)
-        guidance_eval_utils = {"use_perp_neg": False, "neg_guidance_weights": None,
+        guidance_eval_utils = {"use_perp_neg": use_perp_neg, "neg_guidance_weights": neg_guidance_weights,
                                "text_embeddings": text_embeddings, "t_orig": t, "latents_noisy": latents_noisy,
                                "noise_pred": noise_pred}
         return grad, guidance_eval_utils
@@ -297,6 +323,12 @@ class StableDiffusionGuidance(nn.Module):
                                max_step_percent=C(self.cfg.max_step_percent, epoch, global_step))
 
 
+def perpendicular_component(x, y):
+    """The component of x perpendicular to y, per sample (threestudio/utils/ops.py:431-441)."""
+    eps = torch.ones_like(x[:, 0, 0, 0]) * 1e-6
+    return x - (torch.mul(x, y).sum(dim=[1, 2, 3]) / torch.maximum(torch.mul(y, y).sum(dim=[1, 2, 3]), eps)).view(-1, 1, 1, 1) * y
+
+
 class PromptEmbeddings:
     """Stand-in for ``PromptProcessorOutput`` (prompt_processors/base.py:36-78): holds the four
     view-dependent (side/front/back/overhead) cond + uncond embeddings and returns
@@ -304,6 +336,11 @@ class PromptEmbeddings:
     in the reference and is out of scope; benchmarks use N(0,1) embeddings."""
 
     use_perp_neg = False
+    # a * exp(-b r) + c  (prompt_processors/base.py:197-206)
+    perp_neg_f_sb = (1, 0.5, -0.606)
+    perp_neg_f_fsb = (1, 0.5, +0.967)
+    perp_neg_f_fs = (4, 0.5, -2.426)
+    perp_neg_f_sf = (4, 0.5, -2.426)
 
     def __init__(self, text_embeddings_vd, uncond_text_embeddings_vd, front_threshold=45.0, back_threshold=45.0,
                  overhead_threshold=60.0):
@@ -335,3 +372,43 @@ class PromptEmbeddings:
             text = self.text_embeddings.expand(batch_size, -1, -1)
             uncond = self.uncond_text_embeddings.expand(batch_size, -1, -1)
         return torch.cat([text, uncond], dim=0)
+
+    def _direction_idx(self, elevation, azimuth):
+        azi = (azimuth + 180) % 360 - 180
+        idx = torch.zeros_like(elevation, dtype=torch.long)
+        idx[(azi > -self.front_threshold) & (azi < self.front_threshold)] = 1
+        idx[(azi > 180 - self.back_threshold) | (azi < -180 + self.back_threshold)] = 2
+        idx[elevation > self.overhead_threshold] = 3
+        return idx, azi
+
+    def get_text_embeddings_perp_neg(self, elevation, azimuth, camera_distances, view_dependent_prompting=True):
+        """``PromptProcessorOutput.get_text_embeddings_perp_neg`` (prompt_processors/base.py:80-160): per view the
+        positive prompt interpolated between the front / side / back embeddings by azimuth, the unconditional one, and
+        two negative prompts with weights  -(a exp(-b r) + c);  returns ([4B,77,1024] = pos | uncond | neg, [B,2])."""
+        assert view_dependent_prompting, "Perp-Neg only works with view-dependent prompting"
+        B = elevation.shape[0]
+        idx, azi = self._direction_idx(elevation, azimuth)
+        side, front, back, overhead = (self.text_embeddings_vd[i] for i in range(4))
+        decay = lambda f, r: f[0] * torch.exp(-f[1] * r) + f[2]     # noqa: E731  shifted_expotional_decay
+        pos, neg, wts, unc = [], [], [], []
+        for i in range(B):
+            d, a = int(idx[i]), azi[i]
+            u = self.uncond_text_embeddings_vd[d]
+            unc.append(u)
+            if d == 3:                                   # overhead view: no negative direction
+                pos.append(overhead)
+                neg += [u, u]
+                wts += [torch.zeros(()), torch.zeros(())]
+            elif torch.abs(a) < 90:                      # front-side interpolation (0 = side, 1 = front)
+                r = 1 - torch.abs(a) / 90
+                pos.append(r * front + (1 - r) * side)
+                neg += [front, side]
+                wts += [-decay(self.perp_neg_f_fs, r), -decay(self.perp_neg_f_sf, 1 - r)]
+            else:                                        # side-back interpolation (0 = back, 1 = side)
+                r = 2.0 - torch.abs(a) / 90
+                pos.append(r * side + (1 - r) * back)
+                neg += [side, front]
+                wts += [-decay(self.perp_neg_f_sb, r), -decay(self.perp_neg_f_fsb, r)]
+        emb = torch.cat([torch.stack(pos), torch.stack(unc), torch.stack(neg)], dim=0)
+        w = torch.stack([torch.as_tensor(x, dtype=torch.float32) for x in wts]).to(elevation.device).reshape(B, 2)
+        return emb, w

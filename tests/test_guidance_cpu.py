@@ -174,3 +174,60 @@ def test_view_dependent_prompt_selection_matches_reference_rules():
         assert torch.equal(e[i], p.text_embeddings_vd[k]) and torch.equal(e[5 + i], p.uncond_text_embeddings_vd[k])
     e2 = p.get_text_embeddings(el, az, torch.ones(5), False)
     assert torch.equal(e2[0], p.text_embeddings[0]) and torch.equal(e2[9], p.uncond_text_embeddings[0])
+
+
+def test_perp_neg_branch_matches_the_reference_formulas():
+    """Perp-neg prompting (stable_diffusion_guidance.py:196-228, prompt_processors/base.py:80-160; off in
+    GarmentDreamer's config): 4B UNet samples ordered [pos | uncond | neg pairs], interpolated positives and decay
+    weights by azimuth, and noise_pred = uncond + s (e_pos + sum_i w_i perp(e_neg_i, e_pos))."""
+    from garmentdreamer_amd.guidance.stable_diffusion_guidance import perpendicular_component
+    B = 3
+    prompt = PromptEmbeddings.random("cpu")
+    prompt.use_perp_neg = True
+    el = torch.tensor([10.0, 20.0, 80.0])
+    az = torch.tensor([30.0, 150.0, 0.0])            # front-side, side-back, overhead
+    emb, w = prompt.get_text_embeddings_perp_neg(el, az, torch.ones(B) * 2.5, True)
+    assert emb.shape == (4 * B, 77, 1024) and w.shape == (B, 2)
+    side, front, back, over = (prompt.text_embeddings_vd[i] for i in range(4))
+    r0 = 1 - 30.0 / 90
+    assert torch.allclose(emb[0], r0 * front + (1 - r0) * side, atol=1e-5)
+    r1 = 2.0 - 150.0 / 90
+    assert torch.allclose(emb[1], r1 * side + (1 - r1) * back, atol=1e-5)
+    assert torch.equal(emb[2], over)
+    assert torch.equal(emb[2 * B + 0], front) and torch.equal(emb[2 * B + 1], side)       # view 0's negatives
+    assert torch.equal(emb[2 * B + 2], side) and torch.equal(emb[2 * B + 3], front)       # view 1's
+    f = lambda a, b, c, r: a * math.exp(-b * r) + c                                        # noqa: E731
+    assert math.isclose(float(w[0, 0]), -f(4, 0.5, -2.426, r0), rel_tol=1e-6)
+    assert math.isclose(float(w[0, 1]), -f(4, 0.5, -2.426, 1 - r0), rel_tol=1e-6)
+    assert math.isclose(float(w[1, 0]), -f(1, 0.5, -0.606, r1), rel_tol=1e-6)
+    assert math.isclose(float(w[1, 1]), -f(1, 0.5, 0.967, r1), rel_tol=1e-6)
+    assert float(w[2].abs().sum()) == 0.0
+
+    g = torch.Generator().manual_seed(3)
+    eps = torch.randn(4 * B, 4, 64, 64, generator=g)
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, x, t, encoder_hidden_states):
+            assert x.shape[0] == 4 * B and encoder_hidden_states.shape[0] == 4 * B
+            return eps.to(x.dtype)
+
+    gd = StableDiffusionGuidance({"guidance_scale": 7.5, "grad_clip": None, "half_precision_weights": False},
+                                 device="cpu", unet=Stub(), vae=_StubVAE())
+    lat = torch.randn(B, 4, 64, 64, generator=g)
+    noise = torch.randn(B, 4, 64, 64, generator=g)
+    t = torch.tensor([100, 500, 900])
+    grad, utils = gd.compute_grad_sds(lat, t, prompt, el, az, torch.ones(B) * 2.5, noise=noise)
+    e_text, e_unc, e_neg = eps[:B], eps[B:2 * B], eps[2 * B:]
+    e_pos = e_text - e_unc
+    acc = sum(w[:, i].view(-1, 1, 1, 1) * perpendicular_component(e_neg[i::2] - e_unc, e_pos) for i in range(2))
+    ref = e_unc + 7.5 * (e_pos + acc)
+    wt = (1 - gd.alphas[t]).view(-1, 1, 1, 1)
+    assert torch.allclose(grad, wt * (ref - noise), rtol=1e-5, atol=1e-6)
+    assert utils["use_perp_neg"] and torch.equal(utils["neg_guidance_weights"], w)
+    # perpendicular_component really is perpendicular
+    pc = perpendicular_component(e_neg[::2] - e_unc, e_pos)
+    assert float((pc * e_pos).sum(dim=[1, 2, 3]).abs().max()) < 1e-2
