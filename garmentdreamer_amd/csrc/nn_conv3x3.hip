@@ -43,6 +43,15 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// Timing-only switches of tools/nn_variants.sh (never defined in a product build):
+//   GD_PATCH_EPI=1  the patch-staged kernels skip their epilogue stores (wrong results; the condition is never true at
+//                   run time, so the compiler keeps the code that computes the values)
+//   GD_PATCH_EPI=2  8-byte stores straight from the MFMA result layout instead of the LDS-transposed epilogue
+//                   (correct results; the A/B of that epilogue)
+#ifndef GD_PATCH_EPI
+#define GD_PATCH_EPI 0
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int BK = 64;    // channels of one tap per K-step (128-byte rows)
@@ -344,6 +353,133 @@ constexpr int kPatch = 18, kPatchPix = kPatch * kPatch;   // 16x16 tile + 1-pixe
 
 __device__ __forceinline__ float silu_fast(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 
+// Sum over the 16 lanes of a DPP row, result in every lane (quad swaps, half-row mirror, row mirror).
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+    return v;
+}
+
+// GroupNorm statistics of the OUTPUT from the epilogue (stat_part != NULL): the next layer of a ResnetBlock2D chain
+// is a GroupNorm over this very tensor, and its statistics pass is a full re-read of it from HBM (the 512^2 level of
+// the VAE encoder: 537 MB, 100 us per call at 8 views).  Each lane sums the bf16-ROUNDED values it stores (what the
+// consumer will read) and their squares over its 2 pixels x 4 consecutive channels (one group: needs
+// Cout / G % 4 == 0), a DPP row reduction folds 16 pixels, and one lane per row writes the pair: per (image,
+// channel quad) tiles_per_image * 8 fp32 partials, summed in fp64 by gd_nn_groupnorm_finish_partials.  No atomics,
+// so the statistics are deterministic; every row is written by every launch (edge tiles write what they have).
+__device__ __forceinline__ void stat_accumulate(float2& st, uint2 o)
+{
+    const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
+    const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+    st.x += (r0 + r1) + (r2 + r3);
+    st.y += fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, r3 * r3)));
+}
+
+// MFMA pixel column fn -> (row rr in {0,1}, x) of the wave's 2 x 16 pixel block, such that each 16-lane LDS service
+// group reads one patch row
+__device__ __forceinline__ void patch_col(int fn, int& rr, int& fx)
+{
+    if (fn < 4) { rr = 0; fx = fn; }
+    else if (fn < 12) { rr = 1; fx = fn - 4; }
+    else if (fn < 16) { rr = 0; fx = fn - 8; }
+    else if (fn < 20) { rr = 1; fx = fn - 8; }
+    else if (fn < 28) { rr = 0; fx = fn - 12; }
+    else { rr = 1; fx = fn - 16; }
+}
+
+constexpr int kTrRow = 80;                 // bytes per pixel row of the epilogue's transposition buffer (64 + pad)
+constexpr int kTrWave = 64 * kTrRow;       // per wave: 64 pixels x 32 channels
+
+// Epilogue of the patch-staged kernels: out = bf16(acc + bias (+ residual)), optional GroupNorm partial sums.
+// In the MFMA result layout a lane owns 4 consecutive channels of a pixel and neighbouring lanes are neighbouring
+// PIXELS, so a direct store instruction is 64 separate 8-byte writes (one per cache line): with those the stores cost
+// 6-23 % of the VAE encoder's convolutions (GD_PATCH_EPI=1 timing, tools/nn_variants.sh).  With `tr` (a wave-private
+// kTrWave bytes of LDS) and Cout % 8 == 0 the packed values of one 32-channel block go through LDS and leave as
+// 16 bytes per lane, four lanes per pixel: 64 contiguous bytes per pixel and instruction.  Loop order (channel quad,
+// pixel): the partial sums of one quad live in two registers.
+template <int BN, int WN, int FA, int FB>
+__device__ __forceinline__ void patch_epilogue(f32x16 (&acc)[FA][FB], char* tr, int nimg, int tyi, int txi, int n0, int wc,
+                                               int wp, int lane, int H, int W, int Cout, const uint16_t* __restrict__ bias,
+                                               int bias_img_stride, const uint16_t* __restrict__ residual,
+                                               uint16_t* __restrict__ out, float* __restrict__ stat_part, int tpi,
+                                               int tiles_x)
+{
+    const int fk = lane >> 5, fn = lane & 31;
+    int rr, fx;
+    patch_col(fn, rr, fx);
+    bool ok[FB];
+    size_t opix[FB];
+#pragma unroll
+    for (int b = 0; b < FB; b++) {
+        const int oy = tyi * 16 + 4 * wp + 2 * b + rr, ox = txi * 16 + fx;
+        ok[b] = oy < H && ox < W;
+        opix[b] = ((size_t)nimg * H + oy) * W + ox;
+    }
+    const uint16_t* bias_n = bias ? bias + (size_t)nimg * bias_img_stride : nullptr;
+    const int stat_rows = tpi * 8;
+    const int stat_row = (tyi * tiles_x + txi) * 8 + wp * 2 + ((lane >> 4) & 1);
+    const bool wide = GD_PATCH_EPI != 2 && tr != nullptr && (Cout & 7) == 0;
+#pragma unroll
+    for (int a = 0; a < FA; a++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int co = n0 + wc * (BN / WN) + a * 32 + 8 * q + 4 * fk;
+            const bool cok = co < Cout;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias_n && cok) {
+                const uint2 bb = *(const uint2*)(bias_n + co);
+                bv[0] = bf2f((uint16_t)(bb.x & 0xffff)); bv[1] = bf2f((uint16_t)(bb.x >> 16));
+                bv[2] = bf2f((uint16_t)(bb.y & 0xffff)); bv[3] = bf2f((uint16_t)(bb.y >> 16));
+            }
+            float2 st = make_float2(0.f, 0.f);   // sum, sum of squares of the stored values (stat_part)
+#pragma unroll
+            for (int b = 0; b < FB; b++) {
+                if (!ok[b] || !cok) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[a][b][4 * q + e] + bv[e];
+                if (residual) {
+                    const uint2 rv = *(const uint2*)(residual + opix[b] * Cout + co);
+                    v[0] += bf2f((uint16_t)(rv.x & 0xffff)); v[1] += bf2f((uint16_t)(rv.x >> 16));
+                    v[2] += bf2f((uint16_t)(rv.y & 0xffff)); v[3] += bf2f((uint16_t)(rv.y >> 16));
+                }
+                uint2 o;
+                o.x = pack_bf16(v[0], v[1]);
+                o.y = pack_bf16(v[2], v[3]);
+                if (wide) *(uint2*)(tr + (b * 32 + fn) * kTrRow + 16 * q + 8 * fk) = o;
+                else if (GD_PATCH_EPI != 1 || H < 0) *(uint2*)(out + opix[b] * Cout + co) = o;
+                if (stat_part) stat_accumulate(st, o);
+            }
+            if (stat_part) {
+                const float sx = row16_sum(st.x), sy = row16_sum(st.y);
+                if ((lane & 15) == 0 && cok)
+                    *(float2*)(stat_part + (((size_t)nimg * (Cout >> 2) + (co >> 2)) * stat_rows + stat_row) * 2) =
+                        make_float2(sx, sy);
+            }
+        }
+        if (wide) {
+            // LDS operations of one wave execute in order: the reads below see the writes above
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < FB * 2; i++) {
+                const int pr = (lane >> 2) + 16 * i, ch = lane & 3;     // pixel of the wave's block, 8-channel chunk
+                int rr2, fx2;
+                patch_col(pr & 31, rr2, fx2);
+                const int oy = tyi * 16 + 4 * wp + 2 * (pr >> 5) + rr2, ox = txi * 16 + fx2;
+                const int co8 = n0 + wc * (BN / WN) + a * 32 + 8 * ch;
+                if (oy < H && ox < W && co8 < Cout) {
+                    const uint4 v = *(const uint4*)(tr + pr * kTrRow + ch * 16);
+                    if (GD_PATCH_EPI != 1 || H < 0) *(uint4*)(out + (((size_t)nimg * H + oy) * W + ox) * Cout + co8) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // GN = true: GroupNorm(+SiLU) applied in the loader (register staged).  GN = false: plain convolution, the patch
 // is fetched by LDS-DMA like the weights -- 41 LDS-DMA wave-instructions per 64 input channels (5.2 patch + 36
 // weight pieces) instead of the implicit-GEMM kernel's 72.
@@ -352,7 +488,8 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_gn_patch_kernel(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
     int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, int H, int W,
     int Cin, int Cout, const float* __restrict__ mean_rstd, const uint16_t* __restrict__ gamma,
-    const uint16_t* __restrict__ beta, int G, int apply_silu, int tiles_n, int tiles_x, int tiles_y, int nwg)
+    const uint16_t* __restrict__ beta, int G, int apply_silu, int tiles_n, int tiles_x, int tiles_y, int nwg,
+    float* __restrict__ stat_part)
 {
     constexpr int BM = 256;
     constexpr int THREADS = 64 * WN * WM;
@@ -555,39 +692,11 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_gn_patch_kernel(
         }
     }
 
-    // ---- epilogue
-#pragma unroll
-    for (int b = 0; b < FB; b++) {
-        const int oy = tyi * 16 + 4 * wp + 2 * b + rr, ox = txi * 16 + fx;
-        if (oy >= H || ox >= W) continue;
-        const size_t opix = ((size_t)nimg * H + oy) * W + ox;
-        const uint16_t* bias_n = bias ? bias + (size_t)nimg * bias_img_stride : nullptr;
-#pragma unroll
-        for (int a = 0; a < FA; a++) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int co = n0 + wc * (BN / WN) + a * 32 + 8 * q + 4 * fk;
-                if (co >= Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[a][b][4 * q + e];
-                if (bias_n) {
-                    const uint2 bb = *(const uint2*)(bias_n + co);
-                    v[0] += bf2f((uint16_t)(bb.x & 0xffff)); v[1] += bf2f((uint16_t)(bb.x >> 16));
-                    v[2] += bf2f((uint16_t)(bb.y & 0xffff)); v[3] += bf2f((uint16_t)(bb.y >> 16));
-                }
-                if (residual) {
-                    const uint2 rv = *(const uint2*)(residual + opix * Cout + co);
-                    v[0] += bf2f((uint16_t)(rv.x & 0xffff)); v[1] += bf2f((uint16_t)(rv.x >> 16));
-                    v[2] += bf2f((uint16_t)(rv.y & 0xffff)); v[3] += bf2f((uint16_t)(rv.y >> 16));
-                }
-                uint2 o;
-                o.x = pack_bf16(v[0], v[1]);
-                o.y = pack_bf16(v[2], v[3]);
-                *(uint2*)(out + opix * Cout + co) = o;
-            }
-        }
-    }
+    // ---- epilogue: every wave is done with the patch stage of the last chunk once all have passed this barrier; its
+    // memory becomes the transposition buffer
+    if (GD_PATCH_EPI != 2) __syncthreads();
+    patch_epilogue<BN, WN, FA, FB>(acc, sA + ((kc - 1) & 1) * kAStage + wave * kTrWave, nimg, tyi, txi, n0, wc, wp, lane, H, W,
+                                   Cout, bias, bias_img_stride, residual, out, stat_part, tpi, tiles_x);
 }
 
 // The same patch-staged convolution as a PERSISTENT kernel for the plain (GN = false) case; the GroupNorm variants
@@ -598,7 +707,8 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
     int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, int H, int W,
     int Cin, int Cout, const float* __restrict__ mean_rstd, const uint16_t* __restrict__ gamma,
-    const uint16_t* __restrict__ beta, int G, int apply_silu, int tiles_n, int tiles_x, int tiles_y, int nwg)
+    const uint16_t* __restrict__ beta, int G, int apply_silu, int tiles_n, int tiles_x, int tiles_y, int nwg,
+    float* __restrict__ stat_part)
 {
     constexpr int BM = 256;
     constexpr int THREADS = 64 * WN * WM;
@@ -845,39 +955,13 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
             }
         }
 
-        // ---- epilogue of the current tile (the next tile's first patch chunk and weights are already in flight)
-#pragma unroll
-        for (int b = 0; b < FB; b++) {
-            const int oy = cur.tyi * 16 + 4 * wp + 2 * b + rr, ox = cur.txi * 16 + fx;
-            if (oy >= H || ox >= W) continue;
-            const size_t opix = ((size_t)cur.nimg * H + oy) * W + ox;
-            const uint16_t* bias_n = bias ? bias + (size_t)cur.nimg * bias_img_stride : nullptr;
-#pragma unroll
-            for (int a = 0; a < FA; a++) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int co = cur.n0 + wc * (BN / WN) + a * 32 + 8 * q + 4 * fk;
-                    if (co >= Cout) continue;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = acc[a][b][4 * q + e];
-                    if (bias_n) {
-                        const uint2 bb = *(const uint2*)(bias_n + co);
-                        v[0] += bf2f((uint16_t)(bb.x & 0xffff)); v[1] += bf2f((uint16_t)(bb.x >> 16));
-                        v[2] += bf2f((uint16_t)(bb.y & 0xffff)); v[3] += bf2f((uint16_t)(bb.y >> 16));
-                    }
-                    if (residual) {
-                        const uint2 rv = *(const uint2*)(residual + opix * Cout + co);
-                        v[0] += bf2f((uint16_t)(rv.x & 0xffff)); v[1] += bf2f((uint16_t)(rv.x >> 16));
-                        v[2] += bf2f((uint16_t)(rv.y & 0xffff)); v[3] += bf2f((uint16_t)(rv.y >> 16));
-                    }
-                    uint2 o;
-                    o.x = pack_bf16(v[0], v[1]);
-                    o.y = pack_bf16(v[2], v[3]);
-                    *(uint2*)(out + opix * Cout + co) = o;
-                }
-            }
-        }
+        // ---- epilogue of the current tile (the next tile's first patch chunk and weights are already in flight, into
+        // the OTHER patch stage: the stage of the last chunk is free once every wave has passed this barrier, and stays
+        // free until the first step of the next tile issues its second chunk -- behind that step's barrier)
+        if (GD_PATCH_EPI != 2) __syncthreads();
+        patch_epilogue<BN, WN, FA, FB>(acc, sA + ((ga - 1) & 1) * kAStage + wave * kTrWave, cur.nimg, cur.tyi, cur.txi, cur.n0,
+                                       wc, wp, lane, H, W, Cout, bias, bias_img_stride, residual, out, stat_part, tpi,
+                                       tiles_x);
         if (!has_next) break;
         cur = nxt;
         vb = vnext;
@@ -1008,6 +1092,126 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const uint16_t* __re
         o.z = pack_bf16(acc[p][4], acc[p][5]); o.w = pack_bf16(acc[p][6], acc[p][7]);
         *(uint4*)(out + (((size_t)n * H + y) * W + x0 + p) * Cout + oct * 8) = o;
     }
+    }
+}
+
+// The VAE encoder's first convolution (3 -> 128 channels on the full-resolution image) on the matrix cores.  The VALU
+// kernel above spends 27 fp32 FMAs per output -- 0.42 wave instructions per output at 4.5 cycles each, 365 us for
+// the 8 x 512^2 x 128 tensor of the benchmark, three times the 537 MB output write.  Here a wave owns 32 consecutive
+// pixels of a row x all 128 channels: the im2col operand B[k][pixel] (k = (ky, kx, ci), K = 9 * CIN padded to KS * 16)
+// is gathered straight from the image (6 MB, L2 resident; 8 * KS two-byte loads per lane), the weights A[channel][k]
+// stay in registers for the life of the (persistent) wave, and 4 * KS MFMAs produce the tile; the epilogue is the
+// patch-staged kernels' (bf16 pack, 8-byte NHWC stores; the bias is a K column).  stat_part != NULL: GroupNorm partial sums of the
+// stored values as in those kernels, but accumulated in registers over ALL tiles of an image that the wave
+// processes and written once per (image, wave): rows = 8 * gridDim.x per image, every row written by every launch.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_first_mfma_kernel(const uint16_t* __restrict__ in,
+                                                                 const uint16_t* __restrict__ wt,
+                                                                 const uint16_t* __restrict__ bias,
+                                                                 uint16_t* __restrict__ out, int Nimg, int H, int W,
+                                                                 float* __restrict__ stat_part)
+{
+    constexpr int K = 9 * CIN, KS = (K + 16) / 16, FA = 4, Cout = 128;   // K + 1 columns: the last one is the bias
+    const int lane = threadIdx.x & 63, fn = lane & 31, fk = lane >> 5;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int segs_x = (W + 31) >> 5;
+    const int64_t segs = (int64_t)H * segs_x;
+
+    // this lane's K slice: k = 16 * s + 8 * fk + j.  tap[s][j] = element offset of (ky - 1, kx - 1, ci) from the pixel,
+    // times 64, plus the border conditions the tap needs (1: y > 0, 2: y < H - 1, 4: x > 0, 8: x < W - 1, 16: never;
+    // 32: the constant 1.0 that multiplies the bias column)
+    int tap[KS][8];
+    bf16x8_t wa[FA][KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = 16 * s + 8 * fk + j;
+            const int ky = k / (3 * CIN), kx = (k / CIN) % 3, ci = k % CIN;
+            const int need = k == K ? 32 : k > K ? 16 : ((ky == 0 ? 1 : 0) | (ky == 2 ? 2 : 0) | (kx == 0 ? 4 : 0) | (kx == 2 ? 8 : 0));
+            const int off = k >= K ? 0 : ((ky - 1) * W + (kx - 1)) * CIN + ci;
+            tap[s][j] = off * 64 + need;
+        }
+#pragma unroll
+        for (int a = 0; a < FA; a++) {
+            short w8[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = 16 * s + 8 * fk + j;
+                // wt: [Cout][3][3][CIN]; the bias rides in the first padding column (its B entry is 1.0)
+                w8[j] = k < K ? (short)wt[(size_t)(32 * a + fn) * K + k] : (k == K && bias) ? (short)bias[32 * a + fn] : (short)0;
+            }
+            wa[a][s] = bf16x8_t{w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7]};
+        }
+    }
+
+    int64_t t = wave_g;
+    for (int n = 0; n < Nimg; n++) {
+        float2 st[FA][4];
+#pragma unroll
+        for (int a = 0; a < FA; a++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) st[a][q] = make_float2(0.f, 0.f);
+        for (; t < (int64_t)(n + 1) * segs; t += nwaves) {
+            const int seg = (int)(t - (int64_t)n * segs);
+            const int y = seg / segs_x, x = (seg - y * segs_x) * 32 + fn;
+            const bool pix_ok = x < W;
+            const int have = pix_ok ? ((y > 0 ? 1 : 0) | (y < H - 1 ? 2 : 0) | (x > 0 ? 4 : 0) | (x < W - 1 ? 8 : 0)) : 0;
+            const uint16_t* base = in + (((size_t)n * H + y) * W + (pix_ok ? x : 0)) * CIN;
+            f32x16 acc[FA];
+#pragma unroll
+            for (int a = 0; a < FA; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                short p8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int need = tap[s][j] & 63;
+                    const bool ok = pix_ok && (need & ~have) == 0;
+                    p8[j] = need == 32 ? (short)0x3F80 : ok ? (short)base[tap[s][j] >> 6] : (short)0;
+                }
+                const bf16x8_t pb = bf16x8_t{p8[0], p8[1], p8[2], p8[3], p8[4], p8[5], p8[6], p8[7]};
+#pragma unroll
+                for (int a = 0; a < FA; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[a][s], pb, acc[a], 0, 0, 0);
+            }
+            // lanes l and l + 32 hold the two halves of each 8-channel octet of the same pixel: v_permlane32_swap
+            // regroups two octets so that every lane stores 16 contiguous bytes (half as many write requests as
+            // 8-byte stores -- this kernel is bound by them, not by bytes)
+            uint16_t* orow = out + (((size_t)n * H + y) * W + x) * Cout + 8 * fk;
+#pragma unroll
+            for (int a = 0; a < FA; a++) {
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    uint2 o0, o1;
+                    o0.x = pack_bf16(acc[a][4 * q], acc[a][4 * q + 1]);
+                    o0.y = pack_bf16(acc[a][4 * q + 2], acc[a][4 * q + 3]);
+                    o1.x = pack_bf16(acc[a][4 * q + 4], acc[a][4 * q + 5]);
+                    o1.y = pack_bf16(acc[a][4 * q + 6], acc[a][4 * q + 7]);
+                    if (stat_part && pix_ok) {
+                        stat_accumulate(st[a][q], o0);
+                        stat_accumulate(st[a][q + 1], o1);
+                    }
+                    const auto sx = __builtin_amdgcn_permlane32_swap(o0.x, o1.x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(o0.y, o1.y, false, false);
+                    if (pix_ok) *(uint4*)(orow + 32 * a + 8 * q) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                }
+            }
+        }
+        if (stat_part) {
+            const int rows = nwaves * 2, row = wave_g * 2 + ((lane >> 4) & 1);
+#pragma unroll
+            for (int a = 0; a < FA; a++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float sx = row16_sum(st[a][q].x), sy = row16_sum(st[a][q].y);
+                    const int quad = 8 * a + 2 * q + fk;
+                    if ((lane & 15) == 0)
+                        *(float2*)(stat_part + (((size_t)n * (Cout >> 2) + quad) * rows + row) * 2) = make_float2(sx, sy);
+                }
+            }
+        }
     }
 }
 
@@ -1179,7 +1383,8 @@ static void add_tap(ConvGeom& g, int dy, int dx, int widx)
 
 static int launch_patch(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
                         int groups, int apply_silu, const void* weight, const void* bias, int bias_img_stride,
-                        const void* residual, void* y, int N, int H, int W, int Cin, int Cout);
+                        const void* residual, void* y, int N, int H, int W, int Cin, int Cout,
+                        float* stat_part = nullptr);
 
 // Plain stride-1 convolutions run on the persistent patch-staged kernel (LDS-DMA patch) once its (image, 16x16
 // patch, 128- or 256-channel slab) grid has >= 256 workgroups: 1.08-1.24x faster than the implicit-GEMM tiles on
@@ -1246,7 +1451,8 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
 
 static int launch_patch(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
                         int groups, int apply_silu, const void* weight, const void* bias, int bias_img_stride,
-                        const void* residual, void* y, int N, int H, int W, int Cin, int Cout)
+                        const void* residual, void* y, int N, int H, int W, int Cin, int Cout,
+                        float* stat_part)
 {
     if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || Cin % BK || Cout % 4 || Cin <= 0 || Cout <= 0)
@@ -1290,7 +1496,7 @@ static int launch_patch(void* stream, const void* x, const float* mean_rstd, con
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const uint16_t*)x, (const uint16_t*)weight,       \
                            (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y, N, H,  \
                            W, Cin, Cout, mean_rstd, (const uint16_t*)gamma, (const uint16_t*)beta, groups,         \
-                           apply_silu, tiles_n, tiles_x, tiles_y, nwg);                                            \
+                           apply_silu, tiles_n, tiles_x, tiles_y, nwg, stat_part);                                 \
     } while (0)
     int bn = (Cout % 256 == 0) ? 256 : 128;
     if (g_force_variant == 1 || g_force_variant == 0) bn = 128;
@@ -1324,12 +1530,87 @@ int gd_nn_conv3x3_gn_forward(void* stream, const void* x, const float* mean_rstd
                         N, H, W, Cin, Cout);
 }
 
+size_t gd_nn_conv3x3_stat_rows(int N, int H, int W, int Cout, int gn_entry)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4) return 0;
+    if (!gn_entry && !prefer_patch(N, H, W, Cout)) return 0;
+    return (size_t)((H + 15) / 16) * ((W + 15) / 16) * 8;
+}
+
+int gd_nn_conv3x3_gn_forward_stats(void* stream, const void* x, const float* mean_rstd, const void* gamma,
+                                   const void* beta, int groups, int apply_silu, const void* weight, const void* bias,
+                                   int bias_img_stride, const void* residual, void* y, int N, int H, int W, int Cin,
+                                   int Cout, float* stat_part)
+{
+    return launch_patch(stream, x, mean_rstd, gamma, beta, groups, apply_silu, weight, bias, bias_img_stride, residual, y,
+                        N, H, W, Cin, Cout, stat_part);
+}
+
+int gd_nn_conv3x3_forward_stats(void* stream, const void* x, const void* weight, const void* bias, int bias_img_stride,
+                                const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part)
+{
+    if (!stat_part) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_forward_stats: stat_part is NULL");
+    if (!prefer_patch(N, H, W, Cout))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_forward_stats: this shape does not run on the patch-staged kernel "
+                                           "(gd_nn_conv3x3_stat_rows() == 0)");
+    return launch_patch(stream, x, nullptr, nullptr, nullptr, 0, 0, weight, bias, bias_img_stride, residual, y, N, H, W,
+                        Cin, Cout, stat_part);
+}
+
+// persistent workgroups of the matrix-core first convolution: two per CU (8 waves of ~170 VGPRs), fewer for small inputs
+static int first_mfma_grid(int N, int H, int W)
+{
+    const int64_t tiles = (int64_t)N * H * ((W + 31) / 32);
+    int64_t grid = (tiles + 3) / 4;
+    const int64_t cap = 512;   // 2 per CU of an MI355X; a constant, so that gd_nn_conv3x3_first_stat_rows is a pure function
+    if (grid > cap) grid = cap;
+    return (int)(grid < 1 ? 1 : grid);
+}
+
+size_t gd_nn_conv3x3_first_stat_rows(int N, int H, int W, int Cin, int Cout)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 1 || Cin > 4 || Cout != 128 || g_force_variant >= 0) return 0;
+    return (size_t)first_mfma_grid(N, H, W) * 8;
+}
+
+static int first_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int H, int W,
+                         int Cin, int Cout, float* stat_part);
+
 int gd_nn_conv3x3_first_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int H,
                                 int W, int Cin, int Cout)
+{
+    return first_forward(stream, x, weight, bias, y, N, H, W, Cin, Cout, nullptr);
+}
+
+int gd_nn_conv3x3_first_forward_stats(void* stream, const void* x, const void* weight, const void* bias, void* y, int N,
+                                      int H, int W, int Cin, int Cout, float* stat_part)
+{
+    if (!stat_part) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first_forward_stats: stat_part is NULL");
+    return first_forward(stream, x, weight, bias, y, N, H, W, Cin, Cout, stat_part);
+}
+
+static int first_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int H, int W,
+                         int Cin, int Cout, float* stat_part)
 {
     if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (N <= 0 || H <= 0 || W <= 0 || Cin < 1 || Cin > 4 || Cout % 8 || Cout <= 0 || (size_t)9 * Cin * Cout * 4 > 65536)
         return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first: need 1 <= Cin <= 4, Cout % 8 == 0 and 36*Cin*Cout <= 64 KiB of LDS");
+    if (stat_part && Cout != 128) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first: statistics need Cout == 128");
+    if (Cout == 128 && g_force_variant < 0) {     // VAE encoder: the matrix-core kernel
+        if ((double)N * H * W * Cin >= 2147483648.0) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first: tensor too large");
+        const int grid = first_mfma_grid(N, H, W);
+#define GD_FIRST_M(C_)                                                                                             \
+    hipLaunchKernelGGL(conv3x3_first_mfma_kernel<C_>, dim3(grid), dim3(256), 0, (hipStream_t)stream,                \
+                       (const uint16_t*)x, (const uint16_t*)weight, (const uint16_t*)bias, (uint16_t*)y, N, H, W, stat_part)
+        if (Cin == 1) GD_FIRST_M(1);
+        else if (Cin == 2) GD_FIRST_M(2);
+        else if (Cin == 3) GD_FIRST_M(3);
+        else GD_FIRST_M(4);
+#undef GD_FIRST_M
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+        return GD_NN_OK;
+    }
     const int octs = Cout / 8, gpb = 256 / octs;
     const int64_t groups = (int64_t)N * H * ((W + 3) / 4);
     const int64_t blocks = (groups + gpb - 1) / gpb;

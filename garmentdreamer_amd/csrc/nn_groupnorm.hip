@@ -454,6 +454,42 @@ bool make_geo(int HW, int C, int G, int N, Geo* g)
     return true;
 }
 
+// mean / rstd from the per-tile partial sums a convolution's epilogue left (nn_conv3x3.hip, stat_part):
+// part[n][C/4][rows] float2 {sum, sum of squares} per 4-channel quad.  One workgroup per (image, group) adds its
+// cg/4 quads x rows partials in fp64 -- the order is fixed, so the result does not vary from run to run.
+__global__ __launch_bounds__(256) void gn_finish_partials_kernel(const float2* __restrict__ part, int rows, int C, int G,
+                                                                  double M, float eps, float* __restrict__ result)
+{
+    const int n = blockIdx.y, g = blockIdx.x;
+    const int qpg = (C / G) >> 2;
+    const float2* p = part + ((size_t)n * (C >> 2) + (size_t)g * qpg) * rows;   // the group's quads are contiguous
+    const int total = qpg * rows;
+    double sa = 0.0, sb = 0.0;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const float2 v = p[i];
+        sa += (double)v.x;
+        sb += (double)v.y;
+    }
+    __shared__ double s_a[256], s_b[256];
+    s_a[threadIdx.x] = sa;
+    s_b[threadIdx.x] = sb;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_a[threadIdx.x] += s_a[threadIdx.x + w];
+            s_b[threadIdx.x] += s_b[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = s_a[0] / M;
+        double var = s_b[0] / M - mean * mean;
+        var = var < 0 ? 0 : var;
+        result[2 * ((size_t)n * G + g)] = (float)mean;
+        result[2 * ((size_t)n * G + g) + 1] = rsqrtf((float)var + eps);
+    }
+}
+
 int fail(int code, const char* msg)
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -473,12 +509,13 @@ int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const voi
                                  int HW, int C, int G, float eps, int apply_silu, double* stats_ws, float* mean_rstd)
 {
     Geo g;
-    if (!x || !y || !gamma || !beta || !stats_ws || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!x || !y || !gamma || !beta || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (!make_geo(HW, C, G, N, &g)) return fail(GD_NN_ERR_INVALID_ARG, "need C % 8 == 0, C % G == 0, C <= 2560");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(g.nchunks, N), block(g.threads), grid_s(g.nchunks_stats, N);
-    hipLaunchKernelGGL(gn_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows,
-                       g.ppb_stats, eps, stats_ws, mean_rstd, N, 0);
+    if (stats_ws)   // NULL: mean_rstd is an INPUT (gd_nn_groupnorm_finish_partials, or a previous statistics pass)
+        hipLaunchKernelGGL(gn_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows,
+                           g.ppb_stats, eps, stats_ws, mean_rstd, N, 0);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (bf16x8*)y, (const uint16_t*)gamma,
                        (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, apply_silu, mean_rstd);
     hipError_t e = hipGetLastError();
@@ -514,6 +551,19 @@ int gd_nn_groupnorm_stats(void* stream, const void* x, int N, int HW, int C, int
     dim3 block(g.threads), grid_s(g.nchunks_stats, N);
     hipLaunchKernelGGL(gn_stats_kernel, grid_s, block, g.lds, s, (const bf16x8*)x, HW, C, G, g.vpp, g.rows,
                        g.ppb_stats, eps, stats_ws, mean_rstd, N, 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_groupnorm_finish_partials(void* stream, const float* stat_part, int N, size_t rows, int C, int G, int HW,
+                                    float eps, float* mean_rstd)
+{
+    if (!stat_part || !mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || rows == 0 || rows > (1u << 24) || G <= 0 || C % G || (C / G) % 4 || HW <= 0)
+        return fail(GD_NN_ERR_INVALID_ARG, "finish_partials: need C % G == 0 and (C / G) % 4 == 0");
+    hipLaunchKernelGGL(gn_finish_partials_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)stat_part, (int)rows, C, G, (double)HW * (double)(C / G), eps, mean_rstd);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

@@ -136,9 +136,9 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = nn.Conv2d(out_ch, out_ch, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
-    def forward(self, x, temb=None):
+    def forward(self, x, temb=None, next_norm=None):
         if resnet_block_frozen_supported(x, self):   # VAE encoder inside the SDS graph: one autograd node per block
-            return resnet_block_frozen(x, self)
+            return resnet_block_frozen(x, self, next_norm)
         image_bias = None
         if isinstance(temb, TembProjections):   # projected for every block at once (UNet2DConditionModel.forward)
             image_bias = temb.image_bias.get(id(self))
@@ -653,9 +653,10 @@ class _VAEDownBlock(nn.Module):
             [ResnetBlock2D(in_ch if i == 0 else out_ch, out_ch, None, eps=1e-6) for i in range(n_layers)])
         self.downsamplers = nn.ModuleList([Downsample2D(out_ch, padding=0)]) if down else None
 
-    def forward(self, x):
-        for r in self.resnets:
-            x = r(x)
+    def forward(self, x, next_norm=None):
+        for i, r in enumerate(self.resnets):   # the next block's GroupNorm gets its statistics from this block's conv2
+            last = i + 1 == len(self.resnets)
+            x = r(x, next_norm=(next_norm if self.downsamplers is None else None) if last else self.resnets[i + 1].norm1)
         if self.downsamplers is not None:
             x = self.downsamplers[0](x)
         return x
@@ -686,9 +687,10 @@ class Encoder(nn.Module):
         self.conv_out = nn.Conv2d(ch[-1], 2 * latent_channels, 3, padding=1)
 
     def forward(self, x):
-        x = conv3x3_small_cin(x.contiguous(memory_format=torch.channels_last), self.conv_in.weight, self.conv_in.bias)
-        for b in self.down_blocks:
-            x = b(x)
+        x = conv3x3_small_cin(x.contiguous(memory_format=torch.channels_last), self.conv_in.weight, self.conv_in.bias,
+                              next_norm=self.down_blocks[0].resnets[0].norm1)
+        for i, b in enumerate(self.down_blocks):
+            x = b(x, next_norm=self.mid_block.resnets[0].norm1 if i + 1 == len(self.down_blocks) else None)
         x = self.mid_block(x)
         return _conv3(self.conv_out, _gn(self.conv_norm_out, x, True))
 

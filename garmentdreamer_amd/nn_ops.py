@@ -28,6 +28,13 @@ SIGNATURES = {
     "gd_nn_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "gd_nn_groupnorm_silu_forward_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _f]),
     "gd_nn_conv3x3_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_stat_rows": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_first_stat_rows": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_first_forward_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gd_nn_conv3x3_gn_forward_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
+                                            _vp]),
+    "gd_nn_conv3x3_forward_stats": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gd_nn_groupnorm_finish_partials": (_i, [_vp, _vp, _i, C.c_size_t, _i, _i, _i, _f, _vp]),
     "gd_nn_conv3x3_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
@@ -271,12 +278,14 @@ class _Conv3x3(torch.autograd.Function):
 
 
 class _ConvSmallCin(torch.autograd.Function):
-    """First VAE convolution (Cin = 3): forward on the small-Cin VALU kernel (gd_nn_conv3x3_first_forward; an
-    output-write stream), input gradient through the MFMA kernel with the flipped weights zero-padded to 4 output
-    channels (the library dgrad for this shape costs 2.7 ms per step on MI355X; this path ~0.6 ms)."""
+    """First VAE convolution (Cin = 3): forward on gd_nn_conv3x3_first_forward (matrix-core kernel for the VAE's 128
+    output channels, VALU kernel otherwise; an output-write stream), input gradient through the MFMA kernel with the
+    flipped weights zero-padded to 4 output channels (the library dgrad for this shape costs 2.7 ms per step on
+    MI355X; this path ~0.6 ms).  ``next_norm`` = (groups, eps): GroupNorm statistics of the result from the kernel's
+    epilogue, returned as a second (non-differentiable) output, or None when the shape has no such path."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, next_norm=None):
         ctx.weight = weight
         ctx.x_shape = x.shape
         N, Cin, H, W = x.shape
@@ -286,20 +295,37 @@ class _ConvSmallCin(torch.autograd.Function):
             wc = weight.contiguous(memory_format=torch.channels_last)
             y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
             L = lib()
+            rows = 0
+            if next_norm is not None and _EPILOGUE_STATS and Cout % (4 * next_norm[0]) == 0:
+                rows = L.gd_nn_conv3x3_first_stat_rows(N, H, W, Cin, Cout)
+            mr_next = None
             with torch.cuda.device(x.device):
-                ret = L.gd_nn_conv3x3_first_forward(torch.cuda.current_stream(x.device).cuda_stream, xc.data_ptr(),
-                                                    wc.data_ptr(), None if bias is None else bias.data_ptr(),
-                                                    y.data_ptr(), N, H, W, Cin, Cout)
-            if ret < 0:
-                raise RuntimeError(f"gd_nn_conv3x3_first_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
-            return y
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+                bias_p = None if bias is None else bias.data_ptr()
+                if rows:
+                    part = torch.empty(N * (Cout // 4) * rows * 2, dtype=torch.float32, device=x.device)
+                    ret = L.gd_nn_conv3x3_first_forward_stats(stream, xc.data_ptr(), wc.data_ptr(), bias_p, y.data_ptr(),
+                                                              N, H, W, Cin, Cout, part.data_ptr())
+                else:
+                    ret = L.gd_nn_conv3x3_first_forward(stream, xc.data_ptr(), wc.data_ptr(), bias_p, y.data_ptr(), N, H,
+                                                        W, Cin, Cout)
+                if ret < 0:
+                    raise RuntimeError(f"gd_nn_conv3x3_first_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+                if rows:
+                    mr_next = torch.empty(N * next_norm[0] * 2, dtype=torch.float32, device=x.device)
+                    _check(L.gd_nn_groupnorm_finish_partials(stream, part.data_ptr(), N, rows, Cout, next_norm[0], H * W,
+                                                             float(next_norm[1]), mr_next.data_ptr()),
+                           "gd_nn_groupnorm_finish_partials")
+            if mr_next is not None:
+                ctx.mark_non_differentiable(mr_next)
+            return y, mr_next
         with torch.no_grad():
-            return F.conv2d(x, weight, bias, padding=1)
+            return F.conv2d(x, weight, bias, padding=1), None
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dmr=None):
         if not ctx.needs_input_grad[0]:
-            return None, None, None
+            return None, None, None, None
         w = ctx.weight
         Cout, Cin = w.shape[0], w.shape[1]
         f = getattr(w, "_gd_flipped4", None)
@@ -316,14 +342,19 @@ class _ConvSmallCin(torch.autograd.Function):
             w._gd_flipped4, w._gd_flipped4_key = f, key
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx4 = _conv_launch(dy, f, None, None, 4)
-        return dx4[:, :Cin], None, None
+        return dx4[:, :Cin], None, None, None
 
 
-def conv3x3_small_cin(x, weight, bias):
-    """3x3/s1/p1 convolution with Cin <= 4 (image -> features)."""
+def conv3x3_small_cin(x, weight, bias, next_norm=None):
+    """3x3/s1/p1 convolution with Cin <= 4 (image -> features).  ``next_norm``: the GroupNorm module that consumes the
+    result, if known -- its statistics then ride on the returned tensor (see ``resnet_block_frozen``)."""
     if (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.shape[1] <= 4
             and weight.shape[0] % 64 == 0 and not weight.requires_grad):
-        return _ConvSmallCin.apply(x, weight, bias)
+        nn_ = None if next_norm is None else (next_norm.num_groups, next_norm.eps)
+        y, mr_next = _ConvSmallCin.apply(x, weight, bias, nn_)
+        if mr_next is not None:
+            y._gd_gn_stats = (mr_next, nn_[0], nn_[1], y._version)
+        return y
     return F.conv2d(x, weight, bias, padding=1)
 
 
@@ -481,32 +512,62 @@ def _gn_bwd_launch(x, dy, gw, gb, mr, groups, silu, add=None):
     return dx
 
 
-def _gnconv_forward(x, gw, gb, groups, eps, w, bias, residual):
-    """``conv3x3(silu(group_norm(x))) + bias (+ residual)`` without autograd; returns (y, mean_rstd)."""
+def _gnconv_forward(x, gw, gb, groups, eps, w, bias, residual, mr=None, next_norm=None):
+    """``conv3x3(silu(group_norm(x))) + bias (+ residual)`` without autograd; returns (y, mean_rstd, next_mean_rstd).
+    ``mr``: statistics of x already known (skips the statistics pass).  ``next_norm`` = (groups, eps) of a GroupNorm
+    that consumes y: its statistics come out of this convolution's epilogue (gd_nn_conv3x3_*_stats +
+    gd_nn_groupnorm_finish_partials) when the shape runs on a patch-staged kernel, else ``next_mean_rstd`` is None
+    and the consumer runs its own statistics pass."""
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     L = lib()
-    ws = _gn_workspace(x, N, groups)
-    mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+    fused = gn_conv_prefers_fused(x, Cout)
+    ws = _gn_workspace(x, N, groups) if mr is None else None
+    have_mr = mr is not None
+    if mr is None:
+        mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+    rows = 0
+    if next_norm is not None and _EPILOGUE_STATS and Cout % next_norm[0] == 0 and (Cout // next_norm[0]) % 4 == 0:
+        rows = L.gd_nn_conv3x3_stat_rows(N, H, W, Cout, int(fused))
+    part = torch.empty(N * (Cout // 4) * rows * 2, dtype=torch.float32, device=x.device) if rows else None
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        if gn_conv_prefers_fused(x, Cout):
-            y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-            bias_c, stride = _bias_and_stride(bias)
-            _check(L.gd_nn_groupnorm_stats(stream, x.data_ptr(), N, H * W, Cin, groups, float(eps), ws.data_ptr(),
-                                           mr.data_ptr()), "gd_nn_groupnorm_stats")
-            ret = L.gd_nn_conv3x3_gn_forward(stream, x.data_ptr(), mr.data_ptr(), gw.data_ptr(), gb.data_ptr(), groups,
-                                             1, w.data_ptr(), None if bias_c is None else bias_c.data_ptr(), stride,
-                                             None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W,
-                                             Cin, Cout)
+        y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        bias_c, stride = _bias_and_stride(bias)
+        bias_p = None if bias_c is None else bias_c.data_ptr()
+        res_p = None if residual is None else residual.data_ptr()
+        if fused:
+            if not have_mr:
+                _check(L.gd_nn_groupnorm_stats(stream, x.data_ptr(), N, H * W, Cin, groups, float(eps), ws.data_ptr(),
+                                               mr.data_ptr()), "gd_nn_groupnorm_stats")
+            ret = L.gd_nn_conv3x3_gn_forward_stats(stream, x.data_ptr(), mr.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                                   groups, 1, w.data_ptr(), bias_p, stride, res_p, y.data_ptr(), N, H, W,
+                                                   Cin, Cout, None if part is None else part.data_ptr())
             if ret < 0:
                 raise RuntimeError(f"gd_nn_conv3x3_gn_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
-            return y, mr
-        act = torch.empty_like(x, memory_format=torch.channels_last)
-        _check(L.gd_nn_groupnorm_silu_forward(stream, x.data_ptr(), act.data_ptr(), gw.data_ptr(), gb.data_ptr(), N,
-                                              H * W, Cin, groups, float(eps), 1, ws.data_ptr(), mr.data_ptr()),
-               "gd_nn_groupnorm_silu_forward")
-    return _conv_launch(act, w, bias, residual, Cout), mr
+        else:
+            act = torch.empty_like(x, memory_format=torch.channels_last)
+            _check(L.gd_nn_groupnorm_silu_forward(stream, x.data_ptr(), act.data_ptr(), gw.data_ptr(), gb.data_ptr(), N,
+                                                  H * W, Cin, groups, float(eps), 1, None if have_mr else ws.data_ptr(),
+                                                  mr.data_ptr()), "gd_nn_groupnorm_silu_forward")
+            if part is None:
+                return _conv_launch(act, w, bias, residual, Cout), mr, None
+            ret = L.gd_nn_conv3x3_forward_stats(stream, act.data_ptr(), w.data_ptr(), bias_p, stride, res_p, y.data_ptr(),
+                                                N, H, W, Cin, Cout, part.data_ptr())
+            if ret < 0:
+                raise RuntimeError(f"gd_nn_conv3x3_forward_stats failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+        mr_next = None
+        if part is not None:
+            g2, eps2 = next_norm
+            mr_next = torch.empty(N * g2 * 2, dtype=torch.float32, device=x.device)
+            _check(L.gd_nn_groupnorm_finish_partials(stream, part.data_ptr(), N, rows, Cout, g2, H * W, float(eps2),
+                                                     mr_next.data_ptr()), "gd_nn_groupnorm_finish_partials")
+    return y, mr, mr_next
+
+
+# GD_NN_EPILOGUE_STATS=0: every GroupNorm runs its own statistics pass (A/B timing of the epilogue statistics in
+# tools/; never set in tests or the benchmark)
+_EPILOGUE_STATS = os.environ.get("GD_NN_EPILOGUE_STATS", "1") != "0"
 
 
 class _ResnetBlockFrozen(torch.autograd.Function):
@@ -517,18 +578,24 @@ class _ResnetBlockFrozen(torch.autograd.Function):
     (``add`` of gd_nn_groupnorm_silu_backward).  Saves x and conv1's output, as the separate nodes did."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, scw, scb, groups, eps):
-        h, mr1 = _gnconv_forward(x, n1w, n1b, groups, eps, c1w, c1b, None)
+    def forward(ctx, x, n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, scw, scb, groups, eps, mr_in, next_norm):
+        # GroupNorm statistics travel with the tensors: norm2's come out of conv1's epilogue, the next block's norm1's
+        # (next_norm) out of conv2's, and this block's norm1 takes mr_in from its producer -- each saves a full read
+        # of the activation (gd_nn.h, gd_nn_conv3x3_gn_forward_stats)
+        h, mr1, mr2 = _gnconv_forward(x, n1w, n1b, groups, eps, c1w, c1b, None, mr=mr_in, next_norm=(groups, eps))
         skip = x
         if scw is not None:
             skip = F.linear(x.permute(0, 2, 3, 1), scw.flatten(1), scb).permute(0, 3, 1, 2)
-        y, mr2 = _gnconv_forward(h, n2w, n2b, groups, eps, c2w, c2b, skip)
+        y, mr2, mr_next = _gnconv_forward(h, n2w, n2b, groups, eps, c2w, c2b, skip, mr=mr2, next_norm=next_norm)
         ctx.save_for_backward(x, h, mr1, mr2, n1w, n1b, n2w, n2b)
         ctx.c1w, ctx.c2w, ctx.scw, ctx.groups = c1w, c2w, scw, groups
-        return y
+        if mr_next is None:
+            return y, None
+        ctx.mark_non_differentiable(mr_next)
+        return y, mr_next
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dmr=None):
         x, h, mr1, mr2, n1w, n1b, n2w, n2b = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         if dy.dtype != torch.bfloat16:
@@ -540,7 +607,7 @@ class _ResnetBlockFrozen(torch.autograd.Function):
         if ctx.scw is not None:   # 1x1 shortcut: its input gradient is a plain GEMM on the NHWC view
             g_skip = torch.matmul(dy.permute(0, 2, 3, 1), ctx.scw.flatten(1)).permute(0, 3, 1, 2)
         dx = _gn_bwd_launch(x, dact1, n1w, n1b, mr1, ctx.groups, True, add=g_skip)
-        return (dx,) + (None,) * 12
+        return (dx,) + (None,) * 14
 
 
 def resnet_block_frozen_supported(x, block) -> bool:
@@ -557,14 +624,25 @@ def resnet_block_frozen_supported(x, block) -> bool:
             and block.norm1.eps == block.norm2.eps)
 
 
-def resnet_block_frozen(x, block):
+def resnet_block_frozen(x, block, next_norm=None):
+    """``next_norm``: the GroupNorm module that will consume the result (the next block's norm1), if the caller knows
+    it: its statistics are then produced by this block's last convolution and ride on the returned tensor
+    (``_gd_gn_stats``), where the next ``resnet_block_frozen`` call finds them."""
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
     sc = block.conv_shortcut
-    return _ResnetBlockFrozen.apply(x, block.norm1.weight, block.norm1.bias, block.conv1.weight, block.conv1.bias,
-                                    block.norm2.weight, block.norm2.bias, block.conv2.weight, block.conv2.bias,
-                                    None if sc is None else sc.weight, None if sc is None else sc.bias,
-                                    block.norm1.num_groups, block.norm1.eps)
+    mr_in = None
+    tag = getattr(x, "_gd_gn_stats", None)
+    if tag is not None and tag[1:] == (block.norm1.num_groups, block.norm1.eps, x._version):
+        mr_in = tag[0]
+    nn_ = None if next_norm is None else (next_norm.num_groups, next_norm.eps)
+    y, mr_next = _ResnetBlockFrozen.apply(x, block.norm1.weight, block.norm1.bias, block.conv1.weight, block.conv1.bias,
+                                          block.norm2.weight, block.norm2.bias, block.conv2.weight, block.conv2.bias,
+                                          None if sc is None else sc.weight, None if sc is None else sc.bias,
+                                          block.norm1.num_groups, block.norm1.eps, mr_in, nn_)
+    if mr_next is not None:
+        y._gd_gn_stats = (mr_next, nn_[0], nn_[1], y._version)
+    return y
 
 
 def _up2_weights(weight):

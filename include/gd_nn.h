@@ -28,7 +28,8 @@ extern "C" {
  * stats_ws: gd_nn_groupnorm_ws_bytes(N, G) bytes that are ZERO on entry (zero-initialise once; every call
  * leaves them zero again, so one workspace serves all calls on a stream -- the last statistics workgroup
  * finalises and clears, there is no memset / finalize launch); mean_rstd: N*G*2 floats out (saved for backward).  Replaces F.group_norm + F.silu (two kernels + two NCHW<->NHWC copies in
- * PyTorch-ROCm's native path). */
+ * PyTorch-ROCm's native path).  stats_ws == NULL: mean_rstd is an INPUT (statistics already known -- from
+ * gd_nn_groupnorm_finish_partials or gd_nn_groupnorm_stats) and only the apply pass runs. */
 int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
                                  int HW, int C, int G, float eps, int apply_silu, double* stats_ws,
                                  float* mean_rstd);
@@ -98,9 +99,35 @@ int gd_nn_conv3x3_gn_forward(void* stream, const void* x, const float* mean_rstd
                              int groups, int apply_silu, const void* weight, const void* bias, int bias_img_stride,
                              const void* residual, void* y, int N, int H, int W, int Cin, int Cout);
 
+/* GroupNorm statistics of a convolution's OUTPUT from that convolution's epilogue, for ResnetBlock2D chains
+ * (conv -> GroupNorm -> conv ...: Garment_Deformer_NeTF/netf/vsd/lora_unet.py:119-160 pattern; the VAE encoder of
+ * threestudio's StableDiffusionGuidance.encode_images is eleven such blocks): the statistics pass of the next
+ * GroupNorm is a full re-read of the tensor just written (537 MB at the 512^2 level, 8 views).  The `_stats` entries
+ * run the patch-staged kernels with one extra output: stat_part[N][Cout/4][rows] float2 = {sum, sum of squares} of the
+ * bf16 values stored, per 4-channel quad and per 16-pixel row segment of a tile; rows =
+ * gd_nn_conv3x3_stat_rows(N, H, W, Cout, gn_entry) (0: this shape does not run on a patch-staged kernel --
+ * gn_entry = 1 for gd_nn_conv3x3_gn_forward_stats, which always does).  Every element of stat_part is written by
+ * every call (no zeroing needed, no atomics: the statistics are bit-reproducible).
+ * gd_nn_groupnorm_finish_partials turns them into mean_rstd[N][G][2] (fp64 sums; needs (C / G) % 4 == 0). */
+size_t gd_nn_conv3x3_stat_rows(int N, int H, int W, int Cout, int gn_entry);
+int gd_nn_conv3x3_gn_forward_stats(void* stream, const void* x, const float* mean_rstd, const void* gamma,
+                                   const void* beta, int groups, int apply_silu, const void* weight, const void* bias,
+                                   int bias_img_stride, const void* residual, void* y, int N, int H, int W, int Cin,
+                                   int Cout, float* stat_part);
+int gd_nn_conv3x3_forward_stats(void* stream, const void* x, const void* weight, const void* bias, int bias_img_stride,
+                                const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
+/* ... and of the first convolution (gd_nn_conv3x3_first_forward below; Cout == 128 only, the VAE encoder's conv_in):
+ * rows = gd_nn_conv3x3_first_stat_rows(N, H, W, Cin, Cout), 0 when that shape has no statistics path. */
+size_t gd_nn_conv3x3_first_stat_rows(int N, int H, int W, int Cin, int Cout);
+int gd_nn_conv3x3_first_forward_stats(void* stream, const void* x, const void* weight, const void* bias, void* y, int N,
+                                      int H, int W, int Cin, int Cout, float* stat_part);
+int gd_nn_groupnorm_finish_partials(void* stream, const float* stat_part, int N, size_t rows, int C, int G, int HW,
+                                    float eps, float* mean_rstd);
+
 /* First convolution (image / latent -> features): 3x3 / s1 / p1 with Cin <= 4, + bias.  x: bf16 [N,H,W,Cin];
  * weight: bf16 [Cout][3][3][Cin]; y: bf16 [N,H,W,Cout]; Cout % 8 == 0, 36*Cin*Cout bytes of LDS <= 64 KiB.
- * VALU kernel (diffusers `conv_in` of the VAE encoder and of the UNet). */
+ * Cout == 128 (diffusers `conv_in` of the VAE encoder): matrix-core kernel, im2col operand gathered from the image,
+ * bias as an extra K column; other Cout (the UNet's 320): VALU kernel. */
 int gd_nn_conv3x3_first_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int N, int H,
                                 int W, int Cin, int Cout);
 

@@ -141,6 +141,92 @@ def test_vae_resnet_block_as_one_autograd_node_matches_fp32_reference(N, cin, co
     assert F.cosine_similarity(xb.grad.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.999
 
 
+@pytest.mark.parametrize("N,cin,cout,H,W,res", [(2, 128, 128, 256, 256, False),   # GroupNorm-in-loader kernel, BN = 128
+                                                (1, 128, 256, 512, 256, True),    # ... BN = 256
+                                                (8, 256, 512, 64, 64, True),      # persistent plain kernel, BN = 256
+                                                (3, 128, 128, 250, 270, True),    # ragged: edge tiles, fused
+                                                (5, 192, 384, 100, 75, False)])   # ragged, persistent, BN = 128
+def test_groupnorm_statistics_from_the_conv_epilogue_match_the_statistics_pass(N, cin, cout, H, W, res):
+    """gd_nn_conv3x3_*_stats + gd_nn_groupnorm_finish_partials: mean / rstd of the convolution's OUTPUT as left by
+    its epilogue against gd_nn_groupnorm_stats run over that output, and against fp64 torch; the output itself is
+    bit-identical with and without the statistics; two launches give bit-identical statistics (no atomics)."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(N * 1000 + H)
+    cl = torch.channels_last
+    x = (torch.randn(N, cin, H, W, device=DEV, generator=g) * 1.5 + 0.3).to(torch.bfloat16).contiguous(memory_format=cl)
+    w = (torch.randn(cout, cin, 3, 3, device=DEV, generator=g) * 0.03).to(torch.bfloat16).contiguous(memory_format=cl)
+    b = torch.randn(cout, device=DEV, generator=g).to(torch.bfloat16)
+    gw = (1 + 0.1 * torch.randn(cin, device=DEV, generator=g)).to(torch.bfloat16)
+    gb = (0.1 * torch.randn(cin, device=DEV, generator=g)).to(torch.bfloat16)
+    r = torch.randn(N, cout, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl) if res else None
+    groups, eps = 32, 1e-6
+    y0, mr0, none = nn_ops._gnconv_forward(x, gw, gb, groups, eps, w, b, r)
+    assert none is None
+    y1, mr1, mrn = nn_ops._gnconv_forward(x, gw, gb, groups, eps, w, b, r, next_norm=(groups, eps))
+    assert mrn is not None, "this shape should run on a patch-staged kernel"
+    assert torch.equal(y0, y1) and torch.equal(mr0, mr1)
+    y2, _, mrn2 = nn_ops._gnconv_forward(x, gw, gb, groups, eps, w, b, r, mr=mr1, next_norm=(groups, eps))
+    assert torch.equal(y1, y2) and torch.equal(mrn, mrn2)
+    ws = nn_ops._gn_workspace(y1, N, groups)
+    ref = torch.empty_like(mrn)
+    nn_ops._check(nn_ops.lib().gd_nn_groupnorm_stats(torch.cuda.current_stream().cuda_stream, y1.data_ptr(), N, H * W, cout,
+                                                     groups, eps, ws.data_ptr(), ref.data_ptr()), "gd_nn_groupnorm_stats")
+    yd = y1.double().reshape(N, groups, cout // groups, H * W)
+    mean64, var64 = yd.mean(dim=(2, 3)), yd.var(dim=(2, 3), unbiased=False)
+    got = mrn.view(N, groups, 2).double()
+    assert torch.allclose(got[..., 0], mean64, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got[..., 1], (var64 + eps).rsqrt(), rtol=1e-5)
+    assert torch.allclose(mrn, ref, rtol=2e-6, atol=1e-7)
+
+
+def test_vae_encoder_with_epilogue_statistics_equals_the_statistics_pass_path(monkeypatch):
+    """The VAE encoder with GroupNorm statistics riding on the tensors (conv epilogue -> next GroupNorm) against the
+    same encoder with a statistics pass per GroupNorm: latents and image gradient agree to bf16 rounding noise, and
+    the fast path really skipped the passes (counted at the C-ABI)."""
+    from garmentdreamer_amd import nn_ops
+    from garmentdreamer_amd.guidance import sd21
+    torch.manual_seed(3)
+    vae = sd21.AutoencoderKLEncoder().to(DEV).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    for p_ in vae.parameters():
+        p_.requires_grad_(False)
+    g = torch.Generator(DEV).manual_seed(5)
+    img = torch.rand(4, 3, 256, 256, device=DEV, generator=g).to(torch.bfloat16)
+    gy = torch.randn(4, 4, 32, 32, device=DEV, generator=g).to(torch.bfloat16)
+
+    L = nn_ops.lib()
+    passes = {"n": 0}
+    real_stats, real_fwd = L.gd_nn_groupnorm_stats, L.gd_nn_groupnorm_silu_forward
+
+    def counted_stats(*a):
+        passes["n"] += 1
+        return real_stats(*a)
+
+    def counted_fwd(*a):
+        passes["n"] += a[11] is not None      # stats_ws given: the call runs its own statistics pass
+        return real_fwd(*a)
+
+    monkeypatch.setattr(L, "gd_nn_groupnorm_stats", counted_stats)
+    monkeypatch.setattr(L, "gd_nn_groupnorm_silu_forward", counted_fwd)
+
+    def run(flag):
+        monkeypatch.setattr(nn_ops, "_EPILOGUE_STATS", flag)
+        passes["n"] = 0
+        x = img.clone().requires_grad_(True)
+        z = vae.encode(x * 2 - 1).latent_dist.mean
+        z.backward(gy)
+        return z.detach().float(), x.grad.detach().float(), passes["n"]
+
+    z0, g0, n0 = run(False)
+    z1, g1, n1 = run(True)
+    # 11 ResnetBlock2D = 22 GroupNorms (+ mid attention + conv_norm_out); with 4 images of 256^2 the two top levels run
+    # on the patch-staged kernels: norm2 of both blocks and norm1 of the second block, per level, ride on the tensors
+    # ... and norm1 of the very first block takes them from conv_in
+    assert n0 >= 22 and n1 == n0 - 7, (n0, n1)
+    assert F.cosine_similarity(z0.flatten(), z1.flatten(), dim=0).item() > 0.9999
+    assert F.cosine_similarity(g0.flatten(), g1.flatten(), dim=0).item() > 0.999
+    assert (z0 - z1).abs().max().item() <= 2e-2 * z0.abs().max().item()
+
+
 def test_unet_and_vae_bf16_hip_path_tracks_fp32_torch_path():
     """Whole small UNet / VAE: bf16 + HIP GroupNorm kernels vs the same weights in fp32 torch ops."""
     from garmentdreamer_amd.guidance import sd21
@@ -247,6 +333,32 @@ def test_first_conv_small_cin_and_conv1x1_match_torch():
     r1 = F.conv2d(x1.float(), w1.float(), b1.float())
     assert y1.shape == r1.shape and y1.is_contiguous(memory_format=torch.channels_last)
     assert (y1.float() - r1).abs().max().item() <= 2e-2 * r1.abs().max().item()
+
+
+@pytest.mark.parametrize("N,cin,H,W,with_bias", [(2, 3, 40, 56, True), (1, 3, 512, 512, True), (3, 4, 33, 100, False),
+                                                  (2, 1, 7, 31, True), (1, 2, 64, 32, True)])
+def test_first_conv_on_the_matrix_cores_and_its_groupnorm_statistics(N, cin, H, W, with_bias):
+    """gd_nn_conv3x3_first_forward for Cout = 128 (im2col gathered per lane, bias as a K column) against fp32 torch --
+    to one bf16 rounding of the result, since products of bf16 values and their fp32 sums are what torch computes
+    too -- and the epilogue's GroupNorm statistics against fp64 statistics of the stored tensor."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(N + 10 * cin + H)
+    cl = torch.channels_last
+    x = (torch.rand(N, cin, H, W, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16).contiguous(memory_format=cl)
+    w = (torch.randn(128, cin, 3, 3, device=DEV, generator=g) / 4).to(torch.bfloat16).contiguous(memory_format=cl)
+    b = torch.randn(128, device=DEV, generator=g).to(torch.bfloat16) if with_bias else None
+    y, mrn = nn_ops._ConvSmallCin.apply(x, w, b, (32, 1e-6))
+    y_plain, none = nn_ops._ConvSmallCin.apply(x, w, b, None)
+    assert none is None and torch.equal(y, y_plain)
+    ref = F.conv2d(x.float(), w.float(), None if b is None else b.float(), padding=1)
+    assert (y.float() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+    assert mrn is not None
+    yd = y.double().reshape(N, 32, 4, H * W)
+    got = mrn.view(N, 32, 2).double()
+    assert torch.allclose(got[..., 0], yd.mean(dim=(2, 3)), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got[..., 1], (yd.var(dim=(2, 3), unbiased=False) + 1e-6).rsqrt(), rtol=1e-5)
+    _, mrn2 = nn_ops._ConvSmallCin.apply(x, w, b, (32, 1e-6))
+    assert torch.equal(mrn, mrn2)
 
 
 def test_vsd_step_runs_through_hip_kernels_with_lora_backward():
