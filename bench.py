@@ -73,8 +73,8 @@ def latest_profile(pattern: str):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--gaussians", type=int, default=100000)
     ap.add_argument("--res", type=int, default=512)

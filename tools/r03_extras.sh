@@ -11,6 +11,7 @@ python bench.py --vsd --fp8 --res 1024 --steps 10 --warmup 8 2>/dev/null | tail 
 python bench.py --raster-only --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | tail -1 > $o/bench_raster_only_line.json
 python bench.py --raster-only --views 1 --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | tail -1 > $o/bench_raster_only_V1_line.json
 python tools/densify_time.py > $o/densify_time.txt 2>&1
+bash tools/steady_profile.sh $o/bench_V1_kernel_stats_steady.csv --views 1 > $o/bench_V1_steady.txt 2>&1
 bash tools/pmc_raster.sh $o/pmc_raster.txt > /dev/null 2>&1
 for f in $o/*.json; do python -c "
 import json,sys
