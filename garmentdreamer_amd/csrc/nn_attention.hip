@@ -184,15 +184,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
     };
     // Part 2: P = exp2((s - m) c) in place, row sum, O^T += V^T P^T from the V stage at `pv`.
     auto exp_pv = [&](f32x16& s0, f32x16& s1, const char* pv) {
-        const float mc = m_run * c;
-        float psum = 0.f;
+        // two scores per v_pk_fma_f32 / v_pk_add_f32: a packed fp32 instruction holds the SIMD ~5.5 cycles against
+        // 2 x 4.5 for the scalar pair (tools/probes/valu_rate_probe.hip), and this loop is VALU-bound
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 c2 = {c, c}, nmc = {-m_run * c, -m_run * c};
+        f2 psum = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
-            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-            psum += s0[r] + s1[r];
+        for (int r = 0; r < 16; r += 2) {
+            const f2 a = f2{s0[r], s0[r + 1]} * c2 + nmc, b = f2{s1[r], s1[r + 1]} * c2 + nmc;
+            s0[r] = __builtin_amdgcn_exp2f(a.x);
+            s0[r + 1] = __builtin_amdgcn_exp2f(a.y);
+            s1[r] = __builtin_amdgcn_exp2f(b.x);
+            s1[r + 1] = __builtin_amdgcn_exp2f(b.y);
+            psum += f2{s0[r], s0[r + 1]} + f2{s1[r], s1[r + 1]};
         }
-        l_run += psum;
+        l_run += psum.x + psum.y;
         // P (bf16) as the B operand: regs 8u..8u+7 of score block j  <->  16-key group 2j+u
         bf16x8_t pb[4];
 #pragma unroll
