@@ -179,6 +179,39 @@ def test_groupnorm_statistics_from_the_conv_epilogue_match_the_statistics_pass(N
     assert torch.allclose(mrn, ref, rtol=2e-6, atol=1e-7)
 
 
+def test_statistics_riding_on_a_tensor_are_dropped_when_the_tensor_changes():
+    """``_gd_gn_stats`` (statistics a producer left on its output) is only honoured for the very tensor version and
+    GroupNorm configuration it was made for: an in-place edit of the tensor, or a consumer with other groups / eps,
+    falls back to a statistics pass -- same result as without any riding statistics."""
+    from garmentdreamer_amd import nn_ops
+    from garmentdreamer_amd.guidance import sd21
+    torch.manual_seed(11)
+    with torch.device(DEV):
+        b1 = sd21.init_random_(sd21.ResnetBlock2D(128, 128, None, eps=1e-6))
+        b2 = sd21.init_random_(sd21.ResnetBlock2D(128, 128, None, eps=1e-6))
+        b3 = sd21.init_random_(sd21.ResnetBlock2D(128, 128, None, eps=1e-5))
+    for b in (b1, b2, b3):
+        b.to(torch.bfloat16).to(memory_format=torch.channels_last)
+        for p_ in b.parameters():
+            p_.requires_grad_(False)
+    x = torch.randn(2, 128, 256, 256, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    y = b1(x, next_norm=b2.norm1)
+    assert getattr(y, "_gd_gn_stats", None) is not None
+    ref_same = b2(y.detach().clone().requires_grad_(True))          # no riding statistics: own pass
+    got_same = b2(y)                                                  # riding statistics
+    assert F.cosine_similarity(ref_same.float().flatten(), got_same.float().flatten(), dim=0).item() > 0.99999
+    # another eps: the tag does not match, the consumer runs its own pass -> bit-identical to the untagged call
+    assert torch.equal(b3(y), b3(y.detach().clone().requires_grad_(True)))
+    # in-place edit: the version counter moved on, the stale statistics must not be used
+    with torch.no_grad():
+        y2 = y.detach().clone()
+        y2._gd_gn_stats = y._gd_gn_stats[:3] + (y2._version,)
+        y2.mul_(3.0)
+    y2.requires_grad_(True)
+    assert torch.equal(b2(y2), b2(y2.detach().clone().requires_grad_(True)))
+
+
 def test_vae_encoder_with_epilogue_statistics_equals_the_statistics_pass_path(monkeypatch):
     """The VAE encoder with GroupNorm statistics riding on the tensors (conv epilogue -> next GroupNorm) against the
     same encoder with a statistics pass per GroupNorm: latents and image gradient agree to bf16 rounding noise, and
