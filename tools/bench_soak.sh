@@ -1,4 +1,4 @@
-cd /root/repo
+cd $(dirname $0)/..
 ok=0; bad=0
 for i in $(seq 1 16); do
   out=$(python bench.py --no-cpu-baseline --steps 10 --warmup 3 2>&1 | tail -1)
