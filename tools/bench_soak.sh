@@ -1,3 +1,5 @@
+#!/bin/bash
+# Sixteen default-size bench runs back to back: step times and the count of runs the health check refused (non-finite parameters).
 cd $(dirname $0)/..
 ok=0; bad=0
 for i in $(seq 1 16); do

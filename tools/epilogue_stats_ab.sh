@@ -1,4 +1,6 @@
-cd /root/repo
+#!/bin/bash
+# Same-box A/B of the GroupNorm statistics from the convolution epilogues: default bench with GD_NN_EPILOGUE_STATS=0 / 1, interleaved.
+cd $(dirname $0)/..
 for i in 1 2 3; do
   for f in 0 1; do
     GD_NN_EPILOGUE_STATS=$f python bench.py --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "
