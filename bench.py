@@ -247,7 +247,7 @@ def vsd_main(args):
         raise SystemExit(f"bench.py --vsd: unhealthy run {health}")
     if rk == 0:
         tfl = 3 * UNET_TFLOP_PER_SAMPLE + 2 * VAE_TFLOP_PER_IMAGE + 3 * UNET_TFLOP_PER_SAMPLE
-        print(json.dumps({"metric": "NeTF VSD iters/sec (VAE + 3 UNet fwd + LoRA-UNet fwd/bwd), 512^2, 1 view/GPU",
+        emit({"metric": "NeTF VSD iters/sec (VAE + 3 UNet fwd + LoRA-UNet fwd/bwd), 512^2, 1 view/GPU",
                           "value": ws * args.steps / el, "unit": "view-iters/s", "n_gpus": ws, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None,
@@ -261,15 +261,38 @@ def vsd_main(args):
                           "health": health,
                           "roofline_dense": {"bound": "mfma", "achieved": tfl / (el / args.steps),
                                              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                             "frac": tfl / (el / args.steps) / PEAK_BF16_TFLOPS}}), flush=True)
+                                             "frac": tfl / (el / args.steps) / PEAK_BF16_TFLOPS}})
     if gdist.is_dist():
         torch.distributed.destroy_process_group()
 
 
+_RESULT_OUT = None
+
+
+def _claim_stdout():
+    """The driver reads ONE JSON line from stdout.  Native libraries write there too -- RCCL prints a five-line version
+    banner to the C stdout of every process that creates a communicator, flushed at exit, i.e. AFTER the result -- so
+    the process's fd 1 is pointed at stderr for everything except the result line, which goes to a private duplicate
+    of the original stdout."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _RESULT_OUT
+
+
+def emit(line: dict):
+    out = _claim_stdout()
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def main():
     args = parse()
+    _claim_stdout()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args)))
+        emit(cpu_baseline(args))
         return
     if args.vsd:
         return vsd_main(args)
@@ -519,7 +542,7 @@ def main():
             except Exception as e:  # the baseline is reporting only; never fail the bench line on it
                 line["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {type(e).__name__}: {e}"}
-        print(json.dumps(line), flush=True)
+        emit(line)
     if gdist.is_dist():
         torch.distributed.destroy_process_group()
 

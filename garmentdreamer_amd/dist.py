@@ -42,7 +42,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
-    if ws > 1 and not is_dist():
+    # GD_DIST_SINGLE=1: a process group of ONE rank (tests: the RCCL code path of every collective on a single-GPU box)
+    if (ws > 1 or os.environ.get("GD_DIST_SINGLE") == "1") and not is_dist():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

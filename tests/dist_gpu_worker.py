@@ -69,6 +69,7 @@ def main():
             rec["radii"].append(gm.max_radii2D.detach().cpu().clone())
         rec["densified"].append(bool(out["densified"]))
         rec["P_history"].append(gm.get_xyz.shape[0])
+    rec.update(backend=(torch.distributed.get_backend() if gdist.is_dist() else None), world_size=gdist.world_size())
     rec.update(P=gm.get_xyz.shape[0], flat=gm._flat.detach().cpu(), exp_avg=gm._exp_avg.detach().cpu(),
                exp_avg_sq=gm._exp_avg_sq.detach().cpu(), max_radii2D=gm.max_radii2D.detach().cpu(),
                xyz_gradient_accum=gm.xyz_gradient_accum.detach().cpu(), denom=gm.denom.detach().cpu())

@@ -206,6 +206,25 @@ def test_config3_two_ranks_share_one_gpu_real_rasterizer_matches_single_rank(tmp
     assert float(d.max()) < 0.11
 
 
+def test_config3_single_rank_rccl_group_runs_every_collective_on_the_gpu(tmp_path):
+    """The builder gets one GPU at a time, so RCCL cannot be exercised across devices here; what CAN be checked on
+    hardware is that every collective of the sharded loop -- the flat fp32 gradient bucket (sum), the int32 radii
+    (max), the scalar depth maximum and its backward -- executes on the "nccl" (= RCCL) backend with the tensors and
+    dtypes the loop passes, next to the hipGraph replays: a process group of ONE rank on cuda:0 must reproduce the
+    group-less run (to the run-to-run noise of two processes: the GroupNorm statistics use fp64 atomics)."""
+    plain = _run_workers(1, str(tmp_path))[0]
+    rccl = _run_workers(1, str(tmp_path), extra_env={"GD_DIST_BACKEND": "nccl", "GD_DIST_SINGLE": "1"})[0]
+    assert rccl.get("backend") == "nccl" and rccl.get("world_size") == 1 and plain.get("backend") is None
+    assert len(plain["grads"]) == len(rccl["grads"]) > 0
+    for s in range(len(plain["grads"])):
+        cos = _cos(plain["grads"][s], rccl["grads"][s])
+        parity_report.record("configs[3] one-rank RCCL group vs no group (one GPU)", f"step {s} grad bucket", cos=cos)
+        assert cos > 0.9999, (s, cos)
+        assert torch.equal(plain["radii"][s], rccl["radii"][s])
+    assert any(rccl["densified"]) and rccl["P_history"][0] != rccl["P_history"][-1]
+    assert abs(plain["P_history"][-1] - rccl["P_history"][-1]) <= 0.02 * plain["P_history"][-1]
+
+
 def _vsd_objects(kw_unet, kw_vae, dtype, graphs=False, fp32_adapters=True, **gd_kw):
     from garmentdreamer_amd.guidance import sd21
     from garmentdreamer_amd.guidance.sd_vsd import LoraUnet, StableDiffusionVSD
