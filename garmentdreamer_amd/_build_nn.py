@@ -8,6 +8,7 @@ NN_SOURCES = [
     ("nn_attention.hip", []),
     ("nn_prologue.hip", ["-munsafe-fp-atomics"]),
     ("nn_fp8.hip", []),
+    ("nn_linear.hip", []),
 ]
 
 

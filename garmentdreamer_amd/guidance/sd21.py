@@ -37,7 +37,8 @@ import torch.nn.functional as F
 from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, attention_d64_vt, conv1x1, conv3x3, conv3x3_s2, conv3x3_s2_supported, conv3x3_small_cin,
                       conv3x3_supported, geglu, gn_conv3x3, gn_conv3x3_supported, gn_conv_prefers_fused, group_norm_silu,
                       resnet_block_frozen, resnet_block_frozen_supported, upsample2x_conv3x3,
-                      upsample2x_conv3x3_supported)
+                      upsample2x_conv3x3_supported, linear_320,
+                      linear_320_supported)
 
 
 import os as _os
@@ -67,6 +68,23 @@ def _conv3(conv: nn.Conv2d, x, image_bias=None, residual=None):
     if image_bias is not None:
         y = y + image_bias[:, :, None, None]
     return y if residual is None else y + residual
+
+
+import os as _os0
+_LIN320 = _os0.environ.get("GD_LINEAR320", "1") != "0"      # =0: library GEMM (same-box A/B in tools/, never set in tests)
+
+
+def _lin(mod: nn.Linear, x, bias=None):
+    """``mod(x)`` (with ``bias`` in place of ``mod.bias`` if given).  Frozen products with K = 320 on long row sets -- to_q
+    of the cross-attention, to_out.0, proj_in, proj_out (N = 320) and the GEGLU projection (N = 2560) of the 64x64-token
+    transformer blocks -- run on the weights-in-registers streaming kernel (nn_ops.linear_320: they are HBM streams;
+    1.4x / 1.1x the library GEMM on MI355X, tools/linear320_bench.py)."""
+    w = mod.weight
+    b = mod.bias if bias is None else bias
+    if _LIN320 and x.is_cuda and not torch.is_grad_enabled() and not w.requires_grad and w.shape[1] == 320 and \
+            (b is None or b.dtype == w.dtype) and linear_320_supported(x, w):
+        return linear_320(x, w, b)
+    return F.linear(x, w, b)
 
 
 def _gn_conv3(norm: nn.GroupNorm, conv: nn.Conv2d, x, image_bias=None, residual=None):
@@ -199,7 +217,7 @@ class Attention(nn.Module):
             context = context.context
         ctx = x if context is None else context
         if kv is not None:
-            q, (k, v) = self.to_q(x), kv
+            q, (k, v) = _lin(self.to_q, x), kv
         elif _FUSED_QKV and context is None and self.lora is None and x.is_cuda and self.to_q.bias is None and \
                 not self.to_q.weight.requires_grad and not torch.is_grad_enabled():
             # frozen self-attention: ONE [C, 2C] projection for q | k (the attention kernel reads the two strided views)
@@ -210,12 +228,13 @@ class Attention(nn.Module):
             if getattr(self, "_wqkv_src", None) != src:
                 self._wqk = torch.cat([self.to_q.weight, self.to_k.weight], dim=0).detach().contiguous()
                 self._wqkv_src = src
-            q, k = F.linear(x, self._wqk).chunk(2, dim=-1)
+            q, k = (linear_320(x, self._wqk) if _LIN320 and linear_320_supported(x, self._wqk)
+                    else F.linear(x, self._wqk)).chunk(2, dim=-1)
             q = q.view(B, N, self.heads, -1)
             k = k.view(B, N, self.heads, -1)
             if _VT_GEMM and N % 64 == 0 and N >= 256 and q.shape[-1] == 64 and x.dtype == torch.bfloat16:
                 vt = torch.matmul(self.to_v.weight.detach(), x.transpose(1, 2))      # [B, C, N]
-                return self.to_out[0](attention_d64_vt(q, k, vt))
+                return _lin(self.to_out[0], attention_d64_vt(q, k, vt))
             v = self.to_v(x)
             q, k = q.reshape(B, N, -1), k.reshape(B, N, -1)
         else:
@@ -234,7 +253,7 @@ class Attention(nn.Module):
         else:
             o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
             o = o.transpose(1, 2).reshape(B, N, -1)
-        y = self.to_out[0](o)
+        y = _lin(self.to_out[0], o)
         if self.lora is not None:
             y = y + self.lora_scale * self.lora["to_out_lora"](o)
         return y
@@ -246,7 +265,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        return geglu(self.proj(x))   # h * gelu(gate), fused on the GPU (nn_ops.geglu)
+        return geglu(_lin(self.proj, x))   # h * gelu(gate), fused on the GPU (nn_ops.geglu)
 
 
 class FeedForward(nn.Module):
@@ -302,13 +321,13 @@ class Transformer2DModel(nn.Module):
         B, C, H, W = x.shape
         h = _gn(self.norm, x, False)
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)  # free for channels_last activations
-        h = self.proj_in(h)
+        h = _lin(self.proj_in, h)
         if len(self.transformer_blocks) == 1 and h.is_cuda and not torch.is_grad_enabled() and \
                 not self.proj_out.weight.requires_grad:
             # frozen inference: the block's feed-forward output bias b2 is a constant added right before proj_out,
             # so it moves into proj_out's bias (W_out b2 + b_out) and the residual add moves into the GEMM
             h = self.transformer_blocks[0](h, context, defer_ff_bias=True)
-            h = F.linear(h, self.proj_out.weight, self._folded_out_bias(h.dtype))
+            h = _lin(self.proj_out, h, self._folded_out_bias(h.dtype))
         else:
             for blk in self.transformer_blocks:
                 h = blk(h, context)

@@ -28,6 +28,10 @@ SIGNATURES = {
     "gd_nn_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "gd_nn_groupnorm_silu_forward_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _f]),
     "gd_nn_conv3x3_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gd_nn_linear_320_supported": (_i, [C.c_int64, _i, _i]),
+    "gd_nn_linear_320_forward": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64]),
+    "gd_nn_linear_k320_forward": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i]),
+    "gd_nn_linear_320_last_error": (C.c_char_p, []),
     "gd_nn_conv3x3_stat_rows": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_first_stat_rows": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_first_forward_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -1073,6 +1077,28 @@ def linear_supported(x, weight) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous()
             and weight.is_contiguous() and weight.shape[1] % 64 == 0 and weight.shape[0] % 4 == 0
             and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)))
+
+
+def linear_320_supported(x, weight) -> bool:
+    """bf16 GPU rows, K = 320, N = 320 / 640 / 2560, at least 4096 rows (the 64x64-token transformer blocks at any
+    batch)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous()
+            and weight.is_contiguous() and weight.dim() == 2 and x.shape[-1] == weight.shape[1]
+            and bool(lib().gd_nn_linear_320_supported(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0])))
+
+
+def linear_320(x, weight, bias=None):
+    """``F.linear(x, weight, bias)`` for K = 320 (N = 320, 640, 2560) on the weights-in-registers streaming kernel,
+    inference only."""
+    M, N = x.numel() // 320, weight.shape[0]
+    y = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
+    L = lib()
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_linear_k320_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), weight.data_ptr(),
+                                          None if bias is None else bias.data_ptr(), y.data_ptr(), M, N)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_linear_k320_forward failed ({ret}): {L.gd_nn_linear_320_last_error().decode()}")
+    return y
 
 
 def linear(x, weight, bias=None, residual=None):

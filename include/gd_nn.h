@@ -124,6 +124,16 @@ int gd_nn_conv3x3_first_forward_stats(void* stream, const void* x, const void* w
 int gd_nn_groupnorm_finish_partials(void* stream, const float* stat_part, int N, size_t rows, int C, int G, int HW,
                                     float eps, float* mean_rstd);
 
+/* nn.Linear with K = 320 and N = 320, 640 or 2560 on long row sets (to_q / to_out / proj_in / proj_out, the fused q|k
+ * projection and the GEGLU projection of the UNet's 64x64-token transformer blocks: y[M][N] = x[M][320] .
+ * weight[N][320]^T + bias): an HBM stream, run with the weights held in registers by persistent ten-wave workgroups,
+ * one block of 320 output channels each (csrc/nn_linear.hip).  gd_nn_linear_320_supported: 1 when (M, K, N) is such a
+ * product. */
+int gd_nn_linear_320_supported(int64_t M, int K, int N);
+int gd_nn_linear_k320_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M, int N);
+int gd_nn_linear_320_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M);
+const char* gd_nn_linear_320_last_error(void);
+
 /* First convolution (image / latent -> features): 3x3 / s1 / p1 with Cin <= 4, + bias.  x: bf16 [N,H,W,Cin];
  * weight: bf16 [Cout][3][3][Cin]; y: bf16 [N,H,W,Cout]; Cout % 8 == 0, 36*Cin*Cout bytes of LDS <= 64 KiB.
  * Cout == 128 (diffusers `conv_in` of the VAE encoder): matrix-core kernel, im2col operand gathered from the image,

@@ -914,6 +914,34 @@ def test_attention_d64_with_a_key_count_that_is_not_a_multiple_of_64(B, H, S, Sk
     assert F.cosine_similarity(out.float().flatten(), ref.flatten(), dim=0).item() > 0.9995
 
 
+@pytest.mark.parametrize("M,N,with_bias", [(65536, 320, True), (4096, 320, True), (8192, 320, False), (65536 + 37, 320, True),
+                                           (4096 + 1, 320, True), (32 * 256 * 5 + 31, 320, False), (65536, 640, False),
+                                           (8192 + 5, 640, True), (65536, 2560, True), (4096 + 33, 2560, True)])
+def test_linear_320_streaming_kernel_matches_fp32_reference(M, N, with_bias):
+    """gd_nn_linear_320_forward (weights in registers, x streamed through four LDS stages by LDS-DMA, waits counted per
+    instruction) against fp32 torch on the same bf16 operands: every element within one bf16 rounding of the fp32
+    result (products of bf16 values are exact in fp32, sums of 320 of them in another order differ by ~1e-6 relative),
+    ragged row counts, several tiles per workgroup and the 2- and 8-column-block forms (N = 640, 2560) included; two
+    launches are bit-identical."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(M + N)
+    x = torch.randn(M, 320, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, 320, device=DEV, generator=g) / 18).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV, generator=g).to(torch.bfloat16) if with_bias else None
+    assert nn_ops.linear_320_supported(x, w)
+    y = nn_ops.linear_320(x, w, b)
+    ref = F.linear(x.float(), w.float(), None if b is None else b.float())
+    err = (y.float() - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-6).all()), float((err / (ref.abs() + 1e-3)).max())
+    assert torch.equal(y, nn_ops.linear_320(x, w, b))
+    # 3-D input as the transformer blocks pass it
+    if M % 4096 == 0:
+        y3 = nn_ops.linear_320(x.view(M // 4096, 4096, 320), w, b)
+        assert y3.shape == (M // 4096, 4096, N) and torch.equal(y3.reshape(M, N), y)
+    assert not nn_ops.linear_320_supported(x[:, :160], w[:, :160])       # other K: not this kernel's
+    assert not nn_ops.linear_320_supported(x[:1024], w)                  # short row sets stay on the library
+
+
 @pytest.mark.parametrize("M,K,N,res", [(4096, 320, 320, True), (1000, 640, 1920, False), (77, 1024, 640, False),
                                        (65536, 320, 2560, False), (513, 1280, 1284, True)])
 def test_linear_one_tap_gemm_matches_fp32_reference(M, K, N, res):
