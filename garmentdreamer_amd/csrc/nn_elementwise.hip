@@ -17,6 +17,7 @@
 #include <stdio.h>
 
 #include "../../include/gd_nn.h"
+#include "nn_math.h"
 
 namespace {
 
@@ -35,35 +36,18 @@ __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uin
 // Packed fp32 helpers: these row passes are VALU-bound on MI355X (a wave64 VALU instruction holds its SIMD ~4.5 cycles,
 // tools/probes/valu_rate_probe.hip; SQ_INSTS_VALU x 4.5 cycles = the whole kernel time in profiles/r02_pmc.json), so two
 // channels share every arithmetic instruction (v_pk_*_f32) and bf16 rounding is v_cvt_pk_bf16_f32 (nearest even).
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+using gdnn::f2;
+using gdnn::unpack2;
+using gdnn::pack2;
+using gdnn::round_bf16;
+using gdnn::erf_as2;
 struct alignas(16) u32x4 { uint32_t w[4]; };
-__device__ __forceinline__ f2 unpack2(uint32_t w) { return f2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
-__device__ __forceinline__ uint32_t pack2(f2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t)); }
-__device__ __forceinline__ f2 round_bf16(f2 v) { return unpack2(pack2(v)); }
 
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
-}
-
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, three orders below a bf16 ulp of the GELU): one rcp, one
-// exp and a degree-5 Horner instead of libm erff's ~40 instructions -- the kernel is VALU-bound on this function.
-// Two values per call: the polynomial runs on v_pk_fma_f32.
-__device__ __forceinline__ f2 erf_as2(f2 x)
-{
-    const f2 ax = {fabsf(x.x), fabsf(x.y)};
-    const f2 d = 0.3275911f * ax + 1.0f;
-    const f2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    f2 p = 1.061405429f * t + -1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t + -0.284496736f;
-    p = p * t + 0.254829592f;
-    const f2 a = (ax * ax) * -1.44269504088896341f;
-    const f2 e = 1.0f - (p * t) * f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-    return f2{copysignf(e.x, x.x), copysignf(e.y, x.y)};
 }
 
 // x: [rows][2*inner] (hidden | gate), y: [rows][inner]; one thread per 8 output channels
@@ -77,12 +61,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(const bf16x8* __restrict__ x
         const u32x4 g = __builtin_bit_cast(u32x4, x[row * 2 * vin + vin + c]);
         u32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const f2 gv = unpack2(g.w[k]);
-            // F.gelu on a bf16 tensor rounds its result to bf16 before the multiply; keep that rounding
-            const f2 ge = round_bf16((0.5f * gv) * (1.0f + erf_as2(gv * 0.70710678118654752f)));
-            o.w[k] = pack2(unpack2(h.w[k]) * ge);
-        }
+        for (int k = 0; k < 4; k++) o.w[k] = gdnn::geglu2(h.w[k], g.w[k]);   // (nn_math.h; also the fused GEMM epilogue's)
         y[i] = __builtin_bit_cast(bf16x8, o);
     }
 }

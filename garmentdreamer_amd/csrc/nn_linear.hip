@@ -19,6 +19,7 @@
 #include <stdio.h>
 
 #include "../../include/gd_nn.h"
+#include "nn_math.h"
 
 namespace {
 
@@ -50,6 +51,12 @@ __device__ __forceinline__ void bload_lds16(__amdgpu_buffer_rsrc_t rsrc, uint32_
                                              0, 0);
 }
 
+// GEGLU = true: weight is diffusers' GEGLU projection [2 * 160 nb][320] (hidden rows, then gate rows) and y[M][160 nb] =
+// hidden * gelu(gate): a workgroup owns 160 output channels -- waves 0..4 their hidden rows, waves 5..9 their gate rows --
+// and the GEGLU arithmetic (nn_math.h, the separate geglu_kernel's) runs in the store phase on the bf16-rounded tile,
+// i.e. at the rounding points of the unfused path: the [M][2 * 160 nb] intermediate (335 MB at 65536 rows) is neither
+// written nor read.
+template <bool GEGLU>
 __global__ __launch_bounds__(kThreads) void linear_320_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                               const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
                                                               int M, int ntiles, int nb)
@@ -66,25 +73,29 @@ __global__ __launch_bounds__(kThreads) void linear_320_kernel(const uint16_t* __
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
     const int cb = rr % nb, tslot = rr / nb;
     const int tiles_per_pass = (int)(gridDim.x / nb);
-    const int ldy = kN * nb;
-    // this wave's 32 output channels x 320 inputs as MFMA A fragments: row 320 cb + 32 wave + fn, k = 16 s + 8 fk .. + 7
+    constexpr int kOutCh = GEGLU ? kN / 2 : kN;            // output channels of a workgroup
+    const int ldy = kOutCh * nb;
+    // first of this wave's 32 weight rows
+    const int wrow = GEGLU ? (wave < kWaves / 2 ? kOutCh * cb + 32 * wave : kOutCh * nb + kOutCh * cb + 32 * (wave - kWaves / 2))
+                           : kN * cb + 32 * wave;
+    // this wave's 32 output channels x 320 inputs as MFMA A fragments: row wrow + fn, k = 16 s + 8 fk .. + 7
     bf16x8_t wf[kK / 16];
 #pragma unroll
-    for (int s = 0; s < kK / 16; s++)
-        wf[s] = *(const bf16x8_t*)(w + (size_t)(kN * cb + 32 * wave + fn) * kK + 16 * s + 8 * fk);
+    for (int s = 0; s < kK / 16; s++) wf[s] = *(const bf16x8_t*)(w + (size_t)(wrow + fn) * kK + 16 * s + 8 * fk);
     // the lane's 16 bias values as 8 packed bf16 pairs (an LDS copy would make the compiler order its reads behind the
     // LDS-DMA in flight -- s_waitcnt vmcnt(0) in the middle of the pipeline)
     uint2 bq2[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) bq2[q] = bias ? *(const uint2*)(bias + kN * cb + 32 * wave + 8 * q + 4 * fk) : make_uint2(0u, 0u);
+    for (int q = 0; q < 4; q++) bq2[q] = bias ? *(const uint2*)(bias + wrow + 8 * q + 4 * fk) : make_uint2(0u, 0u);
 
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((uint32_t)M * (uint32_t)(kK * 2)), 0x00020000);
     // DMA pieces of one stage: 32 rows x 48 slots = 24 pieces of 64 lanes: waves 0..7 issue kDma = 3 each per tile
     // (pieces w, w + 8, w + 16), waves 8 and 9 none -- the s_waitcnt immediates below count instructions per wave.
     constexpr int kPieces = kBM * kSlots / 64, kDmaWaves = 8, kDma = kPieces / kDmaWaves;
-    constexpr int kStores = kBM * kChunks / kThreads;      // 16-byte stores per thread and (full) tile
-    static_assert(kDma == 3 && kDma * kDmaWaves == kPieces && kStores == 2, "the vmcnt immediates below are written for these counts");
+    constexpr int kOutChunks = kOutCh / 8;                 // 16-byte chunks per output row
+    constexpr int kStores = kBM * kOutChunks / kThreads;   // 16-byte stores per thread and (full) tile: 2, GEGLU 1
+    static_assert(kDma * kDmaWaves == kPieces && kStores * kThreads == kBM * kOutChunks, "instruction counts per wave");
     const bool dma_wave = wave < kDmaWaves;
     uint32_t a_off[kDma];     // byte offset inside the tile's rows of x, or kOOB (padding slot)
 #pragma unroll
@@ -113,10 +124,10 @@ __global__ __launch_bounds__(kThreads) void linear_320_kernel(const uint16_t* __
     size_t st_y[kStores];
 #pragma unroll
     for (int i = 0; i < kStores; i++) {
-        const int j = tid + kThreads * i, row = j / kChunks, c = j - row * kChunks;
+        const int j = tid + kThreads * i, row = j / kOutChunks, c = j - row * kOutChunks;
         st_lds[i] = (uint32_t)(uintptr_t)(sOut + row * kOutPitch + c * 16);
         st_row[i] = (uint32_t)row;
-        st_y[i] = (size_t)row * ldy + kN * cb + c * 8;
+        st_y[i] = (size_t)row * ldy + kOutCh * cb + c * 8;
     }
     // result tile `t` (already complete in LDS half `half`, all waves past a barrier) -> whole 640-byte rows of y.
     // (LDS accesses of the result tile are inline asm: the compiler orders every LDS access it cannot tell apart from
@@ -126,14 +137,22 @@ __global__ __launch_bounds__(kThreads) void linear_320_kernel(const uint16_t* __
     auto store_tile = [&](int t, int half) {
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const int m0 = t * kBM;
-        u32x4 v[kStores];
+        u32x4 v[kStores], g[kStores];
 #pragma unroll
-        for (int i = 0; i < kStores; i++)
+        for (int i = 0; i < kStores; i++) {
             asm volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(st_lds[i] + (uint32_t)(half * kOutTile)) : "memory");
+            if (GEGLU)            // the gate chunk: same row, 320 bytes on (waves 5..9 wrote it)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(g[i]) : "v"(st_lds[i] + (uint32_t)(half * kOutTile + kN)) : "memory");
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < kStores; i++)
+        for (int i = 0; i < kStores; i++) {
+            if (GEGLU) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[i][k] = gdnn::geglu2(v[i][k], g[i][k]);
+            }
             if (m0 + (int)st_row[i] < M) *(u32x4*)(y + (size_t)m0 * ldy + st_y[i]) = v[i];
+        }
     };
 
     // One bare s_barrier (+ LDS wait) per pass: __syncthreads() carries a release fence that the compiler lowers to
@@ -153,12 +172,12 @@ __global__ __launch_bounds__(kThreads) void linear_320_kernel(const uint16_t* __
         // vmcnt retires in issue order on gfx9 (one counter for loads and stores): "at most n younger instructions
         // outstanding" means this pass's DMA has landed.  Issue order per DMA wave: D0 D1 D2 | D3 | D4 S0 | D5 S1 | ...
         // (D = kDma DMA instructions of a tile, S = kStores stores of the tile one pass back), so behind D(it) there are
-        // 6, 6, 8, 10, then 12 of them.
+        // 2 D, 2 D, 2 D + S, 2 D + 2 S, then 2 D + 3 S of them.
         if (dma_wave) {           // (waves 8, 9 issue no DMA: the barrier below is all they need)
-            if (it <= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (it == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (it == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (it <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDma) : "memory");
+            else if (it == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDma + kStores) : "memory");
+            else if (it == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDma + 2 * kStores) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDma + 3 * kStores) : "memory");
         }
         // stage `buf` has landed for everyone; everyone has written the previous result tile and is done READING the
         // one before it (whose LDS half this pass overwrites)
@@ -200,6 +219,29 @@ int fail(int code, const char* msg)
     return code;
 }
 
+template <bool GEGLU>
+int launch_k320(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M, int nb)
+{
+    static_assert((kStages & (kStages - 1)) == 0, "stage index by mask");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
+    static bool attr_set[16] = {false};
+    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)linear_320_kernel<GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        attr_set[dev] = true;
+    }
+    const int ntiles = (int)((M + kBM - 1) / kBM);
+    // 256 workgroups (one per CU of an MI355X; a multiple of 8 nb so that blockIdx -> (XCD, column block, tile slot) is
+    // exact), fewer for short row sets
+    int grid = 256;
+    while (grid > 8 * nb && (grid / nb) / 2 >= ntiles) grid /= 2;
+    hipLaunchKernelGGL(linear_320_kernel<GEGLU>, dim3(grid), dim3(kThreads), kLds, (hipStream_t)stream, (const uint16_t*)x,
+                       (const uint16_t*)weight, (const uint16_t*)bias, (uint16_t*)y, (int)M, ntiles, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,30 +254,21 @@ int gd_nn_linear_320_supported(int64_t M, int K, int N)
             M * N * 2 < 4294967296LL) ? 1 : 0;
 }
 
+int gd_nn_linear_k320_geglu_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M,
+                                    int inner)
+{
+    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (M <= 0 || M * kK * 2 >= 2147483648LL) return fail(GD_NN_ERR_INVALID_ARG, "linear_k320_geglu: need 0 < M and x < 2 GiB");
+    if (inner != 4 * kN) return fail(GD_NN_ERR_INVALID_ARG, "linear_k320_geglu: inner must be 1280 (weight [2560][320])");
+    return launch_k320<true>(stream, x, weight, bias, y, M, inner / (kN / 2));
+}
+
 int gd_nn_linear_k320_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M, int N)
 {
     if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (M <= 0 || M * kK * 2 >= 2147483648LL) return fail(GD_NN_ERR_INVALID_ARG, "linear_k320: need 0 < M and x < 2 GiB");
     if (N != kN && N != 2 * kN && N != 8 * kN) return fail(GD_NN_ERR_INVALID_ARG, "linear_k320: N must be 320, 640 or 2560");
-    static_assert((kStages & (kStages - 1)) == 0, "stage index by mask");
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
-    static bool attr_set[16] = {false};
-    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)linear_320_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        attr_set[dev] = true;
-    }
-    const int nb = N / kN;
-    const int ntiles = (int)((M + kBM - 1) / kBM);
-    // 256 workgroups (one per CU of an MI355X; a multiple of 8 nb so that blockIdx -> (XCD, column block, tile slot) is
-    // exact), fewer for short row sets
-    int grid = 256;
-    while (grid > 8 * nb && (grid / nb) / 2 >= ntiles) grid /= 2;
-    hipLaunchKernelGGL(linear_320_kernel, dim3(grid), dim3(kThreads), kLds, (hipStream_t)stream, (const uint16_t*)x,
-                       (const uint16_t*)weight, (const uint16_t*)bias, (uint16_t*)y, (int)M, ntiles, nb);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
-    return GD_NN_OK;
+    return launch_k320<false>(stream, x, weight, bias, y, M, N / kN);
 }
 
 int gd_nn_linear_320_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M)

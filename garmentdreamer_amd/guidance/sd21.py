@@ -38,7 +38,7 @@ from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, at
                       conv3x3_supported, geglu, gn_conv3x3, gn_conv3x3_supported, gn_conv_prefers_fused, group_norm_silu,
                       resnet_block_frozen, resnet_block_frozen_supported, upsample2x_conv3x3,
                       upsample2x_conv3x3_supported, linear_320,
-                      linear_320_supported)
+                      linear_320_geglu, linear_320_supported)
 
 
 import os as _os
@@ -265,6 +265,10 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
+        w = self.proj.weight
+        if _LIN320 and x.is_cuda and not torch.is_grad_enabled() and not w.requires_grad and tuple(w.shape) == (2560, 320) and \
+                linear_320_supported(x, w):
+            return linear_320_geglu(x, w, self.proj.bias)      # projection + GEGLU in one kernel (64x64-token blocks)
         return geglu(_lin(self.proj, x))   # h * gelu(gate), fused on the GPU (nn_ops.geglu)
 
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "gd_nn_linear_320_supported": (_i, [C.c_int64, _i, _i]),
     "gd_nn_linear_320_forward": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64]),
     "gd_nn_linear_k320_forward": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i]),
+    "gd_nn_linear_k320_geglu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i]),
     "gd_nn_linear_320_last_error": (C.c_char_p, []),
     "gd_nn_conv3x3_stat_rows": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_first_stat_rows": (C.c_size_t, [_i, _i, _i, _i, _i]),
@@ -1098,6 +1099,21 @@ def linear_320(x, weight, bias=None):
                                           None if bias is None else bias.data_ptr(), y.data_ptr(), M, N)
     if ret < 0:
         raise RuntimeError(f"gd_nn_linear_k320_forward failed ({ret}): {L.gd_nn_linear_320_last_error().decode()}")
+    return y
+
+
+def linear_320_geglu(x, weight, bias=None):
+    """diffusers ``GEGLU(320, 1280)``: ``h, g = F.linear(x, weight, bias).chunk(2, -1); h * gelu(g)`` as ONE kernel (the
+    GEGLU arithmetic in the streaming GEMM's store phase); bit-identical to ``geglu(linear_320(x, weight, bias))``."""
+    M, inner = x.numel() // 320, weight.shape[0] // 2
+    y = torch.empty(x.shape[:-1] + (inner,), dtype=torch.bfloat16, device=x.device)
+    L = lib()
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_linear_k320_geglu_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
+                                                weight.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                                M, inner)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_linear_k320_geglu_forward failed ({ret}): {L.gd_nn_linear_320_last_error().decode()}")
     return y
 
 

@@ -132,6 +132,11 @@ int gd_nn_groupnorm_finish_partials(void* stream, const float* stat_part, int N,
 int gd_nn_linear_320_supported(int64_t M, int K, int N);
 int gd_nn_linear_k320_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M, int N);
 int gd_nn_linear_320_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M);
+/* ... with diffusers' GEGLU as the epilogue: weight [2 * inner][320] (hidden rows, then gate rows), bias [2 * inner],
+ * y[M][inner] = (x W_h^T + b_h) * gelu(x W_g^T + b_g) with the rounding points of gd_nn_linear_k320_forward followed by
+ * gd_nn_geglu_forward (bit-identical to that pair); inner = 1280.  The [M][2 * inner] intermediate never exists. */
+int gd_nn_linear_k320_geglu_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M,
+                                    int inner);
 const char* gd_nn_linear_320_last_error(void);
 
 /* First convolution (image / latent -> features): 3x3 / s1 / p1 with Cin <= 4, + bias.  x: bf16 [N,H,W,Cin];

@@ -942,6 +942,23 @@ def test_linear_320_streaming_kernel_matches_fp32_reference(M, N, with_bias):
     assert not nn_ops.linear_320_supported(x[:1024], w)                  # short row sets stay on the library
 
 
+@pytest.mark.parametrize("M", [65536, 4096 + 33, 8192])
+def test_linear_320_with_geglu_epilogue_is_bit_identical_to_the_two_kernels(M):
+    """gd_nn_linear_k320_geglu_forward (GEGLU arithmetic in the streaming GEMM's store phase, on the bf16-rounded tile)
+    against gd_nn_linear_k320_forward + gd_nn_geglu_forward: bit-identical; and against fp32 torch GEGLU."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(M)
+    x = torch.randn(M, 320, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(2560, 320, device=DEV, generator=g) / 18).to(torch.bfloat16)
+    b = torch.randn(2560, device=DEV, generator=g).to(torch.bfloat16)
+    y = nn_ops.linear_320_geglu(x, w, b)
+    two = nn_ops.geglu(nn_ops.linear_320(x, w, b))
+    assert y.shape == (M, 1280) and torch.equal(y, two)
+    h, gate = F.linear(x.float(), w.float(), b.float()).chunk(2, dim=-1)
+    ref = h * F.gelu(gate)
+    assert (y.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M,K,N,res", [(4096, 320, 320, True), (1000, 640, 1920, False), (77, 1024, 640, False),
                                        (65536, 320, 2560, False), (513, 1280, 1284, True)])
 def test_linear_one_tap_gemm_matches_fp32_reference(M, K, N, res):

@@ -36,3 +36,13 @@ for M, N in ((65536, 320), (32768, 320), (8192, 320), (65536 + 37, 320), (65536,
     gb = M * (320 + N) * 2 / 1e3
     print(f"M {M:6d} N {N:4d}: hipBLASLt {t0:6.1f} us ({gb / t0 / 1e3:4.2f} TB/s)   own {t1:6.1f} us ({gb / t1 / 1e3:4.2f} TB/s)   "
           f"rel err own {e_own:.1e} lib {e_lib:.1e}")
+
+M = 65536
+x = torch.randn(M, 320, device=DEV, generator=g).to(torch.bfloat16)
+w = (torch.randn(2560, 320, device=DEV, generator=g) / 18).to(torch.bfloat16)
+b = torch.randn(2560, device=DEV, generator=g).to(torch.bfloat16)
+with torch.no_grad():
+    t_lib = timeit(lambda: nn_ops.geglu(F.linear(x, w, b)))
+    t_two = timeit(lambda: nn_ops.geglu(nn_ops.linear_320(x, w, b)))
+    t_one = timeit(lambda: nn_ops.linear_320_geglu(x, w, b))
+print(f"GEGLU(320, 1280) on {M} rows: hipBLASLt + geglu {t_lib:6.1f} us   own GEMM + geglu {t_two:6.1f} us   fused {t_one:6.1f} us")
