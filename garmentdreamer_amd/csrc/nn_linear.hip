@@ -1,17 +1,21 @@
-// nn.Linear of the UNet's 64x64-token transformer blocks (320 -> 320: to_q of the cross-attention, to_out.0, proj_in,
-// proj_out of diffusers' Transformer2DModel / Attention; GarmentDreamer calls them through
-// threestudio's StableDiffusionGuidance.forward_unet, stable_diffusion_guidance.py:106-118) for MI355X.
+// nn.Linear with K = 320 of the UNet's 64x64-token transformer blocks -- to_q of the cross-attention, to_out.0, proj_in,
+// proj_out (N = 320), the fused q | k projection of the self-attention (N = 640) and the GEGLU projection (N = 2560,
+// optionally with the GEGLU itself as the epilogue) of diffusers' Transformer2DModel / Attention / FeedForward;
+// GarmentDreamer reaches them through threestudio's StableDiffusionGuidance.forward_unet
+// (stable_diffusion_guidance.py:106-118) -- for MI355X.
 //
-// y[M][320] = x[M][320] . W[320][320]^T + bias, bf16 in / out, fp32 accumulation.  With M = 16 * 4096 rows the product
-// moves 42 MB in and 42 MB out for 13 GFLOP: it is an HBM stream (0.16 flop per byte of the MFMA roof), and a tiled
-// library GEMM spends its time in the five-step K pipelines of 512 short-lived workgroups (hipBLASLt: 39 us =
-// 2.2 TB/s).  Here the WEIGHTS LIVE IN REGISTERS: a workgroup is ten waves, wave w keeps output channels
+// y[M][N] = x[M][320] . W[N][320]^T + bias, bf16 in / out, fp32 accumulation.  With M = 16 * 4096 rows the 320 -> 320
+// product moves 42 MB in and 42 MB out for 13 GFLOP: it is an HBM stream, and a tiled library GEMM spends its time in
+// the five-step K pipelines of 512 short-lived workgroups (hipBLASLt: 38 us = 2.2 TB/s).  Here the WEIGHTS LIVE IN
+// REGISTERS: a workgroup is ten waves and owns one block of 320 output channels; wave w keeps channels
 // [32 w, 32 w + 32) x all 320 inputs as its twenty MFMA A-operand fragments (80 VGPRs) for the life of the kernel, and
-// the (persistent) workgroup streams 64-row tiles of x through two LDS stages by LDS-DMA: the next tile is in flight
-// while the ten waves run 40 MFMAs each on the current one.  The result goes through an LDS tile so that it leaves as
-// whole 640-byte rows.
+// the (persistent) workgroup streams 32-row tiles of x through FOUR LDS stages by LDS-DMA -- three tiles in flight
+// behind the one being multiplied, each wait an `s_waitcnt vmcnt(n)` with n counted per instruction (gfx9 retires
+// loads and stores through one in-order counter), never vmcnt(0).  The result goes through an LDS tile so that it
+// leaves as whole rows, and those stores are issued at the top of the NEXT pass, under its MFMAs: one bare s_barrier
+// per pass.  N = 640 / 2560: 2 / 8 column blocks, the workgroups that share a row tile on one XCD.
 //
-// LDS: x stage [64 rows][768 B] (640 used): the 16-byte chunk c of row r sits at slot (c & ~15) | ((c & 15) ^ (r & 15)),
+// LDS: x stage [32 rows][768 B] (640 used): the 16-byte chunk c of row r sits at slot (c & ~15) | ((c & 15) ^ (r & 15)),
 // applied on the SOURCE side of the DMA (the LDS side of a DMA piece is lane-linear); the row pitch is a multiple of
 // 256 B, so the 16 lanes of a ds_read_b128 service group (16 rows with distinct r & 15) read 16 distinct bank quads.
 #include <hip/hip_runtime.h>
