@@ -919,8 +919,9 @@ def test_attention_d64_with_a_key_count_that_is_not_a_multiple_of_64(B, H, S, Sk
                                            (8192 + 5, 640, True), (65536, 2560, True), (4096 + 33, 2560, True)])
 def test_linear_320_streaming_kernel_matches_fp32_reference(M, N, with_bias):
     """gd_nn_linear_320_forward (weights in registers, x streamed through four LDS stages by LDS-DMA, waits counted per
-    instruction) against fp32 torch on the same bf16 operands: every element within one bf16 rounding of the fp32
-    result (products of bf16 values are exact in fp32, sums of 320 of them in another order differ by ~1e-6 relative),
+    instruction) against fp32 torch on the same bf16 operands: every element within one bf16 ulp of the fp32
+    result (products of bf16 values are exact in fp32; sums of 320 of them in another order differ by ~1e-6 relative,
+    which moves an occasional element across a rounding boundary: half an ulp is NOT a valid bound),
     ragged row counts, several tiles per workgroup and the 2- and 8-column-block forms (N = 640, 2560) included; two
     launches are bit-identical."""
     from garmentdreamer_amd import nn_ops
@@ -932,7 +933,7 @@ def test_linear_320_streaming_kernel_matches_fp32_reference(M, N, with_bias):
     y = nn_ops.linear_320(x, w, b)
     ref = F.linear(x.float(), w.float(), None if b is None else b.float())
     err = (y.float() - ref).abs()
-    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-6).all()), float((err / (ref.abs() + 1e-3)).max())
+    assert bool((err <= 2.0 ** -7 * ref.abs() + 1e-5).all()), float((err / (ref.abs() + 1e-3)).max())
     assert torch.equal(y, nn_ops.linear_320(x, w, b))
     # 3-D input as the transformer blocks pass it
     if M % 4096 == 0:
