@@ -11,6 +11,11 @@ One "step" = one full SDS iteration on synthetic data (BASELINE.json metric): ra
 configs[3]: 100k Gaussians x 8 views @ 512^2, the 8 views sharded V/N per GPU ("strong" scaling:
 total work is fixed).  Random-init SD-2.1 weights (no network for checkpoints), bf16.
 
+``--gpus N`` with N > 1 and no torchrun environment makes this process the launcher: it re-executes itself under
+``torch.distributed.run`` with N ranks, one per GPU (backend nccl = RCCL).  In every mode the run is REFUSED (non-zero
+exit, nothing on stdout) when WORLD_SIZE != --gpus or fewer than --gpus devices are visible; ``n_gpus`` in the line is
+the process group's size and ``rccl_ranks`` an all-reduced counter (tests/test_bench_launch.py, gloo, stubbed step).
+
 Rank 0 prints ONE JSON line.  Extra objects on that line:
   roofline      the DOMINANT kernel of the step = the hand-written bf16 MFMA conv3x3 kernel (largest share
                 of GPU time): algorithmic FLOPs (2*N*H*W*Cout*9*Cin per launch) / its summed launch
@@ -87,6 +92,10 @@ def parse():
                     help="e4m3 3x3 convolutions in the no-grad UNet forward (second, non-headline line: dtype says so)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="six nn.Parameters + torch.optim.Adam(fused) instead of the flat-buffer GaussianModel")
+    ap.add_argument("--stub-step", action="store_true",
+                    help="TEST ONLY (tests/test_bench_launch.py): replace the SDS iteration by one small all-reduce so the "
+                         "launch / rank-accounting logic of --gpus N can be exercised on CPU over gloo; the line it prints "
+                         "is labelled metric='stub' and is not a measurement")
     ap.add_argument("--vsd", action="store_true",
                     help="BASELINE configs[4] diagnostic: NeTF VSD iteration (VAE + 2 frozen UNet + LoRA UNet fwd, "
                          "LoRA UNet fwd+bwd) on a synthetic 512^2 render, one view per GPU")
@@ -190,6 +199,7 @@ def vsd_main(args):
     from garmentdreamer_amd.guidance import sd21
     from garmentdreamer_amd.guidance.sd_vsd import LoraUnet, StableDiffusionVSD
     rk, lr, ws = gdist.init_from_env()
+    check_world(args, ws, need_gpus=True)
     device = torch.device("cuda", lr)
     torch.cuda.set_device(device)
     gd = StableDiffusionVSD(device, fp16=True, use_hip_graphs=not args.no_graphs, fp8_unet=bool(args.fp8))
@@ -288,9 +298,88 @@ def emit(line: dict):
     out.flush()
 
 
+def launch_ranks_if_needed(args):
+    """``python bench.py --gpus N`` with N > 1 and no torchrun environment: become the launcher.  The process re-executes
+    itself under ``torch.distributed.run`` with one rank per GPU (the form the driver uses for N > 1), so that the same
+    command line that measures N = 1 measures N GPUs -- never N-fold one GPU.  Under an external torchrun (WORLD_SIZE
+    set) this is a no-op; in every mode ``check_world`` then refuses a world that is not ``--gpus``."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def check_world(args, ws: int, need_gpus: bool):
+    """The number of ranks IS --gpus, and every rank has its own GPU; anything else is refused (exit code 2) instead of
+    measured under a wrong label."""
+    if ws != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has WORLD_SIZE={ws}; launch one rank per GPU "
+                         f"(python bench.py --gpus {args.gpus} launches them itself)")
+    if need_gpus:
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < args.gpus and os.environ.get("GD_DIST_BACKEND") != "gloo":
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible")
+
+
+def rank_accounting(device, local_rank: int) -> dict:
+    """What the process group actually is, from the group itself: ``n_gpus`` = its size, ``rccl_ranks`` = an all-reduced
+    counter (each rank adds 1 through the backend the step uses), ``distinct_devices`` = how many different local
+    device ordinals the ranks run on."""
+    from garmentdreamer_amd import dist as gdist
+    if not gdist.is_dist():
+        return {"n_gpus": 1, "rccl_ranks": 1, "distinct_devices": 1, "backend": None}
+    import torch.distributed as td
+    one = torch.ones(1, device=device, dtype=torch.int32)
+    td.all_reduce(one, op=td.ReduceOp.SUM)
+    mine = torch.tensor([local_rank if device.type == "cuda" else -1 - td.get_rank()], device=device, dtype=torch.int32)
+    every = [torch.zeros_like(mine) for _ in range(td.get_world_size())]
+    td.all_gather(every, mine)
+    return {"n_gpus": td.get_world_size(), "rccl_ranks": int(one.item()),
+            "distinct_devices": len({int(t.item()) for t in every}), "backend": td.get_backend()}
+
+
+def stub_main(args):
+    """--stub-step: the launch + accounting skeleton of main() around a step that is one 1 KiB all-reduce.  CPU / gloo."""
+    from garmentdreamer_amd import dist as gdist
+    rk, lr, ws = gdist.init_from_env("gloo" if not torch.cuda.is_available() else None)
+    check_world(args, ws, need_gpus=False)
+    device = torch.device("cpu")
+    buf = torch.ones(256)
+    for _ in range(args.warmup):
+        gdist.all_reduce_mean_(buf)
+    gdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gdist.all_reduce_mean_(buf)
+    gdist.barrier()
+    el = time.perf_counter() - t0
+    acct = rank_accounting(device, lr)
+    if rk == 0:
+        emit({"metric": "stub", "value": args.steps / el, "unit": "iters/s", "n_gpus": acct["n_gpus"],
+              "rccl_ranks": acct["rccl_ranks"], "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+              "dtype": "none", "data": "none", "config": {"workload": "stub step (one 1 KiB all-reduce); NOT a measurement",
+                                                          "backend": acct["backend"]}})
+    if gdist.is_dist():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
+    launch_ranks_if_needed(args)
     _claim_stdout()
+    if args.stub_step:
+        return stub_main(args)
     if args.cpu_baseline_only:
         emit(cpu_baseline(args))
         return
@@ -304,6 +393,7 @@ def main():
     rk, lr, ws = gdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP rasterizer has no CPU path")
+    check_world(args, ws, need_gpus=True)
     device = torch.device("cuda", lr % torch.cuda.device_count())   # (ranks may share a GPU only under GD_DIST_BACKEND=gloo)
     torch.cuda.set_device(device)
     _native.lib()  # fail loudly right here if the HIP library is missing
@@ -505,10 +595,15 @@ def main():
             kernels_per_step = sum(float(r["CallsPerStep"]) for r in csv.DictReader(open(steady)))
         except Exception:
             pass
+    acct = rank_accounting(device, lr)
+    if acct["n_gpus"] != args.gpus or acct["rccl_ranks"] != args.gpus:
+        raise SystemExit(f"bench.py: rank accounting {acct} does not match --gpus {args.gpus}")
     if rk == 0:
         V = len(view_ids)
         line = {
-            "metric": METRIC, "value": args.steps / elapsed, "unit": "iters/s", "n_gpus": ws, "steps": args.steps,
+            "metric": METRIC, "value": args.steps / elapsed, "unit": "iters/s", "n_gpus": acct["n_gpus"],
+            "rccl_ranks": acct["rccl_ranks"], "distinct_devices": acct["distinct_devices"],
+            "collective_backend": acct["backend"], "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16" if not args.fp8 else "bf16 + fp8(e4m3) 3x3 convolutions of the no-grad UNet forward",
