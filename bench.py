@@ -198,8 +198,8 @@ def vsd_main(args):
     from garmentdreamer_amd import dist as gdist
     from garmentdreamer_amd.guidance import sd21
     from garmentdreamer_amd.guidance.sd_vsd import LoraUnet, StableDiffusionVSD
+    check_world(args, int(os.environ.get("WORLD_SIZE", "1")), need_gpus=True)
     rk, lr, ws = gdist.init_from_env()
-    check_world(args, ws, need_gpus=True)
     device = torch.device("cuda", lr)
     torch.cuda.set_device(device)
     gd = StableDiffusionVSD(device, fp16=True, use_hip_graphs=not args.no_graphs, fp8_unet=bool(args.fp8))
@@ -390,10 +390,10 @@ def main():
     from garmentdreamer_amd.scene import GaussianParams, synthetic_gaussians
     from garmentdreamer_amd.sds_loop import SDSLoop
 
-    rk, lr, ws = gdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP rasterizer has no CPU path")
-    check_world(args, ws, need_gpus=True)
+    check_world(args, int(os.environ.get("WORLD_SIZE", "1")), need_gpus=True)   # before any device / group is touched
+    rk, lr, ws = gdist.init_from_env()
     device = torch.device("cuda", lr % torch.cuda.device_count())   # (ranks may share a GPU only under GD_DIST_BACKEND=gloo)
     torch.cuda.set_device(device)
     _native.lib()  # fail loudly right here if the HIP library is missing
