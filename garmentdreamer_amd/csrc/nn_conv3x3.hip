@@ -974,6 +974,8 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
     }
 }
 
+#include "nn_conv_wino.h"
+
 // out = bf16( sum_s partial[s] + bias + residual ): second half of the split-K path; 8 channels per thread.  Partials
 // are indexed by GEMM row; the row -> output pixel map is the convolution's (identity for stride-1 layers, every
 // second pixel for the parity classes of a stride-2 input gradient).
@@ -1555,6 +1557,76 @@ int gd_nn_conv3x3_forward_stats(void* stream, const void* x, const void* weight,
                                            "(gd_nn_conv3x3_stat_rows() == 0)");
     return launch_patch(stream, x, nullptr, nullptr, nullptr, 0, 0, weight, bias, bias_img_stride, residual, y, N, H, W,
                         Cin, Cout, stat_part);
+}
+
+// ---- Winograd F(2,3)-along-x form of the stride-1 convolution (nn_conv_wino.h)
+size_t gd_nn_conv3x3_wino_weights_bytes(int Cout, int Cin)
+{
+    if (Cout <= 0 || Cin <= 0 || Cin % kWinoCK) return 0;
+    return (size_t)((Cout + 127) / 128) * 3 * (size_t)(Cin / kWinoCK) * (size_t)kWinoWStage;
+}
+
+int gd_nn_conv3x3_wino_weights(void* stream, const void* weight, void* u, int Cout, int Cin)
+{
+    if (!weight || !u || Cout <= 0 || Cin <= 0) return fail(GD_NN_ERR_INVALID_ARG, "wino_weights: bad argument");
+    if (Cin % kWinoCK) return fail(GD_NN_ERR_INVALID_ARG, "wino_weights: Cin % 32 != 0");
+    const size_t total = gd_nn_conv3x3_wino_weights_bytes(Cout, Cin) / 16;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv3x3_wino_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)weight,
+                       (uint16_t*)u, Cout, Cin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_conv3x3_wino_supported(int N, int H, int W, int Cin, int Cout)
+{
+    if (N <= 0 || H < 16 || W < 16 || Cin <= 0 || Cout < 64) return 0;
+    if (Cin % kWinoCK || Cout % 4) return 0;
+    if ((double)N * H * W * Cin * 2.0 >= 2147483648.0 || (double)gd_nn_conv3x3_wino_weights_bytes(Cout, Cin) >= 2147483648.0) return 0;
+    return 1;
+}
+
+int gd_nn_conv3x3_wino_forward(void* stream, const void* x, const void* u, const void* bias, int bias_img_stride,
+                               const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part)
+{
+    if (!x || !u || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!gd_nn_conv3x3_wino_supported(N, H, W, Cin, Cout))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_wino: need Cin % 32 == 0, Cout % 4 == 0, Cout >= 64, H, W >= 16, tensors < 2 GiB");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    const int64_t M = (int64_t)N * H * W;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (g_cprof.on) {
+        std::lock_guard<std::mutex> lk(g_cprof.mu);
+        ea = g_cprof.get(); eb = g_cprof.get();
+        if (ea && eb) (void)hipEventRecord(ea, s);
+    }
+    auto kern = conv3x3_wino_kernel<128>;
+    static bool attr_set[16] = {false};
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoLds);
+        attr_set[dev] = true;
+    }
+    const int tiles_n = (Cout + 127) / 128;
+    const int nwg = N * tiles_x * tiles_y * tiles_n;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), kWinoLds, s, (const uint16_t*)x, (const uint16_t*)u,
+                       (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y, N, H, W, Cin, Cout,
+                       tiles_n, tiles_x, tiles_y, nwg, stat_part);
+    if (ea && eb) {
+        (void)hipEventRecord(eb, s);
+        std::lock_guard<std::mutex> lk(g_cprof.mu);
+        g_cprof.pending.push_back({ea, eb});
+        // ALGORITHMIC flops of the convolution (direct form), whatever the kernel multiplies
+        g_cprof.total_flops += 2.0 * (double)M * Cout * 9.0 * Cin;
+        g_cprof.total_bytes += 2.0 * ((double)M * Cin + 9.0 * Cin * Cout + (double)M * Cout +
+                                      (residual ? (double)M * Cout : 0.0));
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
 }
 
 // persistent workgroups of the matrix-core first convolution: two per CU (8 waves of ~170 VGPRs), fewer for small inputs

@@ -39,6 +39,10 @@ SIGNATURES = {
     "gd_nn_conv3x3_gn_forward_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
                                             _vp]),
     "gd_nn_conv3x3_forward_stats": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gd_nn_conv3x3_wino_supported": (_i, [_i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_wino_weights": (_i, [_vp, _vp, _vp, _i, _i]),
+    "gd_nn_conv3x3_wino_weights_bytes": (C.c_size_t, [_i, _i]),
+    "gd_nn_conv3x3_wino_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_groupnorm_finish_partials": (_i, [_vp, _vp, _i, C.c_size_t, _i, _i, _i, _f, _vp]),
     "gd_nn_conv3x3_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
@@ -225,6 +229,38 @@ def _patch_launch(x, w_khwc, bias, residual, out_channels):
                                          out_channels)
     if ret < 0:
         raise RuntimeError(f"gd_nn_conv3x3_gn_forward failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
+    return y
+
+
+def _wino(weight):
+    """Cached Winograd F(2,3) filter bank (the kernel's 32 KB step images, include/gd_nn.h) of a frozen conv weight
+    (channels_last, i.e. [Cout][3][3][Cin] in memory) -- also of a flipped dgrad weight tensor."""
+    u = getattr(weight, "_gd_wino", None)
+    key = (weight.data_ptr(), weight._version)
+    if u is None or u.device != weight.device or getattr(weight, "_gd_wino_key", None) != key:
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        u = torch.empty(lib().gd_nn_conv3x3_wino_weights_bytes(Cout, Cin) // 2, dtype=torch.bfloat16, device=weight.device)
+        with torch.cuda.device(weight.device):
+            ret = lib().gd_nn_conv3x3_wino_weights(torch.cuda.current_stream(weight.device).cuda_stream,
+                                                   weight.data_ptr(), u.data_ptr(), Cout, Cin)
+        _check(ret, "gd_nn_conv3x3_wino_weights", "gd_nn_conv_last_error")
+        weight._gd_wino, weight._gd_wino_key = u, key
+    return u
+
+
+def _wino_launch(x, w_khwc, bias, residual, out_channels, stat_part=None):
+    """Plain 3x3/s1/p1 convolution on the Winograd F(2,3)-along-x kernel (csrc/nn_conv_wino.h)."""
+    N, Cin, H, W = x.shape
+    L = lib()
+    y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    bias, stride = _bias_and_stride(bias)
+    u = _wino(w_khwc)
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_conv3x3_wino_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), u.data_ptr(),
+                                           None if bias is None else bias.data_ptr(), stride,
+                                           None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
+                                           out_channels, None if stat_part is None else stat_part.data_ptr())
+    _check(ret, "gd_nn_conv3x3_wino_forward", "gd_nn_conv_last_error")
     return y
 
 

@@ -116,6 +116,21 @@ int gd_nn_conv3x3_gn_forward_stats(void* stream, const void* x, const float* mea
                                    int Cout, float* stat_part);
 int gd_nn_conv3x3_forward_stats(void* stream, const void* x, const void* weight, const void* bias, int bias_img_stride,
                                 const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
+/* The same stride-1 convolution with the Winograd F(2,3) minimal-filtering transform along x
+ * (csrc/nn_conv_wino.h): 2/3 of the matrix-core work of the direct form.  u = the transformed filter bank of a
+ * weight tensor [Cout][3][3][Cin], stored as the sequence of 32 KB LDS images the kernel streams -- per (128-channel
+ * block, ky, 32-channel chunk): [4 positions][128 rows][32 ch], gd_nn_conv3x3_wino_weights_bytes() bytes in all
+ * (gd_nn_conv3x3_wino_weights; the caller
+ * caches it per frozen weight like the flipped dgrad weights -- dgrad = the same kernel on the transform of the
+ * flipped weights).  Needs Cin % 32 == 0 (gd_nn_conv3x3_wino_supported).  stat_part: NULL or the GroupNorm partial
+ * sums of the output as in gd_nn_conv3x3_forward_stats (rows = ceil(H/16) * ceil(W/16) * 8).
+ * Replaces the same reference call as gd_nn_conv3x3_forward (diffusers ResnetBlock2D conv1 / conv2, reached from
+ * Garment_3DGS/threestudio/models/guidance/stable_diffusion_guidance.py:153-167). */
+int gd_nn_conv3x3_wino_supported(int N, int H, int W, int Cin, int Cout);
+size_t gd_nn_conv3x3_wino_weights_bytes(int Cout, int Cin);     /* bytes of u (Cout padded to a multiple of 128) */
+int gd_nn_conv3x3_wino_weights(void* stream, const void* weight, void* u, int Cout, int Cin);
+int gd_nn_conv3x3_wino_forward(void* stream, const void* x, const void* u, const void* bias, int bias_img_stride,
+                               const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
 /* ... and of the first convolution (gd_nn_conv3x3_first_forward below; Cout == 128 only, the VAE encoder's conv_in):
  * rows = gd_nn_conv3x3_first_stat_rows(N, H, W, Cin, Cout), 0 when that shape has no statistics path. */
 size_t gd_nn_conv3x3_first_stat_rows(int N, int H, int W, int Cin, int Cout);
