@@ -1560,6 +1560,7 @@ int gd_nn_conv3x3_forward_stats(void* stream, const void* x, const void* weight,
 }
 
 // ---- Winograd F(2,3)-along-x form of the stride-1 convolution (nn_conv_wino.h)
+
 size_t gd_nn_conv3x3_wino_weights_bytes(int Cout, int Cin)
 {
     if (Cout <= 0 || Cin <= 0 || Cin % kWinoCK) return 0;
@@ -1582,17 +1583,20 @@ int gd_nn_conv3x3_wino_weights(void* stream, const void* weight, void* u, int Co
 int gd_nn_conv3x3_wino_supported(int N, int H, int W, int Cin, int Cout)
 {
     if (N <= 0 || H < 16 || W < 16 || Cin <= 0 || Cout < 64) return 0;
-    if (Cin % kWinoCK || Cout % 4) return 0;
+    if (Cin % kWinoCK || Cout % 8) return 0;
     if ((double)N * H * W * Cin * 2.0 >= 2147483648.0 || (double)gd_nn_conv3x3_wino_weights_bytes(Cout, Cin) >= 2147483648.0) return 0;
     return 1;
 }
 
-int gd_nn_conv3x3_wino_forward(void* stream, const void* x, const void* u, const void* bias, int bias_img_stride,
-                               const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part)
+static int launch_wino(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta, int groups,
+                       int apply_silu, const void* u, const void* bias, int bias_img_stride, const void* residual, void* y,
+                       int N, int H, int W, int Cin, int Cout, float* stat_part)
 {
     if (!x || !u || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (!gd_nn_conv3x3_wino_supported(N, H, W, Cin, Cout))
-        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_wino: need Cin % 32 == 0, Cout % 4 == 0, Cout >= 64, H, W >= 16, tensors < 2 GiB");
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_wino: need Cin % 32 == 0, Cout % 8 == 0, Cout >= 64, H, W >= 16, tensors < 2 GiB");
+    if (mean_rstd && (!gamma || !beta || groups <= 0 || Cin % groups))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_wino: GroupNorm needs gamma, beta and Cin % groups == 0");
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
     hipStream_t s = (hipStream_t)stream;
@@ -1604,17 +1608,25 @@ int gd_nn_conv3x3_wino_forward(void* stream, const void* x, const void* u, const
         ea = g_cprof.get(); eb = g_cprof.get();
         if (ea && eb) (void)hipEventRecord(ea, s);
     }
-    auto kern = conv3x3_wino_kernel<128>;
-    static bool attr_set[16] = {false};
-    if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoLds);
-        attr_set[dev] = true;
-    }
     const int tiles_n = (Cout + 127) / 128;
     const int nwg = N * tiles_x * tiles_y * tiles_n;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), kWinoLds, s, (const uint16_t*)x, (const uint16_t*)u,
-                       (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y, N, H, W, Cin, Cout,
-                       tiles_n, tiles_x, tiles_y, nwg, stat_part);
+    const int grid = nwg;      // one tile per workgroup (the persistent form measured slower: nn_conv_wino.h)
+#define GD_LAUNCH_W(GN_)                                                                                           \
+    do {                                                                                                           \
+        auto kern = conv3x3_wino_kernel<GN_>;                                                                      \
+        static bool attr_set[16] = {false};                                                                        \
+        if (!attr_set[dev]) {                                                                                      \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kWinoLds);    \
+            attr_set[dev] = true;                                                                                  \
+        }                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kWinoLds, s, (const uint16_t*)x, (const uint16_t*)u,       \
+                           (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y, N, H,  \
+                           W, Cin, Cout, mean_rstd, (const uint16_t*)gamma, (const uint16_t*)beta, groups,         \
+                           apply_silu, tiles_n, tiles_x, tiles_y, nwg, stat_part);                                 \
+    } while (0)
+    if (mean_rstd) GD_LAUNCH_W(true);
+    else GD_LAUNCH_W(false);
+#undef GD_LAUNCH_W
     if (ea && eb) {
         (void)hipEventRecord(eb, s);
         std::lock_guard<std::mutex> lk(g_cprof.mu);
@@ -1627,6 +1639,22 @@ int gd_nn_conv3x3_wino_forward(void* stream, const void* x, const void* u, const
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
+}
+
+int gd_nn_conv3x3_wino_forward(void* stream, const void* x, const void* u, const void* bias, int bias_img_stride,
+                               const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part)
+{
+    return launch_wino(stream, x, nullptr, nullptr, nullptr, 0, 0, u, bias, bias_img_stride, residual, y, N, H, W, Cin,
+                       Cout, stat_part);
+}
+
+int gd_nn_conv3x3_wino_gn_forward(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
+                                  int groups, int apply_silu, const void* u, const void* bias, int bias_img_stride,
+                                  const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part)
+{
+    if (!mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_wino_gn: mean_rstd is NULL");
+    return launch_wino(stream, x, mean_rstd, gamma, beta, groups, apply_silu, u, bias, bias_img_stride, residual, y, N, H, W,
+                       Cin, Cout, stat_part);
 }
 
 // persistent workgroups of the matrix-core first convolution: two per CU (8 waves of ~170 VGPRs), fewer for small inputs

@@ -39,7 +39,6 @@
 // Timing-only switches of tools/wino_ablate.sh (never defined in a product build; results are wrong by construction):
 //   1 no input transform   2 no filter DMA after the first slice   3 no patch DMA after the first chunk
 //   4 no MFMAs (loads, transform, fragment reads stay)   5 no partner exchange   6 no output stores
-//   7 MFMAs only: no DMA, no transform, no fragment reads
 #ifndef GD_WINO_ABLATE
 #define GD_WINO_ABLATE 0
 #endif
@@ -87,14 +86,26 @@ __global__ __launch_bounds__(256) void conv3x3_wino_weights_kernel(const uint16_
     }
 }
 
-template <int BN>
+// GN = true: diffusers' ResnetBlock2D front half conv(silu(GroupNorm(x))) in one kernel -- the raw patch chunk goes
+// global -> registers -> x * a[n, c] + b[n, c] -> SiLU -> bf16 -> P (a = gamma * rstd, b = beta - mean * a; zero padding
+// applied after the transform) instead of the LDS-DMA.
+//
+// One tile per workgroup, the compiler's own schedule of the step.  Measured and NOT kept (same-box A/B against this
+// form, tools/wino_conv_bench.py): persistent workgroups with the patch loader / transform running across
+// tile boundaries, the step's LDS-DMA and transform dealt out behind the MFMA groups, fragment reads as inline asm with
+// register double buffering and counted waits, filter slices through registers instead of LDS-DMA, a third filter stage
+// fetched two steps ahead -- each 0...-15 %.
+template <bool GN>
 __global__ __launch_bounds__(512) void conv3x3_wino_kernel(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ uw, const uint16_t* __restrict__ bias,
     int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, int H, int W,
-    int Cin, int Cout, int tiles_n, int tiles_x, int tiles_y, int nwg, float* __restrict__ stat_part)
+    int Cin, int Cout, const float* __restrict__ mean_rstd, const uint16_t* __restrict__ gamma,
+    const uint16_t* __restrict__ beta, int G, int apply_silu, int tiles_n, int tiles_x, int tiles_y, int nwg,
+    float* __restrict__ stat_part)
 {
-    static_assert(BN == 128, "tile = 128 output channels");
+    constexpr int BN = 128;
     constexpr int THREADS = 512;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sV = smem;
     char* sW = smem + 2 * kWinoVStage;
@@ -120,6 +131,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(
 
     // ---- raw patch loader (LDS-DMA): piece q = tid + 512 i -> pixel q >> 2, 16-byte chunk q & 3
     uint32_t p_goff[3];
+    uint32_t p_keep = 0;     // GN: bit i = piece i is a pixel inside the image
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const int q = tid + THREADS * i;
@@ -128,12 +140,57 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(
         const int gy = y0 + py, gx = x0 + px;
         const bool inimg = pix < kPatchPix && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         p_goff[i] = inimg ? (uint32_t)((nimg * H + gy) * W + gx) * row_bytes + (uint32_t)(q & 3) * 16u : kOOB;
+        if (inimg) p_keep |= 1u << i;
     }
-    auto issueP = [&](int c) {
+    auto issueP = [&](int c) {      // GN = false: LDS-DMA, out-of-image lanes are zero-filled by the hardware
+        if (GD_WINO_ABLATE == 3) return;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             if (i == 2 && wave >= 5) continue;    // 1344 pieces = 21 wave-instructions
             bload_lds16(rs_in, p_goff[i], (uint32_t)c * (kWinoCK * 2), sP + (wave * 64 + THREADS * i) * 16);
+        }
+    };
+    u32x4 p_reg[3];
+    auto loadP = [&](int c) {       // GN = true: global -> registers
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (i == 2 && wave >= 5) continue;
+            p_reg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)p_goff[i],
+                                                                                    (int)(c * (kWinoCK * 2)), 0));
+        }
+    };
+    const int cg = GN ? Cin / G : 1;
+    const uint32_t sP_off = (uint32_t)(uintptr_t)sP;
+    auto storeP = [&](int c) {      // GN = true: normalise + SiLU + round, registers -> P
+        float sc[8], sh[8];
+        const int ch0 = c * kWinoCK + (tid & 3) * 8;     // (tid + 512 i) & 3 == tid & 3: one channel octet per thread
+        const uint4 gq = *(const uint4*)(gamma + ch0), bq = *(const uint4*)(beta + ch0);
+        const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int g = (ch0 + k) / cg;
+            const float2 mr = *(const float2*)(mean_rstd + ((size_t)nimg * G + g) * 2);
+            const float gm = bf2f((uint16_t)(gw[k >> 1] >> ((k & 1) * 16)));
+            const float bt = bf2f((uint16_t)(bw[k >> 1] >> ((k & 1) * 16)));
+            sc[k] = gm * mr.y;
+            sh[k] = bt - mr.x * sc[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (i == 2 && wave >= 5) continue;
+            const bool keep = (p_keep >> i) & 1u;
+            u32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float lo = __uint_as_float(p_reg[i][k] << 16), hi = __uint_as_float(p_reg[i][k] & 0xffff0000u);
+                lo = lo * sc[2 * k] + sh[2 * k];
+                hi = hi * sc[2 * k + 1] + sh[2 * k + 1];
+                if (apply_silu) { lo = silu_fast(lo); hi = silu_fast(hi); }
+                v[k] = keep ? pack_bf16(lo, hi) : 0u;
+            }
+            // inline asm (here and in the transform): the compiler cannot tell a plain LDS store from the target of the
+            // LDS-DMA in flight (the next filter slice) and would put s_waitcnt vmcnt(0) in front of it
+            asm volatile("ds_write_b128 %0, %1" ::"v"(sP_off + (uint32_t)(tid + THREADS * i) * 16u), "v"(v) : "memory");
         }
     };
     // ---- transformed-filter loader (LDS-DMA): the step's slice is one contiguous 32 KB image (weights kernel above)
@@ -150,7 +207,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(
     auto transform_item = [&](char* dstV, int item) {
         const int c = item & 3, t = (item >> 2) & 7, r = item >> 5;
         const char* src = sP + (r * kPatch + 2 * t) * 64 + c * 16;
-        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
         u32x4 d[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) d[j] = *(const u32x4*)(src + j * 64);
@@ -200,53 +256,34 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(
 
     const int nsteps = 3 * kc;
     // prologue
-    issueP(0);
+    if (GN) { loadP(0); storeP(0); } else issueP(0);
     issueW(0, 0, 0);
-    if (GD_WINO_ABLATE == 8 && nsteps > 1) issueW(1, 1, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     transform_item(sV, tid);
     if (wave == 0) transform_item(sV, 512 + lane);
     __syncthreads();                 // P(0) consumed, V(0) complete
-    if (kc > 1) issueP(1);
+    if (kc > 1) { if (GN) { loadP(1); storeP(1); } else issueP(1); }
     int s = 0;
     for (int c = 0; c < kc; c++) {
         const char* pv = sV + (c & 1) * kWinoVStage;
         char* nv = sV + ((c + 1) & 1) * kWinoVStage;
         for (int ky = 0; ky < 3; ky++, s++) {
-            int bufW = s & 1;
-            if (GD_WINO_ABLATE == 8) {
-                // timing experiment: filter slices fetched TWO steps ahead into a ring of three (the third stage
-                // aliases V: wrong results)
-                bufW = s % 3;
-                if (s + 1 < nsteps && s > 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (ky == 2 && c + 2 < kc) issueP(c + 2);
-                if (s + 2 < nsteps) {
-                    const int s2 = s + 2, c2 = s2 / 3, k2 = s2 - 3 * c2, st = s2 % 3;
-                    char* dst = st == 2 ? smem : sW + st * kWinoWStage;
-                    const uint32_t soff = (uint32_t)((tn * 3 + k2) * kc + c2) * (uint32_t)kWinoWStage;
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        bload_lds16(rs_w, w_voff + (uint32_t)(THREADS * 16 * i), soff, dst + (wave * 64 + THREADS * i) * 16);
-                }
-                if (c + 1 < kc) {
-                    if (ky == 0) transform_item(nv, tid);
-                    else if (ky == 1) { if (wave == (c & 7)) transform_item(nv, 512 + lane); }
-                }
-            } else {
+            const int bufW = s & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (s + 1 < nsteps && GD_WINO_ABLATE != 2 && GD_WINO_ABLATE != 7) issueW(bufW ^ 1, ky == 2 ? 0 : ky + 1, ky == 2 ? c + 1 : c);
+            if (s + 1 < nsteps && GD_WINO_ABLATE != 2) issueW(bufW ^ 1, ky == 2 ? 0 : ky + 1, ky == 2 ? c + 1 : c);
             if (c + 1 < kc) {
-                if (ky == 0) { if (GD_WINO_ABLATE != 1 && GD_WINO_ABLATE != 7) transform_item(nv, tid); }
-                else if (ky == 1) { if (wave == (c & 7) && GD_WINO_ABLATE != 1 && GD_WINO_ABLATE != 7) transform_item(nv, 512 + lane); }
-                else if (c + 2 < kc && GD_WINO_ABLATE != 3 && GD_WINO_ABLATE != 7) issueP(c + 2);       // every wave is past its reads of P(c + 1)
+                if (ky == 0) {
+                    if (GD_WINO_ABLATE != 1) transform_item(nv, tid);
+                    if (GN && c + 2 < kc) loadP(c + 2);
+                } else if (ky == 1) {
+                    if (wave == (c & 7) && GD_WINO_ABLATE != 1) transform_item(nv, 512 + lane);
+                } else if (c + 2 < kc) {       // every wave is past its reads of P(c + 1)
+                    if (GN) storeP(c + 2); else issueP(c + 2);
+                }
             }
-            }
-            const char* pw = (GD_WINO_ABLATE == 8 && bufW == 2) ? smem : sW + bufW * kWinoWStage;
+            const char* pw = sW + bufW * kWinoWStage;
             const uint32_t b_key = ((((uint32_t)(fn >> 3) + (uint32_t)ky) & 1u) << 1) | b_keylo;
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
@@ -255,19 +292,12 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(
                 for (int p = 0; p < 2; p++) {
                     const int pos = 2 * pp + p;
                     bf16x8_t wf[2], vf[2];
-                    if (GD_WINO_ABLATE == 7) {
 #pragma unroll
-                        for (int a = 0; a < 2; a++)
+                    for (int a = 0; a < 2; a++)
+                        wf[a] = *(const bf16x8_t*)(pw + pos * (128 * 64) + a_rd[a] + ((ch ^ a_key) << 4));
 #pragma unroll
-                            for (int e = 0; e < 8; e++) { wf[a][e] = (short)(0x3c00 + lane + a + kk); vf[a][e] = (short)(0x3d00 + lane * 3 + p); }
-                    } else {
-#pragma unroll
-                        for (int a = 0; a < 2; a++)
-                            wf[a] = *(const bf16x8_t*)(pw + pos * (128 * 64) + a_rd[a] + ((ch ^ a_key) << 4));
-#pragma unroll
-                        for (int b = 0; b < 2; b++)
-                            vf[b] = *(const bf16x8_t*)(pv + pos * 9216 + b_rd[b] + ky * 512 + ((ch ^ b_key) << 4));
-                    }
+                    for (int b = 0; b < 2; b++)
+                        vf[b] = *(const bf16x8_t*)(pv + pos * 9216 + b_rd[b] + ky * 512 + ((ch ^ b_key) << 4));
                     if (GD_WINO_ABLATE == 4) {
 #pragma unroll
                         for (int a = 0; a < 2; a++)

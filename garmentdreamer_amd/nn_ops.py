@@ -43,6 +43,7 @@ SIGNATURES = {
     "gd_nn_conv3x3_wino_weights": (_i, [_vp, _vp, _vp, _i, _i]),
     "gd_nn_conv3x3_wino_weights_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_wino_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gd_nn_conv3x3_wino_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_groupnorm_finish_partials": (_i, [_vp, _vp, _i, C.c_size_t, _i, _i, _i, _f, _vp]),
     "gd_nn_conv3x3_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
@@ -89,7 +90,12 @@ def lib():
                                "the HIP guidance kernels have no fallback on GPU tensors")
         L = C.CDLL(_LIB_PATH)  # torch is imported above: one libamdhip64 per process
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                if os.environ.get("GD_NN_LIB"):      # an older experimental build under A/B (tools/): symbol not there yet
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
@@ -261,6 +267,24 @@ def _wino_launch(x, w_khwc, bias, residual, out_channels, stat_part=None):
                                            None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
                                            out_channels, None if stat_part is None else stat_part.data_ptr())
     _check(ret, "gd_nn_conv3x3_wino_forward", "gd_nn_conv_last_error")
+    return y
+
+
+def _wino_gn_launch(x, mean_rstd, gn_weight, gn_bias, groups, silu, w_khwc, bias, residual, out_channels, stat_part=None):
+    """conv3x3(act(GroupNorm(x))) on the Winograd kernel, GroupNorm(+SiLU) applied in its loader; ``mean_rstd`` from
+    gd_nn_groupnorm_stats / finish_partials."""
+    N, Cin, H, W = x.shape
+    L = lib()
+    y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    bias, stride = _bias_and_stride(bias)
+    u = _wino(w_khwc)
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_conv3x3_wino_gn_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
+                                              mean_rstd.data_ptr(), gn_weight.data_ptr(), gn_bias.data_ptr(), groups,
+                                              int(silu), u.data_ptr(), None if bias is None else bias.data_ptr(), stride,
+                                              None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
+                                              out_channels, None if stat_part is None else stat_part.data_ptr())
+    _check(ret, "gd_nn_conv3x3_wino_gn_forward", "gd_nn_conv_last_error")
     return y
 
 

@@ -122,7 +122,7 @@ int gd_nn_conv3x3_forward_stats(void* stream, const void* x, const void* weight,
  * block, ky, 32-channel chunk): [4 positions][128 rows][32 ch], gd_nn_conv3x3_wino_weights_bytes() bytes in all
  * (gd_nn_conv3x3_wino_weights; the caller
  * caches it per frozen weight like the flipped dgrad weights -- dgrad = the same kernel on the transform of the
- * flipped weights).  Needs Cin % 32 == 0 (gd_nn_conv3x3_wino_supported).  stat_part: NULL or the GroupNorm partial
+ * flipped weights).  Needs Cin % 32 == 0 and Cout % 8 == 0 (gd_nn_conv3x3_wino_supported).  stat_part: NULL or the GroupNorm partial
  * sums of the output as in gd_nn_conv3x3_forward_stats (rows = ceil(H/16) * ceil(W/16) * 8).
  * Replaces the same reference call as gd_nn_conv3x3_forward (diffusers ResnetBlock2D conv1 / conv2, reached from
  * Garment_3DGS/threestudio/models/guidance/stable_diffusion_guidance.py:153-167). */
@@ -131,6 +131,10 @@ size_t gd_nn_conv3x3_wino_weights_bytes(int Cout, int Cin);     /* bytes of u (C
 int gd_nn_conv3x3_wino_weights(void* stream, const void* weight, void* u, int Cout, int Cin);
 int gd_nn_conv3x3_wino_forward(void* stream, const void* x, const void* u, const void* bias, int bias_img_stride,
                                const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
+/* ... with GroupNorm(+SiLU) of the input applied in the loader, as gd_nn_conv3x3_gn_forward(_stats). */
+int gd_nn_conv3x3_wino_gn_forward(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
+                                  int groups, int apply_silu, const void* u, const void* bias, int bias_img_stride,
+                                  const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
 /* ... and of the first convolution (gd_nn_conv3x3_first_forward below; Cout == 128 only, the VAE encoder's conv_in):
  * rows = gd_nn_conv3x3_first_stat_rows(N, H, W, Cin, Cout), 0 when that shape has no statistics path. */
 size_t gd_nn_conv3x3_first_stat_rows(int N, int H, int W, int Cin, int Cout);

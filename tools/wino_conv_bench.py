@@ -53,5 +53,18 @@ for (N, ci, co, hw) in SH:
         del ref
         t_p = timeit(lambda: nn_ops._patch_launch(x, w, b, r, co))
         t_w = timeit(lambda: nn_ops._wino_launch(x, w, b, r, co))
+    gtxt = ""
+    if N * hw * hw >= 65536 * 8 and ci % 32 == 0:      # GroupNorm-in-loader pair (the VAE / UNet ResnetBlock front half)
+        with torch.no_grad():
+            gw = torch.ones(ci, device="cuda", dtype=torch.bfloat16); gb = torch.zeros(ci, device="cuda", dtype=torch.bfloat16)
+            mr = torch.tensor([0.0, 1.0], device="cuda").repeat(N * 32).contiguous()
+            L = nn_ops.lib()
+            yg = torch.empty_like(yw)
+            st = torch.cuda.current_stream().cuda_stream
+            fd = lambda: L.gd_nn_conv3x3_gn_forward(st, x.data_ptr(), mr.data_ptr(), gw.data_ptr(), gb.data_ptr(), 32, 1, w.data_ptr(),
+                                                    b.data_ptr(), 0, r.data_ptr(), yg.data_ptr(), N, hw, hw, ci, co)
+            fw = lambda: nn_ops._wino_gn_launch(x, mr, gw, gb, 32, True, w, b, r, co)
+            t_gd, t_gw = timeit(fd), timeit(fw)
+            gtxt = f" | GN: direct {t_gd*1e6:7.1f}us wino {t_gw*1e6:7.1f}us ({t_gd/t_gw:4.2f}x)"
     print(f"N{N} {ci:4d}->{co:4d} @{hw:3d}: direct {t_p*1e6:7.1f}us {fl/t_p/1e12:5.0f}TF | wino {t_w*1e6:7.1f}us {fl/t_w/1e12:5.0f}TF "
-          f"({t_p/t_w:4.2f}x)  max err/max|ref| direct {ed:.2e} wino {ew:.2e}  rel rms direct {rd:.2e} wino {rw:.2e}", flush=True)
+          f"({t_p/t_w:4.2f}x)  max err/max|ref| direct {ed:.2e} wino {ew:.2e}  rel rms direct {rd:.2e} wino {rw:.2e}" + gtxt, flush=True)
