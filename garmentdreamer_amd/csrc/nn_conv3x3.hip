@@ -975,6 +975,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
 }
 
 #include "nn_conv_wino.h"
+#include "nn_conv_wide.h"
 
 // out = bf16( sum_s partial[s] + bias + residual ): second half of the split-K path; 8 channels per thread.  Partials
 // are indexed by GEMM row; the row -> output pixel map is the convolution's (identity for stride-1 layers, every
@@ -1654,6 +1655,100 @@ int gd_nn_conv3x3_wino_gn_forward(void* stream, const void* x, const float* mean
 {
     if (!mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_wino_gn: mean_rstd is NULL");
     return launch_wino(stream, x, mean_rstd, gamma, beta, groups, apply_silu, u, bias, bias_img_stride, residual, y, N, H, W,
+                       Cin, Cout, stat_part);
+}
+
+// ---- wide-tile (128 channels x 16 x 32 pixels) direct form for layers with few output channels (nn_conv_wide.h)
+size_t gd_nn_conv3x3_wide_weights_bytes(int Cout, int Cin)
+{
+    if (Cout <= 0 || Cin <= 0 || Cin % kWideCK) return 0;
+    return (size_t)((Cout + 127) / 128) * 3 * (size_t)(Cin / kWideCK) * (size_t)kWideWStage;
+}
+
+int gd_nn_conv3x3_wide_weights(void* stream, const void* weight, void* u, int Cout, int Cin)
+{
+    if (!weight || !u || Cout <= 0 || Cin <= 0 || Cin % kWideCK) return fail(GD_NN_ERR_INVALID_ARG, "wide_weights: bad argument");
+    const size_t total = gd_nn_conv3x3_wide_weights_bytes(Cout, Cin) / 16;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv3x3_wide_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)weight,
+                       (uint16_t*)u, Cout, Cin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_conv3x3_wide_supported(int N, int H, int W, int Cin, int Cout)
+{
+    if (N <= 0 || H < 16 || W < 16 || Cin <= 0 || Cout < 64) return 0;
+    if (Cin % kWideCK || Cout % 8) return 0;
+    if ((double)N * H * W * Cin * 2.0 >= 2147483648.0 || (double)gd_nn_conv3x3_wide_weights_bytes(Cout, Cin) >= 2147483648.0) return 0;
+    return 1;
+}
+
+static int launch_wide(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta, int groups,
+                       int apply_silu, const void* u, const void* bias, int bias_img_stride, const void* residual, void* y,
+                       int N, int H, int W, int Cin, int Cout, float* stat_part)
+{
+    if (!x || !u || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!gd_nn_conv3x3_wide_supported(N, H, W, Cin, Cout))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_wide: need Cin % 32 == 0, Cout % 8 == 0, Cout >= 64, H, W >= 16, tensors < 2 GiB");
+    if (mean_rstd && (!gamma || !beta || groups <= 0 || Cin % groups))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_wide: GroupNorm needs gamma, beta and Cin % groups == 0");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 15) / 16;
+    const int64_t M = (int64_t)N * H * W;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (g_cprof.on) {
+        std::lock_guard<std::mutex> lk(g_cprof.mu);
+        ea = g_cprof.get(); eb = g_cprof.get();
+        if (ea && eb) (void)hipEventRecord(ea, s);
+    }
+    const int tiles_n = (Cout + 127) / 128;
+    const int nwg = N * tiles_x * tiles_y * tiles_n;
+#define GD_LAUNCH_WD(GN_)                                                                                          \
+    do {                                                                                                           \
+        auto kern = conv3x3_wide_kernel<GN_>;                                                                      \
+        static bool attr_set[16] = {false};                                                                        \
+        if (!attr_set[dev]) {                                                                                      \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);    \
+            attr_set[dev] = true;                                                                                  \
+        }                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), kWideLds, s, (const uint16_t*)x, (const uint16_t*)u,        \
+                           (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y, N, H,  \
+                           W, Cin, Cout, mean_rstd, (const uint16_t*)gamma, (const uint16_t*)beta, groups,         \
+                           apply_silu, tiles_n, tiles_x, tiles_y, nwg, stat_part);                                 \
+    } while (0)
+    if (mean_rstd) GD_LAUNCH_WD(true);
+    else GD_LAUNCH_WD(false);
+#undef GD_LAUNCH_WD
+    if (ea && eb) {
+        (void)hipEventRecord(eb, s);
+        std::lock_guard<std::mutex> lk(g_cprof.mu);
+        g_cprof.pending.push_back({ea, eb});
+        g_cprof.total_flops += 2.0 * (double)M * Cout * 9.0 * Cin;
+        g_cprof.total_bytes += 2.0 * ((double)M * Cin + 9.0 * Cin * Cout + (double)M * Cout +
+                                      (residual ? (double)M * Cout : 0.0));
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_conv3x3_wide_forward(void* stream, const void* x, const void* u, const void* bias, int bias_img_stride,
+                               const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part)
+{
+    return launch_wide(stream, x, nullptr, nullptr, nullptr, 0, 0, u, bias, bias_img_stride, residual, y, N, H, W, Cin,
+                       Cout, stat_part);
+}
+
+int gd_nn_conv3x3_wide_gn_forward(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
+                                  int groups, int apply_silu, const void* u, const void* bias, int bias_img_stride,
+                                  const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part)
+{
+    if (!mean_rstd) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_wide_gn: mean_rstd is NULL");
+    return launch_wide(stream, x, mean_rstd, gamma, beta, groups, apply_silu, u, bias, bias_img_stride, residual, y, N, H, W,
                        Cin, Cout, stat_part);
 }
 

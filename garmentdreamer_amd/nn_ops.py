@@ -44,6 +44,11 @@ SIGNATURES = {
     "gd_nn_conv3x3_wino_weights_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_wino_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_conv3x3_wino_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gd_nn_conv3x3_wide_supported": (_i, [_i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_wide_weights": (_i, [_vp, _vp, _vp, _i, _i]),
+    "gd_nn_conv3x3_wide_weights_bytes": (C.c_size_t, [_i, _i]),
+    "gd_nn_conv3x3_wide_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gd_nn_conv3x3_wide_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_groupnorm_finish_partials": (_i, [_vp, _vp, _i, C.c_size_t, _i, _i, _i, _f, _vp]),
     "gd_nn_conv3x3_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_s2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
@@ -202,8 +207,40 @@ def _bias_and_stride(bias):
     return bias, bias.stride(0)
 
 
+# GD_NN_WINO=0: every stride-1 convolution on the direct kernels (A/B timing in tools/; never set in tests or the benchmark)
+_WINO = os.environ.get("GD_NN_WINO", "1") != "0"
+
+
+def _conv_route(N, H, W, Cin, Cout, gn=False):
+    """Which kernel a stride-1 3x3 convolution runs on: "wide" (128 channels x 16x32 pixels, csrc/nn_conv_wide.h), "wino"
+    (Winograd F(2,3) along x, csrc/nn_conv_wino.h) or None = the direct patch-staged / implicit-GEMM kernels.  Distilled
+    from tools/wino_route_bench.py and tools/gn_route_bench.py (every stride-1 shape of the SDS step, same box, against
+    what the direct path picks): the wide tile wins where a tile has <= 128 output channels to work with (128 -> 128 @
+    512^2 1.06x, 256 -> 128 1.08x, GroupNorm-fused 128 -> 128 1.08-1.11x) and on the 640-channel 32^2 level (1.13-1.21x);
+    Winograd wins wherever the input is >= 320 channels deep (1.03-1.34x); few-input-channel layers that widen
+    (128 -> 256, 256 -> 256, 256 -> 512: 0.90-1.02x) and every other GroupNorm-fused layer (0.87-0.91x) stay direct.
+    Both need a grid of >= 128 tiles: small batches stay on the implicit-GEMM kernel's split-K."""
+    if not _WINO or Cin % 32 or Cout % 8 or Cout < 64 or H < 16 or W < 16:
+        return None
+    tiles_n = (Cout + 127) // 128
+    if Cout <= 128 and (not gn or Cin <= 128) or (not gn and Cout == 640 and W == 32 and Cin >= 320):
+        if N * ((H + 15) // 16) * ((W + 31) // 32) * tiles_n >= 128 and lib().gd_nn_conv3x3_wide_supported(N, H, W, Cin, Cout):
+            return "wide"
+        return None
+    if gn or Cin < 320:
+        return None
+    if N * ((H + 15) // 16) * ((W + 15) // 16) * tiles_n >= 128 and lib().gd_nn_conv3x3_wino_supported(N, H, W, Cin, Cout):
+        return "wino"
+    return None
+
+
 def _conv_launch(x, w_khwc, bias, residual, out_channels):
     N, Cin, H, W = x.shape
+    route = _conv_route(N, H, W, Cin, out_channels)
+    if route == "wino":
+        return _wino_launch(x, w_khwc, bias, residual, out_channels)
+    if route == "wide":
+        return _wide_launch(x, w_khwc, bias, residual, out_channels)
     L = lib()
     y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device,
                     memory_format=torch.channels_last)
@@ -267,6 +304,43 @@ def _wino_launch(x, w_khwc, bias, residual, out_channels, stat_part=None):
                                            None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
                                            out_channels, None if stat_part is None else stat_part.data_ptr())
     _check(ret, "gd_nn_conv3x3_wino_forward", "gd_nn_conv_last_error")
+    return y
+
+
+def _wide(weight):
+    """Cached re-packing of a frozen conv weight for the wide-tile kernel (24 KB step images, include/gd_nn.h)."""
+    u = getattr(weight, "_gd_wide", None)
+    key = (weight.data_ptr(), weight._version)
+    if u is None or u.device != weight.device or getattr(weight, "_gd_wide_key", None) != key:
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        u = torch.empty(lib().gd_nn_conv3x3_wide_weights_bytes(Cout, Cin) // 2, dtype=torch.bfloat16, device=weight.device)
+        with torch.cuda.device(weight.device):
+            ret = lib().gd_nn_conv3x3_wide_weights(torch.cuda.current_stream(weight.device).cuda_stream,
+                                                   weight.data_ptr(), u.data_ptr(), Cout, Cin)
+        _check(ret, "gd_nn_conv3x3_wide_weights", "gd_nn_conv_last_error")
+        weight._gd_wide, weight._gd_wide_key = u, key
+    return u
+
+
+def _wide_launch(x, w_khwc, bias, residual, out_channels, stat_part=None, gn=None):
+    """3x3/s1/p1 convolution on the 128-channel x 16x32-pixel tile (csrc/nn_conv_wide.h); gn = (mean_rstd, gamma, beta,
+    groups, silu) applies GroupNorm(+SiLU) in the loader."""
+    N, Cin, H, W = x.shape
+    L = lib()
+    y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    bias, stride = _bias_and_stride(bias)
+    u = _wide(w_khwc)
+    with torch.cuda.device(x.device):
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        tail = (u.data_ptr(), None if bias is None else bias.data_ptr(), stride, None if residual is None else residual.data_ptr(),
+                y.data_ptr(), N, H, W, Cin, out_channels, None if stat_part is None else stat_part.data_ptr())
+        if gn is None:
+            ret = L.gd_nn_conv3x3_wide_forward(st, x.data_ptr(), *tail)
+        else:
+            mr, gw, gb, groups, silu = gn
+            ret = L.gd_nn_conv3x3_wide_gn_forward(st, x.data_ptr(), mr.data_ptr(), gw.data_ptr(), gb.data_ptr(), groups,
+                                                  int(silu), *tail)
+    _check(ret, "gd_nn_conv3x3_wide_forward", "gd_nn_conv_last_error")
     return y
 
 
@@ -605,7 +679,12 @@ def _gnconv_forward(x, gw, gb, groups, eps, w, bias, residual, mr=None, next_nor
             if not have_mr:
                 _check(L.gd_nn_groupnorm_stats(stream, x.data_ptr(), N, H * W, Cin, groups, float(eps), ws.data_ptr(),
                                                mr.data_ptr()), "gd_nn_groupnorm_stats")
-            ret = L.gd_nn_conv3x3_gn_forward_stats(stream, x.data_ptr(), mr.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+            if _conv_route(N, H, W, Cin, Cout, gn=True) == "wide":
+                ret = L.gd_nn_conv3x3_wide_gn_forward(stream, x.data_ptr(), mr.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                                      groups, 1, _wide(w).data_ptr(), bias_p, stride, res_p, y.data_ptr(),
+                                                      N, H, W, Cin, Cout, None if part is None else part.data_ptr())
+            else:
+                ret = L.gd_nn_conv3x3_gn_forward_stats(stream, x.data_ptr(), mr.data_ptr(), gw.data_ptr(), gb.data_ptr(),
                                                    groups, 1, w.data_ptr(), bias_p, stride, res_p, y.data_ptr(), N, H, W,
                                                    Cin, Cout, None if part is None else part.data_ptr())
             if ret < 0:
@@ -617,8 +696,16 @@ def _gnconv_forward(x, gw, gb, groups, eps, w, bias, residual, mr=None, next_nor
                                                   mr.data_ptr()), "gd_nn_groupnorm_silu_forward")
             if part is None:
                 return _conv_launch(act, w, bias, residual, Cout), mr, None
-            ret = L.gd_nn_conv3x3_forward_stats(stream, act.data_ptr(), w.data_ptr(), bias_p, stride, res_p, y.data_ptr(),
-                                                N, H, W, Cin, Cout, part.data_ptr())
+            route = _conv_route(N, H, W, Cin, Cout)
+            if route == "wino":
+                ret = L.gd_nn_conv3x3_wino_forward(stream, act.data_ptr(), _wino(w).data_ptr(), bias_p, stride, res_p,
+                                                   y.data_ptr(), N, H, W, Cin, Cout, part.data_ptr())
+            elif route == "wide":
+                ret = L.gd_nn_conv3x3_wide_forward(stream, act.data_ptr(), _wide(w).data_ptr(), bias_p, stride, res_p,
+                                                   y.data_ptr(), N, H, W, Cin, Cout, part.data_ptr())
+            else:
+                ret = L.gd_nn_conv3x3_forward_stats(stream, act.data_ptr(), w.data_ptr(), bias_p, stride, res_p, y.data_ptr(),
+                                                    N, H, W, Cin, Cout, part.data_ptr())
             if ret < 0:
                 raise RuntimeError(f"gd_nn_conv3x3_forward_stats failed ({ret}): {L.gd_nn_conv_last_error().decode()}")
         mr_next = None

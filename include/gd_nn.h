@@ -135,6 +135,21 @@ int gd_nn_conv3x3_wino_forward(void* stream, const void* x, const void* u, const
 int gd_nn_conv3x3_wino_gn_forward(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
                                   int groups, int apply_silu, const void* u, const void* bias, int bias_img_stride,
                                   const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
+/* The same stride-1 convolution on a 128-channel x (16 x 32)-pixel tile (csrc/nn_conv_wide.h), for layers whose FEW
+ * output channels (Cout <= 128 per tile) leave the 256-channel tile of gd_nn_conv3x3_forward unavailable: 48 MFMAs per
+ * wave and barrier, 0.77 KB of filter / patch LDS-DMA per MFMA.  u = the filter bank re-packed as the sequence of 24 KB
+ * LDS images the kernel streams -- per (128-channel block, ky, 32-channel chunk): [3 kx][128 rows][32 ch],
+ * gd_nn_conv3x3_wide_weights_bytes() bytes (gd_nn_conv3x3_wide_weights; cached per frozen weight by the caller, dgrad =
+ * the same kernel on the packing of the flipped weights).  Needs Cin % 32 == 0 and Cout % 8 == 0.  stat_part and the
+ * _gn_ form as for the Winograd entry points above (same partial-sum rows).  Replaces the same reference call. */
+int gd_nn_conv3x3_wide_supported(int N, int H, int W, int Cin, int Cout);
+size_t gd_nn_conv3x3_wide_weights_bytes(int Cout, int Cin);
+int gd_nn_conv3x3_wide_weights(void* stream, const void* weight, void* u, int Cout, int Cin);
+int gd_nn_conv3x3_wide_forward(void* stream, const void* x, const void* u, const void* bias, int bias_img_stride,
+                               const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
+int gd_nn_conv3x3_wide_gn_forward(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
+                                  int groups, int apply_silu, const void* u, const void* bias, int bias_img_stride,
+                                  const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
 /* ... and of the first convolution (gd_nn_conv3x3_first_forward below; Cout == 128 only, the VAE encoder's conv_in):
  * rows = gd_nn_conv3x3_first_stat_rows(N, H, W, Cin, Cout), 0 when that shape has no statistics path. */
 size_t gd_nn_conv3x3_first_stat_rows(int N, int H, int W, int Cin, int Cout);

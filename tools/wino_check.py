@@ -8,6 +8,7 @@ import torch.nn.functional as F
 sys.path.insert(0, ".")
 from garmentdreamer_amd import nn_ops
 
+WIDE = len(sys.argv) > 1 and sys.argv[1] == "wide"      # the wide-tile direct kernel (csrc/nn_conv_wide.h) instead
 torch.manual_seed(1)
 dev = "cuda"
 cl = torch.channels_last
@@ -39,7 +40,9 @@ for (N, ci, co, H, W, pib, res, gn) in CASES:
         ref = ref + (b.float()[:, :, None, None] if pib else b.float()[None, :, None, None])
         if res:
             ref = ref + r.float()
-        if gn:
+        if WIDE:
+            y = nn_ops._wide_launch(x, w, b, r, co, part, gn=(mr, gw, gb, groups, True) if gn else None)
+        elif gn:
             y = nn_ops._wino_gn_launch(x, mr, gw, gb, groups, True, w, b, r, co, part)
         else:
             y = nn_ops._wino_launch(x, w, b, r, co, part)
@@ -50,7 +53,7 @@ for (N, ci, co, H, W, pib, res, gn) in CASES:
         yq = y.float().double().view(N, co // 4, 4, H * W)
         s_ref = torch.stack([yq.sum((2, 3)), (yq * yq).sum((2, 3))], -1)
         serr = ((pp - s_ref).abs().max() / s_ref.abs().max()).item()
-        ok = err < 1.2e-2 and serr < 1e-4 and bool(torch.isfinite(part).all())
+        ok = err < (6e-3 if WIDE else 1.2e-2) and serr < 1e-4 and bool(torch.isfinite(part).all())
         bad += not ok
         print(f"N{N} {ci}->{co} {H}x{W} pib={int(pib)} res={int(res)} gn={int(gn)}: err {err:.2e}  stats err {serr:.1e}  {'ok' if ok else 'FAIL'}",
               flush=True)
