@@ -979,3 +979,85 @@ def test_linear_one_tap_gemm_matches_fp32_reference(M, K, N, res):
     err = (y - ref).abs().max().item()
     assert err <= 1e-2 * ref.abs().max().item() + 1e-2, err
     assert F.cosine_similarity(y.flatten(), ref.flatten(), dim=0).item() > 0.9999
+
+
+_WINO_WIDE_CASES = [  # N, Cin, Cout, H, W, per-image bias, residual, GroupNorm in the loader
+    (1, 32, 64, 16, 16, False, False, False), (2, 64, 128, 48, 32, True, True, False), (3, 96, 72, 40, 56, False, True, False),
+    (2, 128, 320, 64, 64, True, False, False), (1, 128, 128, 100, 36, False, False, False),
+    (8, 128, 128, 128, 128, False, True, False), (2, 64, 128, 48, 32, True, True, True), (1, 32, 64, 16, 16, False, False, True),
+    (2, 128, 128, 64, 80, False, True, True), (3, 320, 320, 32, 32, True, False, True), (2, 256, 256, 72, 40, False, False, True),
+    (40, 64, 64, 32, 32, False, True, True)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,per_image_bias,res,gn", _WINO_WIDE_CASES)
+@pytest.mark.parametrize("kernel", ["wino", "wide"])
+def test_winograd_and_wide_tile_convolutions_match_fp32_reference(kernel, N, Cin, Cout, H, W, per_image_bias, res, gn):
+    """The two round-4 forms of the stride-1 3x3 convolution (csrc/nn_conv_wino.h: Winograd F(2,3) along x;
+    csrc/nn_conv_wide.h: 128 channels x 16x32 pixels), plain and with GroupNorm+SiLU in the loader, through the C-ABI,
+    against fp32 PyTorch: ragged sizes, Cout not a multiple of 128, one K chunk, per-image bias, residual, many tiles
+    per CU -- and the GroupNorm partial sums of the epilogue against sums over the stored tensor.  Bar: the direct bf16
+    kernels' (2e-2 of scale, cos > 0.9995); the Winograd form rounds its transformed inputs once more (measured 1.4x
+    the direct kernels' error: 3.2-5.5e-3 of scale against 2.4-3.3e-3)."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(Cin * 7 + Cout + H)
+    cl = torch.channels_last
+    x = (torch.randn(N, Cin, H, W, device=DEV, generator=g) * 1.5 + 0.3).to(torch.bfloat16).contiguous(memory_format=cl)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (3 * Cin ** 0.5)).to(torch.bfloat16).contiguous(memory_format=cl)
+    b = (torch.randn(N, Cout, device=DEV, generator=g) if per_image_bias else torch.randn(Cout, device=DEV, generator=g)).to(torch.bfloat16)
+    r = torch.randn(N, Cout, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl) if res else None
+    groups = 32
+    rows = ((H + 15) // 16) * ((W + 15) // 16) * 8
+    part = torch.full((N * (Cout // 4) * rows * 2,), float("nan"), dtype=torch.float32, device=DEV)   # every row must be written
+    with torch.no_grad():
+        xin = x.float()
+        gnargs = None
+        if gn:
+            gw = (torch.randn(Cin, device=DEV, generator=g) * 0.5 + 1).to(torch.bfloat16)
+            gb = (torch.randn(Cin, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+            xin = F.silu(F.group_norm(xin, groups, gw.float(), gb.float(), 1e-6))
+            xg = x.float().reshape(N, groups, -1)
+            mr = torch.stack([xg.mean(-1), (xg.var(-1, unbiased=False) + 1e-6).rsqrt()], -1).reshape(-1).contiguous()
+            gnargs = (mr, gw, gb, groups, True)
+        ref = F.conv2d(xin, w.float(), None, padding=1)
+        ref = ref + (b.float()[:, :, None, None] if per_image_bias else b.float()[None, :, None, None])
+        if res:
+            ref = ref + r.float()
+        if kernel == "wide":
+            y = nn_ops._wide_launch(x, w, b, r, Cout, part, gn=gnargs)
+        elif gn:
+            y = nn_ops._wino_gn_launch(x, mr, gw, gb, groups, True, w, b, r, Cout, part)
+        else:
+            y = nn_ops._wino_launch(x, w, b, r, Cout, part)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=cl)
+    err = ((y.float() - ref).abs().max() / ref.abs().max()).item()
+    cos = F.cosine_similarity(y.float().flatten(), ref.flatten(), dim=0).item()
+    assert err < 2e-2 and cos > 0.9995, (err, cos)
+    assert torch.isfinite(part).all()
+    got = part.view(N, Cout // 4, rows, 2).double().sum(2)
+    yq = y.float().double().view(N, Cout // 4, 4, H * W)
+    want = torch.stack([yq.sum((2, 3)), (yq * yq).sum((2, 3))], -1)
+    assert ((got - want).abs().max() / want.abs().max()).item() < 1e-5
+
+
+def test_conv_routing_picks_the_measured_kernel_and_all_routes_agree():
+    """nn_ops._conv_route (the per-shape table of tools/wino_route_bench.py) and the three kernels behind it give the
+    same convolution: direct (GD_NN_WINO=0 behaviour), Winograd, wide tile on one shape each route serves."""
+    from garmentdreamer_amd import nn_ops
+    assert nn_ops._conv_route(8, 512, 512, 128, 128) == "wide"
+    assert nn_ops._conv_route(8, 512, 512, 128, 128, gn=True) == "wide"
+    assert nn_ops._conv_route(8, 128, 128, 512, 512) == "wino"
+    assert nn_ops._conv_route(16, 32, 32, 1280, 640) == "wide"
+    assert nn_ops._conv_route(16, 64, 64, 320, 320) == "wino"
+    assert nn_ops._conv_route(8, 256, 256, 256, 256) is None and nn_ops._conv_route(8, 256, 256, 256, 256, gn=True) is None
+    assert nn_ops._conv_route(2, 16, 16, 1280, 1280) is None          # too few tiles: split-K implicit GEMM
+    g = torch.Generator(DEV).manual_seed(5)
+    cl = torch.channels_last
+    x = torch.randn(16, 320, 64, 64, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+    w = (torch.randn(128, 320, 3, 3, device=DEV, generator=g) / 50).to(torch.bfloat16).contiguous(memory_format=cl)
+    with torch.no_grad():
+        ref = F.conv2d(x.float(), w.float(), None, padding=1)
+        ys = [nn_ops._patch_launch(x, w, None, None, 128), nn_ops._wino_launch(x, w, None, None, 128),
+              nn_ops._wide_launch(x, w, None, None, 128), nn_ops._conv_launch(x, w, None, None, 128)]
+    for y in ys:
+        assert ((y.float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
+    assert torch.equal(ys[2], ys[3])         # the router sent this shape (Cout <= 128) to the wide tile
