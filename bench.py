@@ -92,6 +92,8 @@ def parse():
                     help="e4m3 3x3 convolutions in the no-grad UNet forward (second, non-headline line: dtype says so)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="six nn.Parameters + torch.optim.Adam(fused) instead of the flat-buffer GaussianModel")
+    ap.add_argument("--nn-lib", default=None, help="A/B timing: another build of libgd_nn.so (recorded in the line's config)")
+    ap.add_argument("--raster-lib", default=None, help="A/B timing: another build of libgd_raster.so (recorded likewise)")
     ap.add_argument("--stub-step", action="store_true",
                     help="TEST ONLY (tests/test_bench_launch.py): replace the SDS iteration by one small all-reduce so the "
                          "launch / rank-accounting logic of --gpus N can be exercised on CPU over gloo; the line it prints "
@@ -378,6 +380,12 @@ def main():
     args = parse()
     launch_ranks_if_needed(args)
     _claim_stdout()
+    if args.nn_lib:
+        from garmentdreamer_amd import nn_ops as _nn
+        _nn.use_library(args.nn_lib)
+    if args.raster_lib:
+        from garmentdreamer_amd import _native as _nat
+        _nat.use_library(args.raster_lib)
     if args.stub_step:
         return stub_main(args)
     if args.cpu_baseline_only:
@@ -616,7 +624,9 @@ def main():
                        "raster_only": bool(args.raster_only), "hip_graphs": graphs_active,
                        "fp8_unet_sites": (guidance.unet.fp8.sites_run if guidance is not None and
                                           getattr(guidance.unet, "fp8", None) is not None else 0),
-                       "kernels_per_step": kernels_per_step},
+                       "kernels_per_step": kernels_per_step,
+                       "library_override": {"nn": args.nn_lib, "raster": args.raster_lib}
+                       if (args.nn_lib or args.raster_lib) else None},
             "roofline": roofline_conv if roofline_conv is not None else roofline,
             "roofline_raster_bwd": roofline,
             "raster_kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},

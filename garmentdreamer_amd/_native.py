@@ -10,9 +10,19 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GD_RASTER_LIB: optional override for A/B timing of experimental builds (tools/, never set in tests)
-_LIB_PATH = os.environ.get("GD_RASTER_LIB") or os.path.join(_HERE, "libgd_raster.so")
+_LIB_PATH = os.path.join(_HERE, "libgd_raster.so")
 _lib = None
+
+
+def use_library(path: str) -> None:
+    """Point the binding at another build of libgd_raster.so BEFORE its first use -- same-box A/B timing of experimental
+    builds by the scripts under tools/ (tools/ablib.py) and ``bench.py --raster-lib``; the package itself reads no
+    environment variable for this."""
+    global _LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("libgd_raster.so is already loaded")
+    _LIB_PATH = os.path.abspath(path)
+
 
 GD_MAX_VIEWS = 16
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

@@ -79,6 +79,8 @@ __global__ __launch_bounds__(kThreads) void linear_320_kernel(const uint16_t* __
     const int tiles_per_pass = (int)(gridDim.x / nb);
     constexpr int kOutCh = GEGLU ? kN / 2 : kN;            // output channels of a workgroup
     const int ldy = kOutCh * nb;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)y, 0, (int)(uint32_t)((size_t)M * (size_t)ldy * 2u), 0x00020000);      // < 4 GiB (gd_nn_linear_320_supported)
     // first of this wave's 32 weight rows
     const int wrow = GEGLU ? (wave < kWaves / 2 ? kOutCh * cb + 32 * wave : kOutCh * nb + kOutCh * cb + 32 * (wave - kWaves / 2))
                            : kN * cb + 32 * wave;
@@ -155,7 +157,10 @@ __global__ __launch_bounds__(kThreads) void linear_320_kernel(const uint16_t* __
 #pragma unroll
                 for (int k = 0; k < 4; k++) v[i][k] = gdnn::geglu2(v[i][k], g[i][k]);
             }
-            if (m0 + (int)st_row[i] < M) *(u32x4*)(y + (size_t)m0 * ldy + st_y[i]) = v[i];
+            // ONE buffer_store_dwordx4 per chunk by construction -- the vmcnt immediates below count instructions -- with
+            // rows beyond M sent to an out-of-range offset, which the hardware drops (no branch around the store)
+            const uint32_t so = m0 + (int)st_row[i] < M ? (uint32_t)(((size_t)m0 * ldy + st_y[i]) * 2u) : 0xfffffff0u;
+            __builtin_amdgcn_raw_buffer_store_b128(v[i], rs_y, (int)so, 0, 0);
         }
     };
 
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void linear_320_kernel(const uint16_t* __
     }
 }
 
-char g_err[256] = "";
+thread_local char g_err[256] = "";
 int fail(int code, const char* msg)
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);

@@ -223,7 +223,8 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     uint32_t num_rendered = 0;
     GD_HIP(hipMemcpyAsync(&num_rendered, geom.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GD_HIP(hipStreamSynchronize(stream));
-    if (num_rendered > 0x7fffffffu) return fail(GD_ERR_INVALID_ARG, "%s", "num_rendered exceeds int32");
+    // the compact per-strip lists index 4 * num_rendered cells with 32-bit arithmetic (raster_render.hip: my_base, rowpos)
+    if (num_rendered >= (1u << 30)) return fail(GD_ERR_INVALID_ARG, "%s", "num_rendered exceeds 2^30 (32-bit strip-list offsets)");
 
     char* bin_chunk = binning_alloc(binning_user, gd_raster_binning_bytes(num_rendered));
     if (!bin_chunk) return fail(GD_ERR_ALLOC, "%s", "binning allocator returned NULL");

@@ -38,10 +38,6 @@
 #ifndef GD_BWD_CUT
 #define GD_BWD_CUT 12     // cut a window when its fullest block list overshoots a multiple of 16 by <= this many entries (0 = never)
 #endif
-#ifndef GD_BWD_ABLATE
-#define GD_BWD_ABLATE 0   // tools/raster_ab.sh builds only (wrong results): 1 = no chunk loop, 2 = no pixel loop, 3 = no row adds,
-                          // 4 = 1 + no gathers, 5 = 1 + no row stores, 6 = 4 + 5
-#endif
 
 namespace gd {
 
@@ -177,7 +173,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const bool have = lane < nwin;
         ent_next = load_entries(w0 + nwin);
         if (have) {
-            const bool gather = !(GD_BWD_ABLATE == 4 || GD_BWD_ABLATE == 6);
+            const bool gather = true;
             const float2 xy = gather ? means2D[ent.z] : make_float2(1.f, 2.f);
             const float4 co = gather ? conic_opacity[ent.z] : make_float4(1.f, 0.f, 1.f, 0.5f);
             const float4 fd = gather ? rgbd[ent.z] : make_float4(1.f, 0.f, 1.f, 0.5f);
@@ -202,17 +198,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         __builtin_amdgcn_wave_barrier();
 
         uint32_t e_next = (li < my_n) ? s_sub[blk][li] : 0xffu;
-        for (uint32_t k0 = 0; k0 < ((GD_BWD_ABLATE == 1 || GD_BWD_ABLATE >= 4) ? 0u : nmax); k0 += 16u) {
+        for (uint32_t k0 = 0; k0 < nmax; k0 += 16u) {
             // ---- lane (block, i): entry k0 + i of the block's list; an empty lane is an entry nobody blended ----
             // an empty lane computes on entry 0 of the window (always present and finite) with an all-zero pixel mask:
             // its alpha is 0 and it adds exact zeros to both scans.  It must NOT read a table row nobody wrote -- LDS
             // left over from another workgroup can hold NaN bit patterns, and 0 * NaN would poison the row's sum scan.
             const bool filled = e_next != 0xffu;
-#ifdef GD_BWD_TEST_UNINIT_ROW       // tools/ builds only: the defect tests/test_raster_gpu.py's LDS poisoning must catch
-            const uint32_t e = e_next & 63u;
-#else
             const uint32_t e = filled ? (e_next & 63u) : 0u;
-#endif
             const float* er = &s_ent[e][0];
             const float4 r0 = reinterpret_cast<const float4*>(er)[0], r1 = reinterpret_cast<const float4*>(er)[1],
                          r2 = reinterpret_cast<const float4*>(er)[2];
@@ -240,7 +232,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             // one block row (4 pixels = 2 packed pairs) per trip; not unrolled further: the four scans of a trip and
             // the other waves of the SIMD cover the DPP latencies, and the body stays within 128 VGPRs
 #pragma unroll 1
-            for (int y = 0; y < (GD_BWD_ABLATE == 2 ? 0 : 4); y++) {
+            for (int y = 0; y < 4; y++) {
                 float dy, t2;
                 {
 #pragma clang fp contract(off)
@@ -300,7 +292,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 // the entry's table row, rows 2/3 into half 1, even rows first: two plain read-add-write turns
                 float2* dst = reinterpret_cast<float2*>(&s_acc[e][blk >> 1][0]);
 #pragma unroll 1
-                for (uint32_t turn = 0; turn < (GD_BWD_ABLATE == 3 ? 0u : 2u); turn++) {
+                for (uint32_t turn = 0; turn < 2u; turn++) {
                     if ((blk & 1u) == turn && sub != 0u) {
 #pragma unroll
                         for (int k = 0; k < 5; k++) {
@@ -315,7 +307,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         __builtin_amdgcn_wave_barrier();
         // ---- lane = entry of the window: add the two halves, store the entry's row once ----
-        if (lane < nwin && (!(GD_BWD_ABLATE == 5 || GD_BWD_ABLATE == 6) || W < 0)) {
+        if (lane < nwin) {
             float v[kAcc];
             {
                 const float2* src = reinterpret_cast<const float2*>(&s_acc[lane][0][0]);

@@ -82,7 +82,7 @@ def _lin(mod: nn.Linear, x, bias=None):
     w = mod.weight
     b = mod.bias if bias is None else bias
     if _LIN320 and x.is_cuda and not torch.is_grad_enabled() and not w.requires_grad and w.shape[1] == 320 and \
-            (b is None or b.dtype == w.dtype) and linear_320_supported(x, w):
+            linear_320_supported(x, w, b):
         return linear_320(x, w, b)
     return F.linear(x, w, b)
 
@@ -267,7 +267,7 @@ class GEGLU(nn.Module):
     def forward(self, x):
         w = self.proj.weight
         if _LIN320 and x.is_cuda and not torch.is_grad_enabled() and not w.requires_grad and tuple(w.shape) == (2560, 320) and \
-                linear_320_supported(x, w):
+                linear_320_supported(x, w, self.proj.bias):
             return linear_320_geglu(x, w, self.proj.bias)      # projection + GEGLU in one kernel (64x64-token blocks)
         return geglu(_lin(self.proj, x))   # h * gelu(gate), fused on the GPU (nn_ops.geglu)
 

@@ -398,7 +398,7 @@ class PromptEmbeddings:
             if d == 3:                                   # overhead view: no negative direction
                 pos.append(overhead)
                 neg += [u, u]
-                wts += [torch.zeros(()), torch.zeros(())]
+                wts += [torch.zeros((), device=elevation.device), torch.zeros((), device=elevation.device)]
             elif torch.abs(a) < 90:                      # front-side interpolation (0 = side, 1 = front)
                 r = 1 - torch.abs(a) / 90
                 pos.append(r * front + (1 - r) * side)

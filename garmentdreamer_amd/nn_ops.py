@@ -11,9 +11,20 @@ import torch
 import torch.nn.functional as F
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GD_NN_LIB: optional override for A/B timing of experimental builds (tools/, never set in tests)
-_LIB_PATH = os.environ.get("GD_NN_LIB") or os.path.join(_HERE, "libgd_nn.so")
+_LIB_PATH = os.path.join(_HERE, "libgd_nn.so")
+_LIB_OVERRIDDEN = False
 _lib = None
+
+
+def use_library(path: str) -> None:
+    """Point the wrappers at another build of libgd_nn.so BEFORE its first use -- same-box A/B timing of experimental
+    builds by the scripts under tools/ (tools/ablib.py) and ``bench.py --nn-lib``; the package itself reads no environment
+    variable for this.  Symbols an older build lacks are skipped at load (calling them raises)."""
+    global _LIB_PATH, _LIB_OVERRIDDEN
+    if _lib is not None:
+        raise RuntimeError("libgd_nn.so is already loaded")
+    _LIB_PATH, _LIB_OVERRIDDEN = os.path.abspath(path), True
+
 
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
@@ -98,7 +109,7 @@ def lib():
             try:
                 fn = getattr(L, name)
             except AttributeError:
-                if os.environ.get("GD_NN_LIB"):      # an older experimental build under A/B (tools/): symbol not there yet
+                if _LIB_OVERRIDDEN:      # an older experimental build under A/B (use_library): symbol not there yet
                     continue
                 raise
             fn.restype, fn.argtypes = res, args
@@ -1227,11 +1238,15 @@ def linear_supported(x, weight) -> bool:
             and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)))
 
 
-def linear_320_supported(x, weight) -> bool:
+def linear_320_supported(x, weight, bias=None) -> bool:
     """bf16 GPU rows, K = 320, N = 320 / 640 / 2560, at least 4096 rows (the 64x64-token transformer blocks at any
-    batch)."""
+    batch); x and weight 16-byte aligned (LDS-DMA / 16-byte fragment loads), bias bf16 and 8-byte aligned (uint2 loads)
+    -- a view at an odd element offset falls back to ``F.linear`` instead of being read misaligned."""
+    if bias is not None and (bias.dtype != torch.bfloat16 or not bias.is_contiguous() or bias.data_ptr() % 8):
+        return False
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous()
             and weight.is_contiguous() and weight.dim() == 2 and x.shape[-1] == weight.shape[1]
+            and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
             and bool(lib().gd_nn_linear_320_supported(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0])))
 
 

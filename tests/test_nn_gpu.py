@@ -1061,3 +1061,41 @@ def test_conv_routing_picks_the_measured_kernel_and_all_routes_agree():
     for y in ys:
         assert ((y.float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
     assert torch.equal(ys[2], ys[3])         # the router sent this shape (Cout <= 128) to the wide tile
+
+
+def test_linear_320_counted_waits_under_competing_traffic():
+    """The streaming K = 320 GEMM waits with ``s_waitcnt vmcnt(n)``, n counted per instruction (csrc/nn_linear.hip): a tile
+    consumed before its LDS-DMA landed would be off by O(1).  Many launches on fresh data, alone and with a second stream
+    keeping HBM busy, every element checked (the suite-resident form of tools/linear320_stress.py)."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(0)
+    side = torch.cuda.Stream()
+    big = torch.randn(32 * 1024 * 1024, device=DEV)
+    for it in range(48):
+        M = [65536, 16384, 4096 + 32 * (it % 7) + (it % 3), 32768][it % 4]
+        N = [320, 640, 2560][it % 3]
+        x = torch.randn(M, 320, device=DEV, generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, 320, device=DEV, generator=g) / 18).to(torch.bfloat16)
+        b = torch.randn(N, device=DEV, generator=g).to(torch.bfloat16)
+        if it % 2:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    big.mul_(1.0001)
+        y = nn_ops.linear_320(x, w, b)
+        ref = F.linear(x.float(), w.float(), b.float())
+        assert bool(((y.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-5).all()), (it, M, N)
+        if N == 2560:
+            assert torch.equal(nn_ops.linear_320_geglu(x, w, b), nn_ops.geglu(y))
+    torch.cuda.synchronize()
+
+
+def test_linear_320_dispatch_refuses_misaligned_views():
+    from garmentdreamer_amd import nn_ops
+    x = torch.randn(4096, 320, device=DEV).to(torch.bfloat16)
+    w = torch.randn(320, 320, device=DEV).to(torch.bfloat16)
+    b = torch.randn(324, device=DEV).to(torch.bfloat16)
+    assert nn_ops.linear_320_supported(x, w, b[:320])
+    assert not nn_ops.linear_320_supported(x, w, b[1:321])                          # bias at an odd element offset
+    assert not nn_ops.linear_320_supported(x, w, b[:320].float())                   # fp32 bias
+    wbuf = torch.randn(320 * 320 + 8, device=DEV).to(torch.bfloat16)
+    assert not nn_ops.linear_320_supported(x, wbuf[1:1 + 320 * 320].view(320, 320))  # weight 2 bytes off a 16-byte boundary

@@ -4,6 +4,7 @@ oracle: tools/, not product)."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from tests import helpers as h
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 100000

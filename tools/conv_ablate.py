@@ -6,6 +6,7 @@ import sys
 import time
 import torch
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 
 SH = [(8, 512, 512, 128, 2), (8, 256, 256, 256, 2), (8, 128, 128, 512, 1), (16, 1280, 1280, 16, 0), (16, 640, 640, 32, 0),

@@ -5,6 +5,7 @@ import time
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd.nn_ops import conv3x3
 
 # (N, Cin, Cout, HW, launches per SDS step at V=8: UNet batch 16 forward; VAE batch 8 forward + dgrad)

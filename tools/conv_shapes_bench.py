@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd.guidance import sd21  # noqa
 
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 8

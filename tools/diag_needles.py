@@ -2,6 +2,7 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from tests import helpers as h
 from tests.test_raster_gpu import _needle_inputs, _run_gpu_forward, DEV
 from garmentdreamer_amd.diff_gaussian_rasterization import _C

@@ -1,6 +1,7 @@
 import sys, time, torch
 import torch.nn.functional as F
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 cl = torch.channels_last
 x = torch.rand(8, 3, 512, 512, device="cuda").to(torch.bfloat16).contiguous(memory_format=cl)

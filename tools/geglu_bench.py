@@ -1,5 +1,6 @@
 import sys, time, torch
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 import torch.nn.functional as F
 x = (torch.randn(65536, 2560, device="cuda") * 2).to(torch.bfloat16)

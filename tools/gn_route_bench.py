@@ -3,6 +3,7 @@
 direct patch kernel vs Winograd vs wide tile."""
 import sys, time, torch
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 SH = [(V, 128, 128, 512, 1), (V, 128, 128, 512, 0), (V, 128, 256, 256, 0), (V, 256, 256, 256, 1), (V, 256, 256, 256, 0)]

@@ -4,6 +4,7 @@ import time
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 
 DEV = "cuda:0"

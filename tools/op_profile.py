@@ -9,6 +9,7 @@ import torch
 from torch.profiler import ProfilerActivity, profile
 
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 import bench  # noqa: E402
 from garmentdreamer_amd import _native  # noqa: E402
 from garmentdreamer_amd.guidance.stable_diffusion_guidance import PromptEmbeddings, StableDiffusionGuidance  # noqa

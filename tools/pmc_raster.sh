@@ -10,7 +10,7 @@ for g in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES" \
          "FETCH_SIZE" "WRITE_SIZE"; do
   rm -rf /tmp/pmcr_$i
-  rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmcr_$i -o pmc -- python bench.py --raster-only --no-cpu-baseline --steps 3 --warmup 1 > /tmp/pmcr_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmcr_$i -o pmc -- python bench.py ${GD_RASTER_LIB:+--raster-lib $GD_RASTER_LIB} --raster-only --no-cpu-baseline --steps 3 --warmup 1 > /tmp/pmcr_$i.log 2>&1
   python - /tmp/pmcr_$i >> $out <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(float); cnt = collections.Counter()

@@ -6,7 +6,7 @@
 cd $(dirname $0)/..
 if [ "$1" == "build" ]; then
   mkdir -p ablate
-  for v in ${VARIANTS:-"abl1:-DGD_BWD_ABLATE=1" "abl2:-DGD_BWD_ABLATE=2" "abl3:-DGD_BWD_ABLATE=3"}; do
+  for v in ${VARIANTS:-"cut0:-DGD_BWD_CUT=0" "cut8:-DGD_BWD_CUT=8"}; do
     name=${v%%:*}; flags=${v#*:}
     python - "$name" $flags <<'PY'
 import sys, os, subprocess
@@ -25,7 +25,7 @@ PY
   exit 0
 fi
 for so in "" ablate/libgd_raster_*.so; do
-  GD_RASTER_LIB=${so:+$PWD/$so} timeout 300 python bench.py --raster-only --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "
+  timeout 300 python bench.py ${so:+--raster-lib $PWD/$so} --raster-only --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "
 import sys,json
 try:
     d=json.loads(sys.stdin.read()); r=d['raster_kernels_ms_per_step']; print('${so:-product}', ' '.join('%s %.4f' % (k, v) for k, v in r.items()), 'frac %.4f' % d['roofline_raster_bwd']['frac'])

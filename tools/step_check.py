@@ -5,6 +5,7 @@ import argparse
 import sys
 import torch
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 import bench  # noqa: E402
 from garmentdreamer_amd.gaussian_model import GaussianModel  # noqa: E402
 from garmentdreamer_amd.guidance.stable_diffusion_guidance import PromptEmbeddings, StableDiffusionGuidance  # noqa: E402

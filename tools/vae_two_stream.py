@@ -4,6 +4,7 @@ import sys
 import time
 import torch
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd.guidance import sd21
 
 dev = "cuda:0"

@@ -6,6 +6,7 @@ import sys
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 
 WIDE = len(sys.argv) > 1 and sys.argv[1] == "wide"      # the wide-tile direct kernel (csrc/nn_conv_wide.h) instead

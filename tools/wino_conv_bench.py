@@ -5,6 +5,7 @@ import time
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 
 SH = [(8, 128, 128, 512), (8, 128, 256, 256), (8, 256, 256, 256), (8, 256, 512, 128), (8, 512, 512, 128), (8, 512, 512, 64),

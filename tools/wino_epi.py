@@ -2,6 +2,7 @@
 """Epilogue cost of the Winograd kernel: 128->128 @512 with / without bias, residual, statistics."""
 import sys, time, torch
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 N, ci, co, hw = 8, 128, 128, 512
 if len(sys.argv) > 4:

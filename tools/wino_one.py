@@ -3,6 +3,7 @@
 import sys
 import torch
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 N, ci, co, hw = (int(a) for a in sys.argv[1:5])
 which = sys.argv[5]

@@ -8,6 +8,7 @@ import time
 os.environ["GD_NN_WINO"] = "0"
 import torch
 sys.path.insert(0, ".")
+import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 from garmentdreamer_amd import nn_ops
 
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 8
