@@ -19,3 +19,9 @@ def vae_mean(imgs):
     """Posterior mean of the stub encoder for a [B,3,512,512] image in [-1, 1]: 8x average pooling + a 3 -> 4 channel mix."""
     m = torch.nn.functional.avg_pool2d(imgs.float(), 8)
     return torch.einsum("oc,bchw->bohw", _MIX.to(m), m).to(imgs.dtype)
+
+
+def q_unet_fn(x, t, ctx, pose, shading):
+    """Stand-in for the pose-conditioned LoRA UNet of the NeTF stage (v-prediction output)."""
+    s = {"albedo": 1.0, "normal": 0.5, "textureless": 0.25}.get(shading, 2.0)
+    return (0.6 * unet_fn(x, t, ctx).float() - 0.1 * x.float() + 0.05 * s * pose.float().mean(dim=1).view(-1, 1, 1, 1)).to(x.dtype)

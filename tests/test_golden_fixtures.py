@@ -251,3 +251,36 @@ def test_direction_rules_match_the_reference_prompt_processor():
     el, az = torch.from_numpy(z["dir/elevation"]), torch.from_numpy(z["dir/azimuth"])
     got = p.get_text_embeddings(el, az, torch.ones_like(el))[: el.numel(), 0, 0].long().tolist()
     assert got == z["dir/index"].tolist()
+
+
+def test_vsd_train_step_reproduces_the_reference_train_step():
+    """NeTF-stage ``StableDiffusion.train_step`` (sd_vsd_utils.py:131-218: noise injection, classifier-free combination
+    of the frozen UNet, v -> eps of the LoRA UNet's output, w(t), ``SpecifyGradient`` and its 1 / batch backward, the
+    pseudo loss; t5 annealing and direction-dependent embeddings) against outputs of the reference's own function run on
+    the stub networks of tests/golden/stub_nets.py with the same timestep and noise (tests/golden/make_golden_vsd.py)."""
+    from garmentdreamer_amd.guidance.sd_vsd import StableDiffusionVSD
+    from tests.golden import stub_nets
+    z = np.load(os.path.join(G, "vsd_pins.npz"))
+    for k in range(3):
+        p = f"case{k}/"
+        lo, hi, scale, t5, hor = (float(v) for v in z[p + "cfg"])
+        gd = StableDiffusionVSD("cpu", fp16=False, t_range=(lo, hi), unet=_PinUNet(), vae=_PinVAE())
+        assert (gd.min_step, gd.max_step) == (int(1000 * lo), int(1000 * hi))
+        gd.set_text_embeds(*(torch.from_numpy(z[p + "emb_" + n]) for n in ("pos", "neg", "front", "side", "back")))
+        pose = torch.from_numpy(z[p + "pose"])
+        shading = str(z[p + "shading"])
+        # the stub VAE sees the image through 8 x 8 average pooling only: a blocky image with the stored block means
+        img = torch.from_numpy(z[p + "rgb_pooled"]).repeat_interleave(8, 2).repeat_interleave(8, 3).clone().requires_grad_(True)
+        q = lambda x, t, text, c=None, shading=None: stub_nets.q_unet_fn(x, t, text, c, shading)    # noqa: E731
+        noise = torch.from_numpy(z[p + "noise"])
+        loss, pseudo, latents = gd.train_step(img, guidance_scale=scale, q_unet=q, pose=pose, shading=shading, t5=bool(t5),
+                                              hors=None if hor < 0 else [hor], noise=noise, timesteps=torch.from_numpy(z[p + "t"]),
+                                              vae_noise=torch.zeros_like(noise))
+        loss.backward()
+        assert torch.allclose(latents.detach(), torch.from_numpy(z[p + "latents"]), rtol=1e-5, atol=1e-6)
+        ref_loss, ref_pseudo = float(z[p + "loss"]), float(z[p + "pseudo_loss"])
+        assert abs(loss.item() - ref_loss) <= 3e-5 * abs(ref_loss) + 1e-3, (k, loss.item(), ref_loss)
+        assert abs(pseudo.item() - ref_pseudo) <= 1e-4 * abs(ref_pseudo) + 1e-4, (k, pseudo.item(), ref_pseudo)
+        blk = img.grad.view(1, 3, 64, 8, 64, 8)[:, :, :, 0, :, 0].numpy()
+        ref_blk = z[p + "dloss_drgb_block"]
+        assert np.abs(blk - ref_blk).max() <= 5e-5 * np.abs(ref_blk).max(), k
