@@ -91,3 +91,20 @@ def poison_lds():
     L = _native.lib()
     with torch.cuda.device(0):
         assert L.gd_raster_poison_lds(torch.cuda.current_stream().cuda_stream) == 0
+
+
+def needle_inputs(P, HW, seed):
+    """Strongly anisotropic splats (axis ratio up to ~60:1, random orientation) with opacities down to the
+    1/255 threshold: the hard case for the render kernels' per-strip reachability test (a needle that
+    crosses a 16x4 strip diagonally, or clips its corner, must not be dropped)."""
+    inp = raster_inputs(P=P, H=HW, W=HW, seed=seed, scale_mul=1.0)
+    rng = np.random.default_rng(seed)
+    sc = inp["scales"].copy()
+    sc[:, 0] *= rng.uniform(5.0, 30.0, size=P).astype(np.float32)
+    sc[:, 1] *= rng.uniform(0.5, 2.0, size=P).astype(np.float32)
+    sc[:, 2] *= rng.uniform(0.3, 1.0, size=P).astype(np.float32)
+    inp["scales"] = sc
+    op = inp["opacities"].copy()
+    op[: P // 4] = rng.uniform(0.002, 0.02, size=(P // 4, 1)).astype(np.float32)   # around and below 1/255
+    inp["opacities"] = op
+    return inp

@@ -299,3 +299,27 @@ def test_defined_blend_exp_agrees_with_the_c_library_exp_end_to_end():
     for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drotations"):
         s = np.abs(gb_[k]).max()
         assert np.abs(ga_[k] - gb_[k]).max() <= 2e-3 * s, k
+
+
+def test_needle_gradients_are_conditioned_on_the_exponential():
+    """the GPU backward deviates from the oracle by up to 6e-3 * max|ref| on dL_dscales /
+    dL_drotations of 60:1 needles -- kernel defect or conditioning?  Settled without any GPU code: the ORACLE, run on
+    the same needle inputs with two valid exponentials < 1 ulp apart (its defined gd_expf and the C library's expf),
+    moves those tensors by the same amount, while the blend's own sums (colour, opacity, 2-D mean) and dL_dcov3D move
+    100x less.  The GPU test's bar for the amplified chain (tests/test_raster_gpu.py) is twice what is measured here."""
+    inp = h.needle_inputs(20000, 256, 12)
+    a = h.oracle_forward(inp)
+    b = gd_oracle.forward(inp["bg"], inp["means3D"], inp["colors_precomp"], inp["opacities"], inp["scales"],
+                          inp["rotations"], inp["scale_modifier"], inp["cov3D_precomp"], inp["viewmatrix"],
+                          inp["projmatrix"], inp["tanfovx"], inp["tanfovy"], inp["image_height"], inp["image_width"],
+                          inp["sh"], inp["degree"], inp["campos"], omp="libm")
+    assert np.mean(a.n_contrib != b.n_contrib) < 2e-3
+    gc, gd, ga = h.random_image_grads(256, 256, seed=12)
+    ga_, gb_ = gd_oracle.backward(a, gc, gd, ga), gd_oracle.backward(b, gc, gd, ga)
+    d = {k: float(np.abs(ga_[k] - gb_[k]).max() / np.abs(gb_[k]).max()) for k in ga_ if k in gb_ and gb_[k] is not None
+         and np.size(gb_[k])}
+    # amplified chain: moved by the exponential alone at the 1e-3 .. 1e-2 level (measured 5.6e-3 / 6.7e-3 / 2.2e-3)
+    assert 1e-3 < d["dL_dscales"] < 7e-3 and 1e-3 < d["dL_drotations"] < 7e-3 and 5e-4 < d["dL_dmeans3D"] < 7e-3, d
+    # the blend's own sums and the 3-D covariance gradient: 10 .. 100x less
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D"):
+        assert d[k] < 6e-4, (k, d[k])

@@ -183,21 +183,7 @@ def test_backward_long_lists_saturated_pixels():
     assert st.num_rendered > 20 * 4000 / 4 and (st.n_contrib > 64).mean() > 0.2
 
 
-def _needle_inputs(P, HW, seed):
-    """Strongly anisotropic splats (axis ratio up to ~60:1, random orientation) with opacities down to the
-    1/255 threshold: the hard case for the render kernels' per-strip reachability test (a needle that
-    crosses a 16x4 strip diagonally, or clips its corner, must not be dropped)."""
-    inp = h.raster_inputs(P=P, H=HW, W=HW, seed=seed, scale_mul=1.0)
-    rng = np.random.default_rng(seed)
-    sc = inp["scales"].copy()
-    sc[:, 0] *= rng.uniform(5.0, 30.0, size=P).astype(np.float32)
-    sc[:, 1] *= rng.uniform(0.5, 2.0, size=P).astype(np.float32)
-    sc[:, 2] *= rng.uniform(0.3, 1.0, size=P).astype(np.float32)
-    inp["scales"] = sc
-    op = inp["opacities"].copy()
-    op[: P // 4] = rng.uniform(0.002, 0.02, size=(P // 4, 1)).astype(np.float32)   # around and below 1/255
-    inp["opacities"] = op
-    return inp
+_needle_inputs = h.needle_inputs
 
 
 @pytest.mark.parametrize("P,HW,seed", [(3000, 128, 11), (20000, 256, 12)])
@@ -223,9 +209,13 @@ def test_strip_culling_needles_forward_and_backward(P, HW, seed):
              "dL_drotations")
     # Needles are ill-conditioned in fp32: power = -0.5 (a dx^2 + c dy^2) - b dx dy cancels terms of ~1e4 down to
     # O(1), so G = exp(power) carries rounding that depends on the exp implementation (v_exp_f32 in the backward
-    # kernel, gd_expf in the oracle); the preprocess-backward chain (cov2D -> cov3D -> scales / rotations) amplifies it
-    # for 60:1 needles (measured: up to 3.2e-3 * max|ref| on dL_dscales at 20k Gaussians).  All eight tensors are checked; the blend's
-    # own sums are within 4.7e-6 * max|ref|.
+    # kernel, gd_expf in the oracle), and the preprocess-backward chain (cov2D -> cov3D -> scales / rotations) amplifies
+    # it for 60:1 needles.  That this is conditioning and not the kernel is MEASURED on the CPU, with no GPU code in the
+    # loop (tests/test_oracle_kat.py::test_needle_gradients_are_conditioned_on_the_exponential): the oracle run on two
+    # valid exponentials < 1 ulp apart (gd_expf, the C library's expf) moves dL_dscales / dL_drotations / dL_dmeans3D by
+    # 5.6e-3 / 6.7e-3 / 2.2e-3 of max|ref| on these very inputs (20k Gaussians) -- the GPU deviates by 6.2e-3 / 6.0e-3 /
+    # 1.5e-3.  The bar for that chain is twice the measured oracle-to-oracle distance; the blend's own sums (not
+    # amplified) keep the tight bar and are within 4.7e-6 * max|ref|.
     for n, g in zip(names, grads):
         blend_sum = n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dsh")
         if blend_sum:
@@ -233,7 +223,7 @@ def test_strip_culling_needles_forward_and_backward(P, HW, seed):
         else:
             # single elements of the amplified chain deviate by up to ~1e-2 * max|ref| (one needle in 20 000); the
             # tensors as a whole agree to 1e-6 in direction
-            _check_grads(n, g, ref[n], rtol=2e-2, atol_scale=2e-2, case=f"needles P={P} {HW}^2")
+            _check_grads(n, g, ref[n], rtol=2e-2, atol_scale=1.4e-2, case=f"needles P={P} {HW}^2")
             a, b = g.detach().cpu().double().flatten(), torch.as_tensor(ref[n]).double().flatten()
             assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99999, n
     # the backward pass is atomic-free: same inputs -> the same bits
