@@ -107,6 +107,7 @@ GeomState carve_geom(char* chunk, size_t VP, size_t* used)
     obtain(p, g.tiles_touched, VP);
     obtain(p, g.point_offsets, VP);
     obtain(p, g.block_sums, (VP + kGaussBlock - 1) / kGaussBlock + 1);
+    obtain(p, g.alpha_thr, VP);
     if (used) *used = (size_t)(p - chunk);
     return g;
 }

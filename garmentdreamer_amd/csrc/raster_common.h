@@ -33,6 +33,8 @@ struct GeomState {
     uint32_t* tiles_touched;  // [VP]
     uint32_t* point_offsets;  // [VP] inclusive scan of tiles_touched
     uint32_t* block_sums;     // [ceil(VP/256) + 1] exclusive-scanned block totals, last = R
+    float* alpha_thr;         // [VP] smallest exponent with alpha >= 1/255 for this opacity (raster_blend_math.h); written for
+                              // visible Gaussians only, last so that the offsets of the fields above are unchanged
 };
 struct ImageState {
     uint2* ranges;        // [V*tiles]

@@ -17,6 +17,7 @@
 //
 // Matrix helper mirrors GLM's column-major mat3 (m[c][r]) including evaluation order.
 #include "raster_common.h"
+#include "raster_blend_math.h"
 
 namespace gd {
 
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(kGaussBlock) void preprocess_kernel(
             my_r = (int)my_radius;
             gs.means2D[vp] = make_float2(px, py);
             gs.conic_opacity[vp] = make_float4(conic[0], conic[1], conic[2], opacities[g]);
+            gs.alpha_thr[vp] = alpha_threshold_exact(opacities[g]);     // the blend's contribution test, once per Gaussian
             gs.rgbd[vp] = make_float4(rgb[0], rgb[1], rgb[2], p_view[2]);
             touched = (y1 - y0) * (x1 - x0);
         } while (false);

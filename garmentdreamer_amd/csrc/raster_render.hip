@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "raster_common.h"
+#include "raster_blend_math.h"
 
 
 namespace gd {
@@ -40,26 +41,6 @@ __device__ __forceinline__ uint32_t block_to_tile(uint32_t b, uint32_t n)
     return b;
 }
 
-// Single, separately rounded fp32 operations.  (HIP's __fmul_rn / __fadd_rn are ordinary inline functions compiled
-// with the default fast contraction: after inlining the compiler still fuses them into FMAs -- measured: 7 % of the
-// pixels of a forward pass differed from the oracle by one ulp.  Operators written under `fp contract(off)` carry no
-// contraction licence.)
-__device__ __forceinline__ float mul_rn(float a, float b)
-{
-#pragma clang fp contract(off)
-    return a * b;
-}
-__device__ __forceinline__ float add_rn(float a, float b)
-{
-#pragma clang fp contract(off)
-    return a + b;
-}
-__device__ __forceinline__ float sub_rn(float a, float b)
-{
-#pragma clang fp contract(off)
-    return a - b;
-}
-
 // power = -0.5 (a dx^2 + c dy^2) - b dx dy in EXACTLY the reference's evaluation order, every operation rounded
 // on its own (forward.cu:341 / backward.cu:528 as the oracle compiles them, no FMA contraction): the forward
 // blend, the backward blend and the oracle then agree on the bits of `power`, hence on which (pixel, Gaussian)
@@ -72,50 +53,6 @@ __device__ __forceinline__ float power_exact(const float t1, const float bdx, co
     const float t2 = mul_rn(mul_rn(c, dy), dy);
     const float s = add_rn(t1, t2);
     return fmaf(-0.5f, s, -mul_rn(bdx, dy));
-}
-
-// exp of the blend, defined operation by operation (oracle/gd_oracle.c gd_expf: Cody-Waite reduction + Cephes degree-5
-// polynomial, every step one correctly rounded fp32 operation): the forward pass then reproduces the oracle BIT FOR BIT
-// -- the blended pairs, n_contrib, the pixels and the alpha image whose complement is the backward pass's T_final.
-__device__ __forceinline__ float gd_expf(float x)
-{
-#pragma clang fp contract(off)
-    if (x < -87.0f) return 0.0f;
-    const float n = rintf(mul_rn(x, 1.44269504088896341f));
-    float r = __fmaf_rn(n, -0.693359375f, x);
-    r = __fmaf_rn(n, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = __fmaf_rn(p, r, 1.3981999507e-3f);
-    p = __fmaf_rn(p, r, 8.3334519073e-3f);
-    p = __fmaf_rn(p, r, 4.1665795894e-2f);
-    p = __fmaf_rn(p, r, 1.6666665459e-1f);
-    p = __fmaf_rn(p, r, 5.0000001201e-1f);
-    p = __fmaf_rn(p, mul_rn(r, r), r);
-    p = add_rn(p, 1.0f);
-    return ldexpf(p, (int)n);
-}
-
-// Smallest fp32 exponent p with  !(min(0.99, o * expf(p)) < 1/255): `power >= thr` is then the forward pass's
-// contribution test itself (forward.cu:346-348), decided without evaluating the exponential per pair.
-// A few accurate expf per STAGED entry (once per tile and entry).
-__device__ __forceinline__ float alpha_threshold_exact(const float o)
-{
-#pragma clang fp contract(off)
-    const float k = 1.0f / 255.0f;
-    float t = -logf(255.0f * o);
-    if (!(o > 0.0f) || !isfinite(t)) return INFINITY;     // opacity 0 (or NaN): nothing ever contributes
-#pragma unroll 1
-    for (int it = 0; it < 8; it++) {      // walk down while the next lower exponent still passes
-        const float d = nextafterf(t, -INFINITY);
-        if (fminf(0.99f, mul_rn(o, gd_expf(d))) < k) break;
-        t = d;
-    }
-#pragma unroll 1
-    for (int it = 0; it < 16; it++) {     // walk up while this exponent fails
-        if (!(fminf(0.99f, mul_rn(o, gd_expf(t))) < k)) break;
-        t = nextafterf(t, INFINITY);
-    }
-    return t;
 }
 
 // Which of the tile's four 16x4 pixel strips can an entry reach?  Bit s is CLEAR only if the minimum of the
@@ -161,7 +98,8 @@ __device__ __forceinline__ uint32_t strip_alive_mask(const float2 xy, const floa
 __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     int W, int H, uint32_t gx, uint32_t gy, uint32_t tiles_total, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
-    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd, const float* __restrict__ bg_color,
+    const float4* __restrict__ conic_opacity, const float* __restrict__ alpha_thr, const float4* __restrict__ rgbd,
+    const float* __restrict__ bg_color,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     uint32_t* __restrict__ n_contrib, uint2* __restrict__ pair_counts, const uint32_t* __restrict__ slot_of,
     uint4* __restrict__ clist, uint32_t* __restrict__ strip_count, uint32_t* __restrict__ rowpos)
@@ -173,6 +111,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     __shared__ float4 s_fd[kTilePix];
     __shared__ float s_thr[kTilePix];   // ln(1/(255 opacity)) - margin: below it alpha < 1/255 for certain
     __shared__ uint32_t s_mask[kTilePix];  // strip_alive_mask per staged entry (0 beyond the list end)
+    __shared__ __attribute__((aligned(4))) uint8_t s_idx[4][68];   // per wave: compact list of the current 64 entries it must walk
 
     const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
     const uint32_t tpv = gx * gy;
@@ -222,7 +161,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
             s_xy[tid] = xy;
             const float4 c4 = conic_opacity[id];
             s_co[tid] = make_float4(c4.x, c4.z, c4.y, c4.w);     // (a, c | b, opacity): a|c pairs with dx|dy
-            const float thr = alpha_threshold_exact(c4.w);
+            const float thr = alpha_thr[id];          // alpha_threshold_exact(opacity), from preprocess_kernel
             s_thr[tid] = thr;
             s_fd[tid] = rgbd[id];
             alive = strip_alive_mask(xy, c4, -thr + 1e-2f + 1e-3f * fabsf(thr), tile_x0, tile_y0);
@@ -233,28 +172,38 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
         const uint32_t cbase = (uint32_t)i * kTilePix;
         bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;
         for (int c = 0; wave_live && c < n; c += 64) {
-            // 64 entries' strip bits -> one scalar bitmap of the entries this wave must look at
-            uint64_t bits = __builtin_amdgcn_ballot_w64(((s_mask[c + lane] >> wave) & 1u) != 0);
+            // 64 entries' strip bits -> the COMPACT list of the entries this wave must look at, in list order: lane l with
+            // its bit set writes l at its rank.  The walk below then needs no scalar bit arithmetic per entry (find-first,
+            // clear-lowest, 64-bit compares: the kernel issued as many SALU as VALU instructions, and a CU issues one SALU
+            // instruction per cycle for all its waves) -- one broadcast LDS read hands it four indices at a time; up to three
+            // sentinel indices (64) pad the last group: they blend nothing (threshold +inf) and match no lane.
+            const uint64_t bits = __builtin_amdgcn_ballot_w64(((s_mask[c + lane] >> wave) & 1u) != 0);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(bits);
+            if ((bits >> lane) & 1ull)
+                s_idx[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u))] = (uint8_t)lane;
+            if (lane < 3u) s_idx[wave][cnt + lane] = 64;
             // lane l collects, for list entry c + l, the ballot of the strip's pixels that BLEND it: the backward pass
-            // walks exactly these (pixel, entry) pairs (ballots[list position][strip]; zero = nobody, also for the
-            // entries the strip culling or an early exit never looked at)
+            // walks exactly these (pixel, entry) pairs (zero = nobody, also for the entries the strip culling or an early
+            // exit never looked at)
             uint32_t wb_lo = 0, wb_hi = 0;
-            while (bits) {
-                const int jl = (int)__builtin_ctzll(bits);
-                const int j = c + jl;
-                bits &= bits - 1;
-                bool blend = false;
-                if (!done) {
-                    const float2 xy = s_xy[j];
-                    const float4 co = s_co[j];                       // a, c, b, opacity
-                    const f2 d = f2{xy.x, xy.y} - pixf;               // (dx, dy)
-                    const f2 t12 = (f2{co.x, co.y} * d) * d;          // ((a dx) dx, (c dy) dy), forward.cu:341's order
-                    const float power = fmaf(-0.5f, add_rn(t12.x, t12.y), -mul_rn(mul_rn(co.z, d.x), d.y));
-                    // alpha >= 1/255  <=>  power >= s_thr (exact, alpha_threshold_exact): only contributing pairs pay
-                    // for the exponential
-                    if (!(power > 0.0f) && !(power < s_thr[j])) {
-                        const float alpha = fminf(0.99f, mul_rn(co.w, gd_expf(power)));
-                        {
+            for (uint32_t k = 0; k < cnt; k += 4u) {
+                const uint32_t packed = *(const uint32_t*)&s_idx[wave][k];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t jl = (packed >> (8 * u)) & 0xffu;
+                    const int j = c + (int)(jl & 63u);
+                    bool blend = false;
+                    if (!done) {
+                        const float2 xy = s_xy[j];
+                        const float4 co = s_co[j];                       // a, c, b, opacity
+                        const float thr = jl < 64u ? s_thr[j] : INFINITY;
+                        const f2 d = f2{xy.x, xy.y} - pixf;               // (dx, dy)
+                        const f2 t12 = (f2{co.x, co.y} * d) * d;          // ((a dx) dx, (c dy) dy), forward.cu:341's order
+                        const float power = fmaf(-0.5f, add_rn(t12.x, t12.y), -mul_rn(mul_rn(co.z, d.x), d.y));
+                        // alpha >= 1/255  <=>  power >= thr (exact, alpha_threshold_exact): only contributing pairs pay for
+                        // the exponential
+                        if (!(power > 0.0f) && !(power < thr)) {
+                            const float alpha = fminf(0.99f, mul_rn(co.w, gd_expf(power)));
                             // the oracle's operations, each rounded on its own (forward.cu:349-363 without contraction)
                             const float test_T = mul_rn(T, sub_rn(1.0f, alpha));
                             if (test_T < 0.0001f) {
@@ -272,12 +221,12 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
                             }
                         }
                     }
+                    const uint64_t bal = __builtin_amdgcn_ballot_w64(blend);
+                    const bool mine = lane == jl;
+                    wb_lo = mine ? (uint32_t)bal : wb_lo;
+                    wb_hi = mine ? (uint32_t)(bal >> 32) : wb_hi;
                 }
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(blend);
-                const bool mine = (int)lane == jl;
-                wb_lo = mine ? (uint32_t)bal : wb_lo;
-                wb_hi = mine ? (uint32_t)(bal >> 32) : wb_hi;
-                if (__builtin_amdgcn_ballot_w64(!done) == 0) {
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) {      // every pixel of the strip has saturated
                     wave_live = false;
                     break;
                 }
@@ -328,7 +277,7 @@ void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int 
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
     hipLaunchKernelGGL(render_forward_kernel, dim3(tiles_total), dim3(kTilePix), 0, s, W, H, (uint32_t)tiles_x,
-                       (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D, g.conic_opacity, g.rgbd, bg,
+                       (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D, g.conic_opacity, g.alpha_thr, g.rgbd, bg,
                        out_color, out_depth, out_alpha, n_contrib, pair_counts, slot_of, clist, strip_count, rowpos);
 }
 
