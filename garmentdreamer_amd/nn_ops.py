@@ -235,10 +235,11 @@ def _conv_route(N, H, W, Cin, Cout, gn=False):
         return None
     tiles_n = (Cout + 127) // 128
     if Cout <= 128 and (not gn or Cin <= 128) or (not gn and Cout == 640 and W == 32 and Cin >= 320):
-        if N * ((H + 15) // 16) * ((W + 31) // 32) * tiles_n >= 128 and lib().gd_nn_conv3x3_wide_supported(N, H, W, Cin, Cout):
+        # (the wide tile needs a fuller grid than the Winograd one: 256 -> 128 @ 256^2 at ONE image, 128 tiles, 0.72x)
+        if N * ((H + 15) // 16) * ((W + 31) // 32) * tiles_n >= (256 if Cout <= 128 else 160) and \
+                lib().gd_nn_conv3x3_wide_supported(N, H, W, Cin, Cout):
             return "wide"
-        return None
-    if gn or Cin < 320:
+    if gn or (Cin < 320 and Cout > 128):
         return None
     if N * ((H + 15) // 16) * ((W + 15) // 16) * tiles_n >= 128 and lib().gd_nn_conv3x3_wino_supported(N, H, W, Cin, Cout):
         return "wino"

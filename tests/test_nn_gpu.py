@@ -1046,7 +1046,7 @@ def test_conv_routing_picks_the_measured_kernel_and_all_routes_agree():
     assert nn_ops._conv_route(8, 512, 512, 128, 128) == "wide"
     assert nn_ops._conv_route(8, 512, 512, 128, 128, gn=True) == "wide"
     assert nn_ops._conv_route(8, 128, 128, 512, 512) == "wino"
-    assert nn_ops._conv_route(16, 32, 32, 1280, 640) == "wide"
+    assert nn_ops._conv_route(16, 32, 32, 1280, 640) == "wide" and nn_ops._conv_route(8, 32, 32, 1280, 640) == "wino"
     assert nn_ops._conv_route(16, 64, 64, 320, 320) == "wino"
     assert nn_ops._conv_route(8, 256, 256, 256, 256) is None and nn_ops._conv_route(8, 256, 256, 256, 256, gn=True) is None
     assert nn_ops._conv_route(2, 16, 16, 1280, 1280) is None          # too few tiles: split-K implicit GEMM
@@ -1060,7 +1060,7 @@ def test_conv_routing_picks_the_measured_kernel_and_all_routes_agree():
               nn_ops._wide_launch(x, w, None, None, 128), nn_ops._conv_launch(x, w, None, None, 128)]
     for y in ys:
         assert ((y.float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
-    assert torch.equal(ys[2], ys[3])         # the router sent this shape (Cout <= 128) to the wide tile
+    assert torch.equal(ys[1], ys[3])         # 128 wide tiles are too few: the router sent this shape to the Winograd kernel
 
 
 def test_linear_320_counted_waits_under_competing_traffic():
