@@ -522,16 +522,19 @@ def main():
         ach = conv_flops / (conv_ms * 1e-3) / 1e12
         roofline_conv = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "conv3x3_nhwc_bf16_kernel + conv3x3_gn_patch_kernel + conv3x3_patch_stream_kernel",
+                         "kernel": ("conv3x3 family: conv3x3_wino_kernel (Winograd F(2,3) along x) + conv3x3_wide_kernel (128 ch x "
+                                    "16x32 px) + conv3x3_gn_patch_kernel + conv3x3_patch_stream_kernel + conv3x3_nhwc_bf16_kernel"),
                          "avg_launch_us": conv_ms / conv_n * 1e3, "launches": conv_n,
                          "flops_per_launch": conv_flops / conv_n, "ms_per_step": conv_ms / max(conv_steps, 1),
                          "algorithmic_bytes_per_launch": conv_bytes / conv_n,
                          "timing": conv_note,
                          "note": ("dominant kernel family of the step (largest share of GPU time): the bf16 MFMA 3x3 "
-                                  "convolution of the VAE encoder / UNet -- implicit-GEMM kernel (stride 1 / 2, dgrad, "
-                                  "split-K) and its patch-staged sibling with GroupNorm+SiLU fused into the loader; "
-                                  "algorithmic FLOPs = 2*M*Cout*taps*Cin per launch, summed over the launches of the "
-                                  "timed region.  The MFMA stream alone (no loads / LDS reads / barriers) measures "
+                                  "convolution of the VAE encoder / UNet -- routed per shape (nn_ops._conv_route) between the "
+                                  "Winograd F(2,3)-along-x kernel (2/3 of the multiplications of the direct form), the wide-tile "
+                                  "direct kernel, the patch-staged direct kernels (GroupNorm+SiLU in the loader) and the "
+                                  "implicit-GEMM kernel (stride 2, dgrad classes, split-K); algorithmic FLOPs = the DIRECT form's "
+                                  "2*M*Cout*taps*Cin per launch whatever the kernel multiplies, summed over the launches of "
+                                  "the timed region.  The MFMA stream alone (no loads / LDS reads / barriers) measures "
                                   "1.2-1.45 PFLOP/s on this chip with random data (power-limited clock, "
                                   "profiles/r01_conv_ablation.txt), i.e. the practical ceiling is ~0.55 of `peak`")}
     if bwd_n > 0:
@@ -571,7 +574,7 @@ def main():
                 ks = pmc["kernels"]
                 if roofline_conv is not None:
                     fam = {k: v for k, v in ks.items() if k.startswith("conv3x3_") and "hbm_bytes_per_launch" in v
-                           and "first" not in k and "flip" not in k}
+                           and "first" not in k and "flip" not in k and "weights" not in k}
                     n = sum(v["launches_sampled"] for v in fam.values())
                     if n:
                         roofline_conv["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in fam.values()) / n
