@@ -1234,6 +1234,7 @@ __global__ void conv3x3_flip_weights_kernel(const uint16_t* __restrict__ w, uint
 int g_first_grid = 2048;   // persistent workgroups of the first-conv kernel (GD_NN_FIRST_GRID overrides, tuning)
 int g_num_cus = 256;       // MI355X; refreshed from the device properties at the first patch launch
 int g_patch_persistent = -1;   // GD_NN_PATCH_PERSISTENT=0: one workgroup per tile (A/B)
+int g_route_scale = 1;     // kernel selection sees a batch of N * g_route_scale images (gd_nn_conv_set_route_scale)
 int g_force_split = -1;    // tuning hook: -1 heuristic, 1 = never split, S > 1 = force S ranges of the K-step sequence
 int g_force_variant = -1;  // tuning hook: 0 = 128x128, 1 = 128x256, 2 = 256x256, -1 = heuristic
 
@@ -1285,6 +1286,7 @@ static int choose_split(int64_t M, int Cout, int ntaps, int Cin)
 {
     const int steps = ntaps * (Cin / BK);
     if (g_force_split >= 0) return g_force_split > 1 && g_force_split <= steps ? g_force_split : 1;
+    M *= g_route_scale;
     const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
     if (tiles >= 256 || Cout % 8 || steps < 8) return 1;
     return pick_split(M, tiles, steps);
@@ -1323,11 +1325,12 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
         // rules distilled from tools/conv_kernel_bench.py on MI355X: the 256x256 tile wins whenever Cout fills it
         // and there is most of a wave of tiles; 128 ch x 256 px wins for long pixel dimensions with deep K or huge M;
         // otherwise the 128x128 tile (2 workgroups per CU) hides latency best.
-        const int64_t t256 = ((M + 255) / 256) * ((Cout + 255) / 256);
-        const int64_t t128x256 = ((M + 255) / 256) * ((Cout + 127) / 128);
+        const int64_t Ms = M * g_route_scale;
+        const int64_t t256 = ((Ms + 255) / 256) * ((Cout + 255) / 256);
+        const int64_t t128x256 = ((Ms + 255) / 256) * ((Cout + 127) / 128);
         if (Cout % 256 == 0 && t256 >= 192) variant = 2;
-        else if (Cout <= 32 && M >= (1 << 18)) variant = 4;   // few output channels (first conv's dgrad, Cout = 4)
-        else if (t128x256 >= 512 && (Cin >= 512 || M >= (1 << 20))) variant = 1;
+        else if (Cout <= 32 && Ms >= (1 << 18)) variant = 4;   // few output channels (first conv's dgrad, Cout = 4)
+        else if (t128x256 >= 512 && (Cin >= 512 || Ms >= (1 << 20))) variant = 1;
         else variant = 0;
     }
     hipEvent_t ea = nullptr, eb = nullptr;
@@ -1399,7 +1402,7 @@ static bool prefer_patch(int N, int H, int W, int Cout)
     if (g_force_variant >= 0 || g_force_split >= 0) return g_force_variant == 3;
     if (Cout < 64 || H < 16 || W < 16) return false;
     const int bn = Cout % 256 == 0 ? 256 : 128;
-    const int64_t wgs = (int64_t)N * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
+    const int64_t wgs = (int64_t)N * g_route_scale * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + bn - 1) / bn);
     return wgs >= 256;
 }
 
@@ -1415,6 +1418,13 @@ size_t gd_nn_conv3x3_ws_bytes(int N, int H, int W, int Cin, int Cout)
 int gd_nn_conv_force_split(int s)
 {
     g_force_split = s;
+    return GD_NN_OK;
+}
+
+int gd_nn_conv_set_route_scale(int k)
+{
+    if (k < 1) return fail(GD_NN_ERR_INVALID_ARG, "conv route scale must be >= 1");
+    g_route_scale = k;
     return GD_NN_OK;
 }
 

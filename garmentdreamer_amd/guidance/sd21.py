@@ -37,7 +37,7 @@ import torch.nn.functional as F
 from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, attention_d64_vt, conv1x1, conv3x3, conv3x3_s2, conv3x3_s2_supported, conv3x3_small_cin,
                       conv3x3_supported, geglu, gn_conv3x3, gn_conv3x3_supported, gn_conv_prefers_fused, group_norm_silu,
                       resnet_block_frozen, resnet_block_frozen_supported, upsample2x_conv3x3,
-                      upsample2x_conv3x3_supported, linear_320,
+                      upsample2x_conv3x3_supported, linear_320, route_rows, route_scale,
                       linear_320_geglu, linear_320_supported)
 
 
@@ -74,6 +74,28 @@ import os as _os0
 _LIN320 = _os0.environ.get("GD_LINEAR320", "1") != "0"      # =0: library GEMM (same-box A/B in tools/, never set in tests)
 
 
+def _lib_linear(x, w, b=None):
+    """``F.linear`` on the library GEMM (hipBLASLt).  The library picks its tile / split-K from M, and the summation
+    order of a row can depend on the tile it falls in, so a rank holding 1/k of the views would not reproduce the
+    single-rank run of the whole batch: under batch-invariant selection (nn_ops.set_route_scale(k),
+    SDSLoop(batch_invariant=True)) the GEMM runs on the single-rank row set with this rank's rows at their global
+    positions and zeros elsewhere (nn_ops.route_rows; tools/batch_invariance_probe.py, tools/guidance_invariance.py:
+    the 16x16-token GEGLU projection is the product of the UNet forward whose bits change between 16 and 8 latents)."""
+    if route_scale() > 1 and x.is_cuda:
+        padded, take = route_rows(x.reshape(-1, x.shape[-1]))
+        return take(F.linear(padded, w, b)).reshape(*x.shape[:-1], w.shape[0])
+    return F.linear(x, w, b)
+
+
+def _lib_addmm(c, a, w_t):
+    """``torch.addmm(c, a, w_t)`` with the same row placement under batch-invariant selection (see _lib_linear)."""
+    if route_scale() > 1 and a.is_cuda:
+        pa, take = route_rows(a)
+        pc, _ = route_rows(c)
+        return take(torch.addmm(pc, pa, w_t))
+    return torch.addmm(c, a, w_t)
+
+
 def _lin(mod: nn.Linear, x, bias=None):
     """``mod(x)`` (with ``bias`` in place of ``mod.bias`` if given).  Frozen products with K = 320 on long row sets -- to_q
     of the cross-attention, to_out.0, proj_in, proj_out (N = 320) and the GEGLU projection (N = 2560) of the 64x64-token
@@ -84,7 +106,7 @@ def _lin(mod: nn.Linear, x, bias=None):
     if _LIN320 and x.is_cuda and not torch.is_grad_enabled() and not w.requires_grad and w.shape[1] == 320 and \
             linear_320_supported(x, w, b):
         return linear_320(x, w, b)
-    return F.linear(x, w, b)
+    return _lib_linear(x, w, b)
 
 
 def _gn_conv3(norm: nn.GroupNorm, conv: nn.Conv2d, x, image_bias=None, residual=None):
@@ -229,16 +251,16 @@ class Attention(nn.Module):
                 self._wqk = torch.cat([self.to_q.weight, self.to_k.weight], dim=0).detach().contiguous()
                 self._wqkv_src = src
             q, k = (linear_320(x, self._wqk) if _LIN320 and linear_320_supported(x, self._wqk)
-                    else F.linear(x, self._wqk)).chunk(2, dim=-1)
+                    else _lib_linear(x, self._wqk)).chunk(2, dim=-1)
             q = q.view(B, N, self.heads, -1)
             k = k.view(B, N, self.heads, -1)
             if _VT_GEMM and N % 64 == 0 and N >= 256 and q.shape[-1] == 64 and x.dtype == torch.bfloat16:
                 vt = torch.matmul(self.to_v.weight.detach(), x.transpose(1, 2))      # [B, C, N]
                 return _lin(self.to_out[0], attention_d64_vt(q, k, vt))
-            v = self.to_v(x)
+            v = _lin(self.to_v, x)
             q, k = q.reshape(B, N, -1), k.reshape(B, N, -1)
         else:
-            q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
+            q, k, v = _lin(self.to_q, x), _lin(self.to_k, ctx), _lin(self.to_v, ctx)
         if self.lora is not None:
             q = q + self.lora_scale * self.lora["to_q_lora"](x)
             k = k + self.lora_scale * self.lora["to_k_lora"](ctx)
@@ -278,7 +300,7 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Identity(), nn.Linear(dim * mult, dim)])
 
     def forward(self, x):
-        return self.net[2](self.net[0](x))
+        return _lin(self.net[2], self.net[0](x))
 
 
 class BasicTransformerBlock(nn.Module):
@@ -300,7 +322,7 @@ class BasicTransformerBlock(nn.Module):
         if defer_ff_bias:
             # last residual inside the GEMM (beta = 1): x + gelu-gated(n) @ W2^T; the caller owes the constant b2
             g = self.ff.net[0](n)
-            return torch.addmm(x.reshape(-1, x.shape[-1]), g.reshape(-1, g.shape[-1]), self.ff.net[2].weight.t()).view_as(x)
+            return _lib_addmm(x.reshape(-1, x.shape[-1]), g.reshape(-1, g.shape[-1]), self.ff.net[2].weight.t()).view_as(x)
         return x + self.ff(n)
 
 
@@ -430,7 +452,7 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = nn.Linear(out_ch, out_ch)
 
     def forward(self, x):
-        return self.linear_2(F.silu(self.linear_1(x)))
+        return _lin(self.linear_2, F.silu(_lin(self.linear_1, x)))
 
 
 def sinusoidal_timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -495,7 +517,7 @@ class UNet2DConditionModel(nn.Module):
                 w = torch.cat([t for a in atts for t in (a.to_k.weight, a.to_v.weight)], dim=0).to(ctx.dtype).contiguous()
             cache = self._ctx_cat = (key, w)
         with torch.no_grad():
-            allp = F.linear(ctx, cache[1])
+            allp = _lib_linear(ctx, cache[1])
         kv, off = {}, 0
         for a in atts:
             c = a.to_k.out_features
@@ -521,7 +543,7 @@ class UNet2DConditionModel(nn.Module):
                 bias = torch.cat([b.time_emb_proj.bias + b.conv1.bias for b in blocks], dim=0).to(temb.dtype)
             cache = self._temb_cat = (key, w, bias)
         with torch.no_grad():
-            allp = F.linear(F.silu(temb), cache[1], cache[2])
+            allp = _lib_linear(F.silu(temb), cache[1], cache[2])
         out, off = {}, 0
         for b in blocks:
             c = b.time_emb_proj.out_features
@@ -657,15 +679,15 @@ class _VAEAttention(nn.Module):
             # cheap on a 288 GB part.  Frozen weights: one [C, 3C] projection with the softmax scale folded into its
             # q rows (no N x C scaling pass forward or backward); the bmm's read the strided q / k / v views.
             if _FUSED_QKV and not (self.to_q.weight.requires_grad or self.to_k.weight.requires_grad or self.to_v.weight.requires_grad):
-                q, k, v = F.linear(h, *self._qkv_scaled(h.dtype, C ** -0.5)).chunk(3, dim=-1)
+                q, k, v = _lib_linear(h, *self._qkv_scaled(h.dtype, C ** -0.5)).chunk(3, dim=-1)
             else:
-                q, k, v = self.to_q(h) * (C ** -0.5), self.to_k(h), self.to_v(h)
+                q, k, v = _lin(self.to_q, h) * (C ** -0.5), _lin(self.to_k, h), _lin(self.to_v, h)
             p = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
             o = torch.bmm(p, v)
         else:
             q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
             o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
-        o = self.to_out[0](o).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        o = _lin(self.to_out[0], o).reshape(B, H, W, C).permute(0, 3, 1, 2)
         return x + o
 
 

@@ -213,15 +213,16 @@ class StableDiffusionGuidance(nn.Module):
 
     def _encode_prepared(self, x, vae_noise, out_dtype):
         """``x``: images already mapped to [-1, 1] in the VAE's dtype (``encode_images`` or the fused prologue)."""
-        if self.cfg.use_hip_graphs and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
-            xc = x.contiguous(memory_format=torch.channels_last)
-            try:
-                posterior = sd21.DiagonalGaussianDistribution(self._graphed_vae_moments(xc))
-            except RuntimeError as e:
-                self._graphs_failed(e)
+        with nn_ops.route_batch(1, x.shape[0]):
+            if self.cfg.use_hip_graphs and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+                xc = x.contiguous(memory_format=torch.channels_last)
+                try:
+                    posterior = sd21.DiagonalGaussianDistribution(self._graphed_vae_moments(xc))
+                except RuntimeError as e:
+                    self._graphs_failed(e)
+                    posterior = self.vae.encode(x).latent_dist
+            else:
                 posterior = self.vae.encode(x).latent_dist
-        else:
-            posterior = self.vae.encode(x).latent_dist
         noise = None if vae_noise is None else vae_noise.to(self.weights_dtype)
         latents = posterior.sample(noise) * self.vae.config.scaling_factor
         return latents.to(out_dtype)
@@ -242,8 +243,9 @@ class StableDiffusionGuidance(nn.Module):
                 if noise is None:
                     noise = torch.randn_like(latents)
                 latents_noisy = self.scheduler.add_noise(latents, noise, t)
-                noise_pred = self.forward_unet(torch.cat([latents_noisy] * 4, dim=0), torch.cat([t] * 4),
-                                               encoder_hidden_states=text_embeddings)
+                with nn_ops.route_batch(4, 4 * batch_size):
+                    noise_pred = self.forward_unet(torch.cat([latents_noisy] * 4, dim=0), torch.cat([t] * 4),
+                                                   encoder_hidden_states=text_embeddings)
             noise_pred_text = noise_pred[:batch_size]
             noise_pred_uncond = noise_pred[batch_size:batch_size * 2]
             noise_pred_neg = noise_pred[batch_size * 2:]
@@ -263,8 +265,9 @@ class StableDiffusionGuidance(nn.Module):
                     noise = torch.randn_like(latents)
                 latents_noisy = self.scheduler.add_noise(latents, noise, t)
                 latent_model_input = torch.cat([latents_noisy] * 2, dim=0)
-                noise_pred = self.forward_unet(latent_model_input, torch.cat([t] * 2),
-                                               encoder_hidden_states=text_embeddings)
+                with nn_ops.route_batch(2, 2 * batch_size):
+                    noise_pred = self.forward_unet(latent_model_input, torch.cat([t] * 2),
+                                                   encoder_hidden_states=text_embeddings)
             noise_pred_text, noise_pred_uncond = noise_pred.chunk(2)
             noise_pred = noise_pred_text + self.cfg.guidance_scale * (noise_pred_text - noise_pred_uncond)
 

@@ -35,6 +35,7 @@ SIGNATURES = {
     "gd_nn_conv3x3_ws_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_forward_ws": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t]),
     "gd_nn_conv_force_split": (_i, [_i]),
+    "gd_nn_conv_set_route_scale": (_i, [_i]),
     "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
     "gd_nn_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "gd_nn_groupnorm_silu_forward_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _f]),
@@ -221,6 +222,69 @@ def _bias_and_stride(bias):
 # GD_NN_WINO=0: every stride-1 convolution on the direct kernels (A/B timing in tools/; never set in tests or the benchmark)
 _WINO = os.environ.get("GD_NN_WINO", "1") != "0"
 
+_ROUTE_SCALE = 1
+_ROUTE_RANK = 0
+_ROUTE_BATCH = None     # (groups, samples) of the call in flight, see route_batch
+
+
+def set_route_scale(k: int, rank: int = 0) -> None:
+    """Batch-invariant kernel selection (include/gd_nn.h gd_nn_conv_set_route_scale): every routing rule in this
+    module and in the library that looks at the batch sees N * k images.  The sharded loop sets k = world size when
+    asked for `batch_invariant` gradients, so a rank with 1/k of the views runs the kernels (and bf16 summation
+    orders) the single-rank run of the whole camera batch runs; k = 1 tunes each launch for the batch it gets.
+    `rank`: this rank's position among the k shares (dist.shard_views deals view v to rank v % k) -- the library GEMMs
+    are given their rows at the positions the single-rank batch holds them (route_rows)."""
+    global _ROUTE_SCALE, _ROUTE_RANK
+    k, rank = int(k), int(rank)
+    if not 0 <= rank < max(k, 1):
+        raise ValueError(f"rank {rank} outside 0..{k - 1}")
+    if lib().gd_nn_conv_set_route_scale(k) != 0:
+        raise ValueError(f"route scale must be >= 1, got {k}")
+    _ROUTE_SCALE, _ROUTE_RANK = k, rank
+
+
+def route_scale() -> int:
+    return _ROUTE_SCALE
+
+
+class route_batch:
+    """``with route_batch(groups, samples):`` -- the network call inside runs on `samples` batch entries made of
+    `groups` concatenated copies of this rank's views (2 for the SDS UNet call: text | unconditional; 1 for the VAE).
+    Only read under batch-invariant selection (set_route_scale(k > 1))."""
+
+    def __init__(self, groups: int, samples: int):
+        self.value = (int(groups), int(samples))
+
+    def __enter__(self):
+        global _ROUTE_BATCH
+        self.prev, _ROUTE_BATCH = _ROUTE_BATCH, self.value
+        return self
+
+    def __exit__(self, *exc):
+        global _ROUTE_BATCH
+        _ROUTE_BATCH = self.prev
+        return False
+
+
+def route_rows(rows):
+    """Under batch-invariant selection: the [M, K] row set of a library GEMM laid out as the single-rank run of the
+    whole camera batch holds it -- k x M rows, this rank's samples at their global positions (view j of this rank is
+    global view j * k + rank inside each of the `groups` copies), zeros elsewhere -- plus the function that takes this
+    rank's rows back out of the product.  hipBLASLt picks tile and split-K from M, and (stream-K) the summation order of
+    a row from the tile it falls in: both then match the single-rank run bit for bit."""
+    k, r = _ROUTE_SCALE, _ROUTE_RANK
+    M, K = rows.shape
+    G, B = _ROUTE_BATCH if _ROUTE_BATCH is not None else (1, 0)
+    if B <= 0 or B % G or M % B:
+        G, B = 1, 1                      # unknown structure: this rank's rows first, zero rows after them
+    c, T = B // G, M // B
+    padded = rows.new_zeros((G, c, k, T, K))
+    padded[:, :, r] = rows.view(G, c, T, K)
+
+    def take(out):
+        return out.view(G, c, k, T, out.shape[-1])[:, :, r].reshape(M, out.shape[-1])
+    return padded.view(k * M, K), take
+
 
 def _conv_route(N, H, W, Cin, Cout, gn=False):
     """Which kernel a stride-1 3x3 convolution runs on: "wide" (128 channels x 16x32 pixels, csrc/nn_conv_wide.h), "wino"
@@ -236,12 +300,12 @@ def _conv_route(N, H, W, Cin, Cout, gn=False):
     tiles_n = (Cout + 127) // 128
     if Cout <= 128 and (not gn or Cin <= 128) or (not gn and Cout == 640 and W == 32 and Cin >= 320):
         # (the wide tile needs a fuller grid than the Winograd one: 256 -> 128 @ 256^2 at ONE image, 128 tiles, 0.72x)
-        if N * ((H + 15) // 16) * ((W + 31) // 32) * tiles_n >= (256 if Cout <= 128 else 160) and \
+        if N * _ROUTE_SCALE * ((H + 15) // 16) * ((W + 31) // 32) * tiles_n >= (256 if Cout <= 128 else 160) and \
                 lib().gd_nn_conv3x3_wide_supported(N, H, W, Cin, Cout):
             return "wide"
     if gn or (Cin < 320 and Cout > 128):
         return None
-    if N * ((H + 15) // 16) * ((W + 15) // 16) * tiles_n >= 128 and lib().gd_nn_conv3x3_wino_supported(N, H, W, Cin, Cout):
+    if N * _ROUTE_SCALE * ((H + 15) // 16) * ((W + 15) // 16) * tiles_n >= 128 and lib().gd_nn_conv3x3_wino_supported(N, H, W, Cin, Cout):
         return "wino"
     return None
 
@@ -645,7 +709,7 @@ def gn_conv_prefers_fused(x, out_channels: int) -> bool:
     if _GN_FUSED_OVERRIDE is not None:      # GD_NN_GN_FUSED=0/1: A/B timing of the routing rule (tools/, never set in tests)
         return _GN_FUSED_OVERRIDE
     bn = 256 if out_channels % 256 == 0 else 128
-    wgs = x.shape[0] * -(-x.shape[2] // 16) * -(-x.shape[3] // 16) * -(-out_channels // bn)
+    wgs = x.shape[0] * _ROUTE_SCALE * -(-x.shape[2] // 16) * -(-x.shape[3] // 16) * -(-out_channels // bn)
     return x.shape[2] * x.shape[3] >= 256 * 256 and wgs >= 384
 
 
@@ -840,7 +904,7 @@ def upsample2x_conv3x3_supported(x, weight) -> bool:
         return False
     # each parity class is its own launch of N*H*W pixels x Cout channels in 128x128 tiles; below about half a
     # wave of tiles (one or two views per GPU) the single split-K launch on the upsampled tensor fills the chip better
-    tiles = -(-(x.shape[0] * x.shape[2] * x.shape[3]) // 128) * -(-weight.shape[0] // 128)
+    tiles = -(-(x.shape[0] * _ROUTE_SCALE * x.shape[2] * x.shape[3]) // 128) * -(-weight.shape[0] // 128)
     return tiles >= 128
 
 
@@ -1209,7 +1273,7 @@ class Fp8State:
 
     def wants(self, conv, x) -> bool:
         N, Cin, H, W = x.shape
-        return (x.is_cuda and x.dtype == torch.bfloat16 and N * H * W >= self.min_pixels and Cin % 16 == 0
+        return (x.is_cuda and x.dtype == torch.bfloat16 and N * _ROUTE_SCALE * H * W >= self.min_pixels and Cin % 16 == 0
                 and conv.out_channels % 4 == 0 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
                 and conv.padding == (1, 1))
 

@@ -70,8 +70,14 @@ class SDSLoop:
     def __init__(self, gaussians, guidance, prompt_utils, bg_color: torch.Tensor,
                  render_batch_fn: Optional[Callable] = None, lambda_sds: float = 1.0, lambda_sparsity: float = 1.0,
                  lr_scale: float = 1.0, fused_adam: Optional[bool] = None, densify: bool = True,
-                 cameras_extent: float = 4.0, densify_seed: int = 0):
+                 cameras_extent: float = 4.0, densify_seed: int = 0, batch_invariant: bool = False):
         self.gaussians = gaussians
+        if batch_invariant and gaussians.get_xyz.is_cuda:
+            # sharded run that must reproduce the single-rank gradients as closely as bf16 allows: the guidance
+            # kernels are selected for the whole camera batch (views per rank x world size), not for this rank's
+            # share (include/gd_nn.h gd_nn_conv_set_route_scale); costs a few % of step time on small shares
+            from . import dist as gdist, nn_ops
+            nn_ops.set_route_scale(gdist.world_size(), gdist.rank())
         self.guidance = guidance
         self.prompt_utils = prompt_utils
         self.bg = bg_color

@@ -83,6 +83,11 @@ int gd_nn_conv3x3_forward_ws(void* stream, const void* x, const void* weight, co
                              size_t ws_bytes);
 /* tuning hook: -1 heuristic (default), 1 never split, 3 / 9 force that split factor */
 int gd_nn_conv_force_split(int s);
+/* Batch-invariant kernel selection for sharded runs: every tile / split-K / patch-vs-GEMM rule that looks at the
+ * batch sees N * k images, so a rank that holds 1/k of the views (threestudio's DDP split of the camera batch,
+ * GaussianDreamer.py:189-191) picks the kernels - and therefore the bf16 summation orders - the single-rank run
+ * of the whole batch picks.  k = 1 (default): each launch is tuned for the batch it gets. */
+int gd_nn_conv_set_route_scale(int k);
 
 /* GroupNorm statistics only: mean_rstd[N][G][2] = {mean, 1/sqrt(var + eps)} of x (bf16 [N,HW,C]); stats_ws as in
  * gd_nn_groupnorm_silu_forward.  Feeds gd_nn_conv3x3_gn_forward (and gd_nn_groupnorm_silu_backward). */

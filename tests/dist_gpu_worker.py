@@ -49,7 +49,8 @@ def main():
         guidance = StableDiffusionGuidance({"guidance_scale": 7.5, "grad_clip": [0, 1.5, 2.0, 1000],
                                             "half_precision_weights": False}, device=dev, unet=unet, vae=vae)
     gm = GaussianModel.from_activated(synthetic_gaussians(P, seed=2), device=dev)
-    loop = SDSLoop(gm, guidance, PromptEmbeddings.random(dev), torch.ones(3, device=dev), densify_seed=123)
+    loop = SDSLoop(gm, guidance, PromptEmbeddings.random(dev), torch.ones(3, device=dev), densify_seed=123,
+                   batch_invariant=os.environ.get("GD_TEST_BATCH_INVARIANT") == "1")
     loop.global_step = FIRST_STEP
     view_ids = gdist.shard_views(V_TOTAL, rk, ws)
     g = torch.Generator().manual_seed(11)
