@@ -251,7 +251,11 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     for (int b = 0; b < FB; b++) pf0[b] = *(const bf16x8_t*)(smem + p_rd[b]);
 #endif
     issue(0);
+#if GD_CONV_ABLATE == 8
+    for (int s = 0; s < (nsteps > 1 ? 1 : nsteps); s++) {
+#else
     for (int s = 0; s < nsteps; s++) {
+#endif
         const int buf = s & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if GD_CONV_ABLATE != 5 && GD_CONV_ABLATE != 6
@@ -308,8 +312,15 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[a][b][4 * q + e];
-                if (partial) {   // fp32 partial of this K range, indexed by GEMM row (compact also for strided outputs)
-                    *(float4*)(partial + ((size_t)blockIdx.y * (size_t)M + (size_t)m) * Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+                if (partial) {
+                    // fp32 partial of this K range in MFMA fragment order: every store instruction of a wave writes one
+                    // contiguous 1 KB block of the tile's 64 KB image (conv_splitk_reduce_kernel decodes the same
+                    // order).  Indexed by GEMM row / channel, each lane's 16 bytes fell in a line of their own:
+                    // the scattered partial stores were HALF the time of the one-view-per-GPU convolutions
+                    // (tools/conv_small_ablate.py: 640 -> 640 @ 32^2, 2 latents, 32 -> 17 us without them)
+                    // (split launches always use the 128 x 128 / 4-wave tile: launch_conv)
+                    *(float4*)(partial + (((size_t)blockIdx.y * nwg + bid) * (BN * BM / 4) +
+                                          (((wave * FB + b) * FA + a) * 4 + q) * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
                     continue;
                 }
                 if (bias_n) {
@@ -977,45 +988,50 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
 #include "nn_conv_wino.h"
 #include "nn_conv_wide.h"
 
-// out = bf16( sum_s partial[s] + bias + residual ): second half of the split-K path; 8 channels per thread.  Partials
-// are indexed by GEMM row; the row -> output pixel map is the convolution's (identity for stride-1 layers, every
-// second pixel for the parity classes of a stride-2 input gradient).
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ partial, int S, size_t MC,
-                                                                 int Cout, int HWg, int Wg, int Hout, int Wout, int osy,
-                                                                 int osx, int ooy, int oox,
+// out = bf16( sum_s partial[s] + bias + residual ): second half of the split-K path, 4 channels per thread, splits
+// added in index order (deterministic).  Partials are tile images in the convolution's MFMA fragment order (coalesced
+// 16-byte accesses on both sides); GEMM row -> output pixel is the convolution's map (identity for stride-1 layers,
+// every second pixel for the parity classes of a stride-2 input gradient).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ partial, int S, int nwg,
+                                                                 int tiles_n, int64_t M, int Cout, int HWg, int Wg, int Hout,
+                                                                 int Wout, int osy, int osx, int ooy, int oox,
                                                                  const uint16_t* __restrict__ bias, int bias_img_stride,
                                                                  const uint16_t* __restrict__ residual,
                                                                  uint16_t* __restrict__ out)
 {
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
-    if (i >= MC) return;
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = 0.f;
+    // one thread = one float4 of a 128 x 128 tile image in the convolution's fragment order:
+    //   r = (((wave * 2 + b) * 2 + a) * 4 + q) * 64 + lane   (wave = pixel half * 2 + channel half of the tile)
+    const int tile = blockIdx.x >> 4;
+    const int r = ((blockIdx.x & 15) << 8) | threadIdx.x;
+    const int lane = r & 63, q = (r >> 6) & 3, a = (r >> 8) & 1, b = (r >> 9) & 1, wave = r >> 10;
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const int64_t m = (int64_t)tm * 128 + (wave >> 1) * 64 + b * 32 + (lane & 31);
+    const int co = tn * 128 + (wave & 1) * 64 + a * 32 + 8 * q + 4 * (lane >> 5);
+    if (m >= M || co >= Cout) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* p = (const float4*)partial + (size_t)tile * 4096 + r;
     for (int sidx = 0; sidx < S; sidx++) {
-        const float4 p0 = *(const float4*)(partial + (size_t)sidx * MC + i);
-        const float4 p1 = *(const float4*)(partial + (size_t)sidx * MC + i + 4);
-        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
-        v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+        const float4 t = p[(size_t)sidx * nwg * 4096];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
-    const size_t m = i / Cout;
-    const int co = (int)(i - m * Cout);
-    const size_t nimg = m / (size_t)HWg;
-    const int rem = (int)(m - nimg * (size_t)HWg);
+    const size_t nimg = (size_t)(m / HWg);
+    const int rem = (int)(m - (int64_t)nimg * HWg);
     const int ga = rem / Wg, gb = rem - ga * Wg;
-    const size_t o = (((size_t)nimg * Hout + (size_t)(ga * osy + ooy)) * Wout + (size_t)(gb * osx + oox)) * Cout + co;
+    const size_t o = ((nimg * Hout + (size_t)(ga * osy + ooy)) * Wout + (size_t)(gb * osx + oox)) * Cout + co;
     if (bias) {
-        const uint16_t* bn = bias + nimg * (size_t)bias_img_stride + co;
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] += bf2f(bn[k]);
+        const uint2 bb = *(const uint2*)(bias + nimg * (size_t)bias_img_stride + co);
+        v.x += bf2f((uint16_t)(bb.x & 0xffff)); v.y += bf2f((uint16_t)(bb.x >> 16));
+        v.z += bf2f((uint16_t)(bb.y & 0xffff)); v.w += bf2f((uint16_t)(bb.y >> 16));
     }
     if (residual) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] += bf2f(residual[o + k]);
+        const uint2 rr = *(const uint2*)(residual + o);
+        v.x += bf2f((uint16_t)(rr.x & 0xffff)); v.y += bf2f((uint16_t)(rr.x >> 16));
+        v.z += bf2f((uint16_t)(rr.y & 0xffff)); v.w += bf2f((uint16_t)(rr.y >> 16));
     }
-    uint4 ov;
-    ov.x = pack_bf16(v[0], v[1]); ov.y = pack_bf16(v[2], v[3]); ov.z = pack_bf16(v[4], v[5]); ov.w = pack_bf16(v[6], v[7]);
-    *(uint4*)(out + o) = ov;
+    uint2 ov;
+    ov.x = pack_bf16(v.x, v.y);
+    ov.y = pack_bf16(v.z, v.w);
+    *(uint2*)(out + o) = ov;
 }
 
 // First convolution of the VAE encoder / UNet: Cin <= 4 (image or latent -> features), 3x3 / s1 / p1, + bias.
@@ -1282,6 +1298,13 @@ static int pick_split(int64_t M, int64_t tiles, int steps)
     return s < 2 ? 1 : s;
 }
 
+// fp32 scratch of a split-K launch: `split` images of the padded 128 x 128 tile grid (every workgroup stores its
+// accumulators in MFMA fragment order, one contiguous 64 KB block per tile and K range)
+static size_t split_ws_bytes(int split, int64_t M, int Cout)
+{
+    return (size_t)split * (size_t)((M + 127) / 128) * (size_t)((Cout + 127) / 128) * 16384u * sizeof(float);
+}
+
 static int choose_split(int64_t M, int Cout, int ntaps, int Cin)
 {
     const int steps = ntaps * (Cin / BK);
@@ -1315,7 +1338,7 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
     // pixels, else the 128x128 / 4-wave tile.
     const int64_t Mo = (int64_t)N * g.Hout * g.Wout;
     int split = ws ? choose_split(M, Cout, g.ntaps, Cin) : 1;
-    if (split > 1 && ws_bytes < (size_t)split * M * Cout * sizeof(float)) split = 1;
+    if (split > 1 && ws_bytes < split_ws_bytes(split, M, Cout)) split = 1;
     float* partial = split > 1 ? (float*)ws : nullptr;
     const int total_steps = g.ntaps * (Cin / BK);
     const int tps = split > 1 ? (total_steps + split - 1) / split : total_steps;
@@ -1360,9 +1383,9 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
     else GD_LAUNCH(128, 128, 2, 2);
 #undef GD_LAUNCH
     if (split > 1) {
-        const size_t MC = (size_t)M * Cout;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((MC / 8 + 255) / 256)), dim3(256), 0, s, partial,
-                           split, MC, Cout, g.Hg * g.Wg, g.Wg, g.Hout, g.Wout, g.osy, g.osx, g.ooy, g.oox,
+        const int tiles_n = (Cout + 127) / 128, nwg = (int)((M + 127) / 128) * tiles_n;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)nwg * 16u), dim3(256), 0, s, partial, split, nwg,
+                           tiles_n, M, Cout, g.Hg * g.Wg, g.Wg, g.Hout, g.Wout, g.osy, g.osx, g.ooy, g.oox,
                            (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y);
     }
     if (ea && eb) {
@@ -1412,7 +1435,7 @@ size_t gd_nn_conv3x3_ws_bytes(int N, int H, int W, int Cin, int Cout)
     if (prefer_patch(N, H, W, Cout)) return 0;
     const int64_t M = (int64_t)N * H * W;
     const int split = choose_split(M, Cout, 9, Cin);
-    return split > 1 ? (size_t)split * M * Cout * sizeof(float) : 0;
+    return split > 1 ? split_ws_bytes(split, M, Cout) : 0;
 }
 
 int gd_nn_conv_force_split(int s)
@@ -1874,7 +1897,7 @@ static size_t geom_ws_bytes(int N, const ConvGeom& g, int Cin, int Cout)
 {
     const int64_t M = (int64_t)N * g.Hg * g.Wg;
     const int split = choose_split(M, Cout, g.ntaps, Cin);
-    return split > 1 ? (size_t)split * M * Cout * sizeof(float) : 0;
+    return split > 1 ? split_ws_bytes(split, M, Cout) : 0;
 }
 
 // fp32 scratch the split-K form of the stride-2 layers wants (0: the layer fills the chip unsplit); forward, or the
