@@ -237,6 +237,93 @@ __global__ void gn_apply_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict
     for (; p < p1; p += rows) body(xn[(size_t)p * vpp + tv], p);
 }
 
+// ---- one-launch GroupNorm(+SiLU) for tensors whose (image, group) slice fits a workgroup's registers ------------
+// The two-pass form above (statistics kernel, apply kernel) reads x twice and pays two launches; on the UNet's maps
+// (<= 64x64 at <= 16 latents) most of its time is launch latency and the second read.  Here ONE workgroup owns one
+// (image, group): its HW x C/G slice (<= 128 KB) is read ONCE into registers -- dword = 2 channels, lane-consecutive
+// within a pixel's C/G-channel run, then on to the next pixel (stride C) -- summed (per-thread fp32, cross-thread fp64),
+// normalised from the registers and written.  Read 1x + write 1x instead of read 2x + write 1x, one launch instead of
+// two, no workspace / atomics (bit-reproducible).  Inference only: the backward pass wants mean / rstd (two-pass form).
+template <int THREADS, int R>
+__global__ __launch_bounds__(THREADS) void gn_group_fused_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ y,
+                                                                 const uint16_t* __restrict__ gamma,
+                                                                 const uint16_t* __restrict__ beta, int HW, int C2,
+                                                                 int cg2, int G, uint32_t magic, float eps,
+                                                                 int apply_silu)
+{
+    constexpr int WAVES = THREADS / 64;
+    __shared__ double s_red[2][WAVES];
+    __shared__ f2 s_a[64], s_b[64];
+    // XCD-aware order: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The C/G-channel runs of
+    // neighbouring groups share cache lines (20 bytes of a 640-byte pixel row at C = 320), so the groups of an image
+    // are kept on ONE XCD -- dealt round-robin, each line was fetched by up to six L2s
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int n = bid / G, g = bid - n * G, tid = threadIdx.x;
+    const int total = HW * cg2;
+    // image n as a buffer: 32-bit byte offsets (one VGPR per access instead of a 64-bit address pair), and an offset
+    // past the end reads 0 / drops the store, so the ragged tail needs no branch
+    const uint32_t img_bytes = (uint32_t)HW * (uint32_t)C2 * 4u;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)n * HW * C2), 0, (int)img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)n * HW * C2), 0, (int)img_bytes, 0x00020000);
+    const uint32_t goff = (uint32_t)g * (uint32_t)cg2 * 4u;
+    uint32_t v[R];
+    f2 s = f2{0.f, 0.f}, ss = f2{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int d = tid + i * THREADS;
+        const uint32_t p = __umulhi((uint32_t)d, magic);          // d / cg2 (exact for d < 2^32 / cg2)
+        const uint32_t off = d < total ? (p * (uint32_t)C2 + ((uint32_t)d - p * (uint32_t)cg2)) * 4u + goff : 0xfffffff0u;
+        v[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0);
+        if ((i & (R >= 64 ? 3 : 7)) == (R >= 64 ? 3 : 7)) __builtin_amdgcn_sched_barrier(0);   // offsets are made a few at a time, not R at a time
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const f2 f = unpack2(v[i]);
+        s += f;
+        ss += f * f;
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    double a = (double)s.x + (double)s.y, b = (double)ss.x + (double)ss.y;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = a; s_red[1][tid >> 6] = b; }
+    __syncthreads();
+    if (tid < cg2) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) { sa += s_red[0][w]; sb += s_red[1][w]; }
+        const double M = (double)total * 2.0;
+        const double mean = sa / M;
+        double var = sb / M - mean * mean;
+        var = var < 0 ? 0 : var;
+        const float meanf = (float)mean, rstd = rsqrtf((float)var + eps);
+        const int c = (g * cg2 + tid) * 2;
+        const float a0 = rstd * bf2f(gamma[c]), a1 = rstd * bf2f(gamma[c + 1]);
+        s_a[tid] = f2{a0, a1};
+        s_b[tid] = f2{bf2f(beta[c]) - meanf * a0, bf2f(beta[c + 1]) - meanf * a1};
+    }
+    __syncthreads();
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));       // the offsets are recomputed here, not kept alive across the reduction
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int d = tid2 + i * THREADS;
+        const uint32_t p = __umulhi((uint32_t)d, magic);
+        const uint32_t j = (uint32_t)d - p * (uint32_t)cg2;
+        const uint32_t off = d < total ? (p * (uint32_t)C2 + j) * 4u + goff : 0xfffffff0u;
+        f2 z = unpack2(v[i]) * s_a[j & 63] + s_b[j & 63];
+        if (apply_silu) z = z * sigmoid2(z);
+        __builtin_amdgcn_raw_buffer_store_b32(pack2(z), rs_y, off, 0, 0);
+        if ((i & (R >= 64 ? 3 : 7)) == (R >= 64 ? 3 : 7)) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+
 // Same pass with an e4m3 result (one fp32 scale per tensor, value = scale * byte): the input of the fp8 convolution of
 // the no-grad UNet forward (csrc/nn_fp8.hip) -- the quantisation costs no extra pass and halves the bytes written.
 __global__ void gn_apply_fp8_kernel(const bf16x8* __restrict__ x, uint2* __restrict__ y,
@@ -518,6 +605,39 @@ int gd_nn_groupnorm_silu_forward(void* stream, const void* x, void* y, const voi
                            g.ppb_stats, eps, stats_ws, mean_rstd, N, 0);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, s, (const bf16x8*)x, (bf16x8*)y, (const uint16_t*)gamma,
                        (const uint16_t*)beta, HW, C, G, g.vpp, g.rows, g.ppb, apply_silu, mean_rstd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_groupnorm_silu_fused_supported(int N, int HW, int C, int G)
+{
+    if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || (C / G) % 2 || C / G < 4 || C / G > 128) return 0;
+    // 10-channel runs (C = 320) on 64x64 maps: 20 four-byte loads per thread from 20-byte runs -- level with the two-pass
+    // kernels at 16 latents, 0.84x at 2 (tools/gn_small_bench.py); every other shape of the UNet is 1.2-5x faster
+    const long total = (long)HW * (C / G / 2);
+    if (total > 1024L * 16 && C / G < 16) return 0;
+    return total <= 1024L * 32 ? 1 : 0;
+}
+
+int gd_nn_groupnorm_silu_fused_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
+                                       int HW, int C, int G, float eps, int apply_silu)
+{
+    if (!x || !y || !gamma || !beta) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!gd_nn_groupnorm_silu_fused_supported(N, HW, C, G))
+        return fail(GD_NN_ERR_INVALID_ARG, "fused GroupNorm: need C % G == 0, C / G even, 4 <= C / G <= 128, HW * C / G <= 65536");
+    const int cg2 = C / G / 2, total = HW * cg2;
+    const uint32_t magic = (uint32_t)((0x100000000ull + (uint64_t)cg2 - 1) / (uint64_t)cg2);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)G * (unsigned)N);
+#define GD_GN_FUSED(T_, R_)                                                                                             \
+    hipLaunchKernelGGL((gn_group_fused_kernel<T_, R_>), grid, dim3(T_), 0, s, (const uint32_t*)x, (uint32_t*)y,          \
+                       (const uint16_t*)gamma, (const uint16_t*)beta, HW, C / 2, cg2, G, magic, eps, apply_silu)
+    if (total <= 256 * 8) GD_GN_FUSED(256, 8);
+    else if (total <= 1024 * 8) GD_GN_FUSED(1024, 8);
+    else if (total <= 1024 * 16) GD_GN_FUSED(1024, 16);
+    else GD_GN_FUSED(1024, 32);      // (1024 x 64 = the 640 / 960-channel 64x64 maps would need 24 spilled registers)
+#undef GD_GN_FUSED
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

@@ -29,6 +29,8 @@ def use_library(path: str) -> None:
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "gd_nn_groupnorm_silu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "gd_nn_groupnorm_silu_fused_supported": (_i, [_i, _i, _i, _i]),
+    "gd_nn_groupnorm_silu_fused_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i]),
     "gd_nn_groupnorm_silu_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
@@ -189,6 +191,22 @@ class _GroupNormSiLU(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+# GD_NN_GN_SMALL=0: the two-pass GroupNorm also where the one-launch form applies (A/B timing in tools/; never set in tests)
+_GN_FUSED_SMALL = os.environ.get("GD_NN_GN_SMALL", "1") != "0"
+
+
+def _gn_fused_small(x, weight, bias, groups, eps, silu):
+    """Inference GroupNorm(+SiLU) in one launch (gd_nn_groupnorm_silu_fused_forward): one workgroup per (image, group)."""
+    N, Cc, H, W = x.shape
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    w, b = weight.contiguous(), bias.contiguous()
+    with torch.cuda.device(x.device):
+        _check(lib().gd_nn_groupnorm_silu_fused_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
+                                                        y.data_ptr(), w.data_ptr(), b.data_ptr(), N, H * W, Cc, groups,
+                                                        float(eps), int(silu)), "gd_nn_groupnorm_silu_fused_forward")
+    return y
+
+
 def group_norm_silu(x, weight, bias, groups: int, eps: float, silu: bool = True):
     """``silu(group_norm(x))`` (or just group_norm).  HIP kernel for bf16 NHWC tensors on the GPU."""
     if x.is_cuda:
@@ -197,6 +215,9 @@ def group_norm_silu(x, weight, bias, groups: int, eps: float, silu: bool = True)
         if x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0:
             if not x.is_contiguous(memory_format=torch.channels_last):
                 x = x.contiguous(memory_format=torch.channels_last)
+            if _GN_FUSED_SMALL and not (torch.is_grad_enabled() and x.requires_grad) and \
+                    lib().gd_nn_groupnorm_silu_fused_supported(x.shape[0], x.shape[2] * x.shape[3], x.shape[1], groups):
+                return _gn_fused_small(x, weight, bias, groups, eps, silu)
             return _GroupNormSiLU.apply(x, weight, bias, groups, eps, silu)
         # fp32 GPU runs (parity checks of the bf16 path) use torch's ops
     y = F.group_norm(x, groups, weight, bias, eps)

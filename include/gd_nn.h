@@ -89,6 +89,16 @@ int gd_nn_conv_force_split(int s);
  * of the whole batch picks.  k = 1 (default): each launch is tuned for the batch it gets. */
 int gd_nn_conv_set_route_scale(int k);
 
+/* gd_nn_groupnorm_silu_forward as ONE launch for inference on small feature maps (the UNet's GroupNorms at <= 16
+ * latents: diffusers ResnetBlock2D.norm1 / norm2, Transformer2DModel.norm, conv_norm_out): one workgroup per (image,
+ * group) holds its HW x C/G slice in registers -- x is read once, no workspace, no statistics output (the backward pass
+ * needs the two-pass form).  _supported: C % G == 0, C / G even, 4 <= C / G <= 128, HW * C / G <= 65536 elements
+ * (<= 32768 when C / G < 16: short channel runs load poorly)
+ * (the slice lives in the workgroup's registers). */
+int gd_nn_groupnorm_silu_fused_supported(int N, int HW, int C, int G);
+int gd_nn_groupnorm_silu_fused_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
+                                       int HW, int C, int G, float eps, int apply_silu);
+
 /* GroupNorm statistics only: mean_rstd[N][G][2] = {mean, 1/sqrt(var + eps)} of x (bf16 [N,HW,C]); stats_ws as in
  * gd_nn_groupnorm_silu_forward.  Feeds gd_nn_conv3x3_gn_forward (and gd_nn_groupnorm_silu_backward). */
 int gd_nn_groupnorm_stats(void* stream, const void* x, int N, int HW, int C, int G, float eps, double* stats_ws,

@@ -1,9 +1,12 @@
 """CPU checks of the SDS guidance algebra and the SD-2.1 restatement.
 
-The reference's guidance arithmetic lives in the un-vendored diffusers==0.19.0 + hub weights, so
-nothing here can be pinned against reference outputs ("parity unpinned"); these tests pin
-the algebra the reference file itself states (stable_diffusion_guidance.py:185-276,374-448), the
-published architecture facts and the analytic scheduler constants.
+The reference's network arithmetic lives in the un-vendored diffusers==0.19.0 + hub weights, so the
+NETWORK numerics cannot be pinned against reference outputs ("parity unpinned"); these tests
+check the algebra the reference file itself states (stable_diffusion_guidance.py:185-276,374-448), the
+published architecture facts and the analytic scheduler constants.  Since round 4 the reference's own
+Python around the networks (compute_grad_sds, __call__, the prompt-direction selection) IS pinned: it is run
+with stand-in networks by tests/golden/make_golden_guidance.py and the build is held to those vectors in
+tests/test_golden_fixtures.py.
 """
 import math
 

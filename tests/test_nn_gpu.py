@@ -34,6 +34,58 @@ def test_groupnorm_silu_matches_fp32_reference(N, C, H, W, silu):
     assert cos > 0.9995, cos
 
 
+@pytest.mark.parametrize("N,C,H,W,silu", [(2, 320, 32, 32, True), (16, 1280, 32, 32, True), (2, 1280, 8, 8, False),
+                                          (3, 2560, 16, 16, True), (2, 1920, 32, 32, True), (2, 960, 32, 32, True),
+                                          (2, 640, 32, 32, False), (1, 1920, 5, 7, True), (2, 128, 2, 2, True),
+                                          (4, 1280, 16, 16, True)])
+def test_one_launch_groupnorm_matches_fp32_reference_and_the_two_pass_kernels(N, C, H, W, silu):
+    """Inference GroupNorm(+SiLU) of the UNet's maps in ONE launch (gd_nn_groupnorm_silu_fused_forward: one workgroup
+    per (image, group), slice in registers) against fp32 torch at the GroupNorm bar, and against the two-pass
+    kernels it replaces: same coefficients up to the last bit of mean / rstd, so the bf16 outputs may differ by one
+    rounding step on a few elements, never more."""
+    from garmentdreamer_amd import nn_ops
+    assert nn_ops.lib().gd_nn_groupnorm_silu_fused_supported(N, H * W, C, 32) == 1
+    g = torch.Generator(DEV).manual_seed(C + H + N)
+    x = (torch.randn(N, C, H, W, device=DEV, generator=g) * 1.7 + 0.4).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, device=DEV, generator=g) * 0.5 + 1.0).to(torch.bfloat16)
+    b = (torch.randn(C, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
+    with torch.no_grad():
+        y = nn_ops.group_norm_silu(x, w, b, 32, 1e-5, silu)                 # no grad: the one-launch form
+        y2 = nn_ops._GroupNormSiLU.apply(x, w, b, 32, 1e-5, silu)           # statistics kernel + apply kernel
+        y_again = nn_ops.group_norm_silu(x, w, b, 32, 1e-5, silu)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y, y_again)                                          # no atomics: reproducible
+    yr = F.group_norm(x.float(), 32, w.float(), b.float(), 1e-5)
+    yr = F.silu(yr) if silu else yr
+    assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item() + 1e-2
+    d = (y.float() - y2.float()).abs()
+    ulp = torch.maximum(y2.float().abs(), torch.full_like(d, 2.0 ** -8)) * 2.0 ** -7      # one bf16 step at |y|
+    assert bool((d <= ulp).all()), float((d / ulp).max())
+    assert float((d > 0).float().mean()) < 2e-2
+    # a tensor that needs a gradient keeps the two-pass form (the backward pass reads mean / rstd)
+    xg = x.clone().requires_grad_(True)
+    yg = nn_ops.group_norm_silu(xg, w, b, 32, 1e-5, silu)
+    assert yg.grad_fn is not None and torch.equal(yg.detach(), y2)
+
+
+def test_one_launch_groupnorm_refuses_slices_that_do_not_fit_the_registers():
+    from garmentdreamer_amd import nn_ops
+    L = nn_ops.lib()
+    assert L.gd_nn_groupnorm_silu_fused_supported(2, 64 * 64, 640, 32) == 0        # 160 KB per (image, group)
+    assert L.gd_nn_groupnorm_silu_fused_supported(8, 512 * 512, 128, 32) == 0
+    assert L.gd_nn_groupnorm_silu_fused_supported(2, 64 * 64, 320, 32) == 0        # 10-channel runs: two-pass is level
+    assert L.gd_nn_groupnorm_silu_fused_supported(2, 64, 328, 41) == 1             # C / G = 8
+    assert L.gd_nn_groupnorm_silu_fused_supported(2, 64, 96, 32) == 0              # C / G odd
+    assert L.gd_nn_groupnorm_silu_fused_supported(2, 64, 64, 32) == 0              # C / G = 2
+    x = torch.zeros(2, 640, 64, 64, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.ones(640, device=DEV, dtype=torch.bfloat16)
+    ret = L.gd_nn_groupnorm_silu_fused_forward(torch.cuda.current_stream().cuda_stream, x.data_ptr(), x.data_ptr(), w.data_ptr(),
+                                               w.data_ptr(), 2, 64 * 64, 640, 32, 1e-5, 1)
+    assert ret == -1 and b"fused GroupNorm" in L.gd_nn_last_error()
+    with torch.no_grad():          # the dispatch falls back to the two-pass kernels
+        y = nn_ops.group_norm_silu(torch.randn_like(x), w, torch.zeros_like(w), 32, 1e-5, True)
+    assert torch.isfinite(y.float()).all()
+
 def test_groupnorm_workspace_is_shared_and_left_zero():
     """The statistics workspace is zero-initialised once per (device, stream) and every call must leave it zero
     (last-workgroup finalize + clear, include/gd_nn.h): interleave shapes, forward and backward, on one workspace,

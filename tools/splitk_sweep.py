@@ -5,7 +5,7 @@
 import sys
 import torch
 sys.path.insert(0, ".")
-import ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
+import tools.ablib  # noqa: F401,E402  (GD_NN_LIB / GD_RASTER_LIB -> use_library)
 import garmentdreamer_amd  # noqa: F401
 from garmentdreamer_amd import nn_ops
 from garmentdreamer_amd.nn_ops import conv3x3
