@@ -86,8 +86,6 @@ class StableDiffusionGuidance(nn.Module):
         super().__init__()
         cfg = cfg or {}
         self.cfg = cfg if isinstance(cfg, self.Config) else self.Config(**cfg)
-        if self.cfg.use_sjc:
-            raise NotImplementedError("score-jacobian-chaining is not on GarmentDreamer's path (use_sjc=False)")
         self.device = torch.device(device)
         self.configure(unet, vae)
 
@@ -118,6 +116,11 @@ class StableDiffusionGuidance(nn.Module):
         self.num_train_timesteps = self.scheduler.config.num_train_timesteps
         self.set_min_max_steps()
         self.alphas = self.scheduler.alphas_cumprod.to(self.device)
+        if self.cfg.use_sjc:
+            # score-jacobian chaining (:109-118, :132-134; off in GarmentDreamer's config): the reference swaps in a
+            # DDPMScheduler with the SAME scaled-linear betas 0.00085 .. 0.012, i.e. the same alphas_cumprod; only
+            # sigma_t = sqrt((1 - abar_t) / abar_t) is new
+            self.us = torch.sqrt((1 - self.alphas) / self.alphas)
         self.grad_clip_val: Optional[float] = None
         self._unet_graphs = {}
         self._vae_graphs = {}
@@ -285,6 +288,55 @@ class StableDiffusionGuidance(nn.Module):
                                "noise_pred": noise_pred}
         return grad, guidance_eval_utils
 
+    def compute_grad_sjc(self, latents, t, prompt_utils, elevation, azimuth, camera_distances,
+                         noise: Optional[torch.Tensor] = None):
+        """Score-jacobian-chaining form of the latent gradient (reference :278-372; ``use_sjc``, off in
+        GarmentDreamer's config): the latent is perturbed in the variance-EXPLODING parametrisation
+        ``z = y + sigma_t n``, the UNet sees ``z / sqrt(1 + sigma_t^2)``, and with the denoised estimate
+        ``D = z - sigma_t eps`` the gradient is ``-(D - y) / sigma_t`` (``var_red``) or ``-(D - z) / sigma_t``."""
+        use_perp_neg = bool(getattr(prompt_utils, "use_perp_neg", False))
+        batch_size = elevation.shape[0]
+        sigma = self.us[t].view(-1, 1, 1, 1)
+        neg_guidance_weights = None
+        if use_perp_neg:
+            text_embeddings, neg_guidance_weights = prompt_utils.get_text_embeddings_perp_neg(
+                elevation, azimuth, camera_distances, self.cfg.view_dependent_prompting)
+            reps = 4
+        else:
+            text_embeddings = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances,
+                                                               self.cfg.view_dependent_prompting)
+            reps = 2
+        with torch.no_grad():
+            if noise is None:
+                noise = torch.randn_like(latents)
+            y = latents
+            zs = y + sigma * noise
+            scaled_zs = zs / torch.sqrt(1 + sigma ** 2)
+            with nn_ops.route_batch(reps, reps * batch_size):
+                noise_pred = self.forward_unet(torch.cat([scaled_zs] * reps, dim=0), torch.cat([t] * reps),
+                                               encoder_hidden_states=text_embeddings)
+        if use_perp_neg:
+            noise_pred_text = noise_pred[:batch_size]
+            noise_pred_uncond = noise_pred[batch_size:batch_size * 2]
+            noise_pred_neg = noise_pred[batch_size * 2:]
+            e_pos = noise_pred_text - noise_pred_uncond
+            accum_grad = 0
+            n_negative_prompts = neg_guidance_weights.shape[-1]
+            for i in range(n_negative_prompts):
+                e_i_neg = noise_pred_neg[i::n_negative_prompts] - noise_pred_uncond
+                accum_grad = accum_grad + neg_guidance_weights[:, i].view(-1, 1, 1, 1).to(e_pos) * \
+                    perpendicular_component(e_i_neg, e_pos)
+            noise_pred = noise_pred_uncond + self.cfg.guidance_scale * (e_pos + accum_grad)
+        else:
+            noise_pred_text, noise_pred_uncond = noise_pred.chunk(2)
+            noise_pred = noise_pred_text + self.cfg.guidance_scale * (noise_pred_text - noise_pred_uncond)
+        Ds = zs - sigma * noise_pred
+        grad = -(Ds - y) / sigma if self.cfg.var_red else -(Ds - zs) / sigma
+        guidance_eval_utils = {"use_perp_neg": use_perp_neg, "neg_guidance_weights": neg_guidance_weights,
+                               "text_embeddings": text_embeddings, "t_orig": t, "latents_noisy": scaled_zs,
+                               "noise_pred": noise_pred}
+        return grad, guidance_eval_utils
+
     def __call__(self, rgb, prompt_utils, elevation, azimuth, camera_distances, rgb_as_latents=False,
                  guidance_eval=False, noise: Optional[torch.Tensor] = None, timesteps: Optional[torch.Tensor] = None,
                  vae_noise: Optional[torch.Tensor] = None, **kwargs):
@@ -305,8 +357,8 @@ class StableDiffusionGuidance(nn.Module):
         else:
             t = timesteps.to(device=self.device, dtype=torch.long)
 
-        grad, guidance_eval_utils = self.compute_grad_sds(latents, t, prompt_utils, elevation, azimuth,
-                                                          camera_distances, noise)
+        compute_grad = self.compute_grad_sjc if self.cfg.use_sjc else self.compute_grad_sds
+        grad, guidance_eval_utils = compute_grad(latents, t, prompt_utils, elevation, azimuth, camera_distances, noise)
         grad = torch.nan_to_num(grad)
         if self.grad_clip_val is not None:
             grad = grad.clamp(-self.grad_clip_val, self.grad_clip_val)

@@ -242,6 +242,46 @@ def test_guidance_call_reproduces_the_reference_guidance_code():
         assert np.abs(rgb.grad.numpy() - ref_g).max() <= 5e-5 * np.abs(ref_g).max(), name
 
 
+def test_guidance_sjc_branch_reproduces_the_reference_code():
+    """``use_sjc``: ``compute_grad_sjc`` (variance-exploding perturbation, the scaled UNet input, both forms of the
+    gradient, the Perp-Neg combination) and ``__call__`` around it against outputs of the reference's own functions
+    (stable_diffusion_guidance.py:278-372, 409-412; tests/golden/make_golden_guidance_sjc.py)."""
+    from garmentdreamer_amd.guidance.stable_diffusion_guidance import PromptEmbeddings, StableDiffusionGuidance
+    z0, z = _guidance_pins(), np.load(os.path.join(G, "guidance_sjc_pins.npz"))
+    el, az, dist = (torch.from_numpy(z0[k]) for k in ("elevation", "azimuth", "camera_distances"))
+    t, noise = torch.from_numpy(z["t"]), torch.from_numpy(z["noise"])
+    for name in ("sjc_varred", "sjc_plain_clip", "sjc_perpneg"):
+        scale, clip, var_red = (float(v) for v in z[name + "/cfg"])
+        gd = StableDiffusionGuidance({"guidance_scale": scale, "grad_clip": None, "half_precision_weights": False,
+                                      "use_sjc": True, "var_red": bool(var_red)},
+                                     device="cpu", unet=_PinUNet(), vae=_PinVAE())
+        gd.grad_clip_val = None if clip < 0 else clip
+        prompt = PromptEmbeddings(torch.from_numpy(z[name + "/text_vd"]), torch.from_numpy(z[name + "/uncond_vd"]))
+        prompt.use_perp_neg = name.endswith("perpneg")
+        rgb = torch.from_numpy(z0["rgb"]).clone().requires_grad_(True)
+        seen = {}
+        inner = gd.compute_grad_sjc
+
+        def spy(*a, **k):
+            gr, u = inner(*a, **k)
+            seen["grad"], seen["u"] = gr, u
+            return gr, u
+        gd.compute_grad_sjc = spy
+        out = gd(rgb, prompt, el, az, dist, noise=noise, timesteps=t, vae_noise=torch.zeros_like(noise))
+        out["loss_sds"].backward()
+        u = seen["u"]
+        for key, val in (("latents_noisy", u["latents_noisy"]), ("noise_pred", u["noise_pred"]), ("grad", seen["grad"])):
+            sub, mom = _sub_and_moments(val)
+            ref_sub, ref_mom = z[f"{name}/{key}_sub"], z[f"{name}/{key}_moments"]
+            scale_ = np.abs(ref_sub).max()
+            assert np.abs(sub - ref_sub).max() <= 2e-5 * scale_, (name, key, np.abs(sub - ref_sub).max(), scale_)
+            assert np.allclose(mom, ref_mom, rtol=5e-5), (name, key, mom, ref_mom)
+        assert abs(out["loss_sds"].item() - float(z[name + "/loss_sds"])) <= 2e-5 * float(z[name + "/loss_sds"]), name
+        assert abs(out["grad_norm"].item() - float(z[name + "/grad_norm"])) <= 2e-5 * float(z[name + "/grad_norm"]), name
+        ref_g = z[name + "/dloss_drgb"]
+        assert np.abs(rgb.grad.numpy() - ref_g).max() <= 5e-5 * np.abs(ref_g).max(), name
+
+
 def test_direction_rules_match_the_reference_prompt_processor():
     """front / side / back / overhead selection at the thresholds and across the azimuth wrap, against the index the
     reference's own DirectionConfig lambdas assign (prompt_processors/base.py:222-290 through get_text_embeddings)."""
