@@ -232,7 +232,7 @@ def vsd_main(args):
         lu = gd.lora_train_loss(q, latents, pose, shading="albedo", unet_bs=1)
         opt.zero_grad(set_to_none=True)
         lu.backward()
-        if ws > 1:
+        if gdist.collectives_on():
             grads = [p.grad for p in train if p.grad is not None]
             if bucket is None:
                 bucket = gdist.GradBucket(grads)

@@ -10,8 +10,11 @@ exactly:
     [all parameter grads | summed viewspace grads], scaled by 1/N so the result equals the
     single-GPU gradient (``loss_sds`` is normalised by the LOCAL batch size,
     stable_diffusion_guidance.py:427, and every rank holds V/N views);
-  * one all-reduce(max) of ``radii`` (int32);
-  * a scalar max-all-reduce for ``depths.max()`` (+ its scalar sum in backward).
+  * ONE all-reduce(max) of an int32 buffer [``radii`` | bits of this rank's ``depths.max()``], started
+    asynchronously right after the rasterizer's forward pass and waited on where its first consumer (the sparsity
+    head, after the guidance forward) runs: it overlaps the VAE / UNet work (round 4; rounds 1-3 ran a blocking
+    scalar max after the render and a blocking radii max after the backward pass);
+  * a scalar sum in the backward pass of the depth maximum (the gradient goes to the rank that owns it).
 xGMI is point-to-point, so per-iteration traffic is kept to one ~7 MB bucket (P = 100k) instead
 of one collective per parameter tensor.  Parameters and optimizer state are replicated.
 """
@@ -30,6 +33,13 @@ def is_dist() -> bool:
 
 def world_size() -> int:
     return dist.get_world_size() if is_dist() else 1
+
+
+def collectives_on() -> bool:
+    """True when the loop must run its collectives: a group of more than one rank, or the one-rank group of
+    ``GD_DIST_SINGLE=1`` (hardware check of the RCCL path of every collective on a single-GPU box: with one rank each
+    of them is an identity, but it is issued on the "nccl" backend with the loop's tensors, dtypes and streams)."""
+    return is_dist() and (dist.get_world_size() > 1 or os.environ.get("GD_DIST_SINGLE") == "1")
 
 
 def rank() -> int:
@@ -89,7 +99,51 @@ class _GlobalMax(torch.autograd.Function):
 
 
 def global_max(local_max: torch.Tensor) -> torch.Tensor:
-    return _GlobalMax.apply(local_max) if world_size() > 1 else local_max
+    return _GlobalMax.apply(local_max) if collectives_on() else local_max
+
+
+class _GlobalMaxKnown(torch.autograd.Function):
+    """``_GlobalMax`` whose forward collective has already run (``PendingMax``): only the backward sum is left."""
+
+    @staticmethod
+    def forward(ctx, local_max: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+        ctx.save_for_backward(local_max.detach() >= g)
+        return g.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (is_owner,) = ctx.saved_tensors
+        g = grad_out.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return torch.where(is_owner, g, torch.zeros_like(g)), None
+
+
+class PendingMax:
+    """One asynchronous all-reduce(max) carrying the per-Gaussian ``radii`` (int32, max over this rank's views) AND
+    this rank's ``depths.max()``: a non-negative fp32 value orders like its bit pattern read as int32, so the scalar
+    rides in the tail slot of the integer buffer.  ``start`` right after the rasterizer's forward pass, ``finish``
+    where the results are first needed -- the collective then runs beside the guidance forward on RCCL's stream."""
+
+    def __init__(self, radii_local: torch.Tensor, local_max: torch.Tensor):
+        if radii_local.dtype != torch.int32 or local_max.dtype != torch.float32:
+            raise TypeError("PendingMax: radii must be int32 and the depth maximum fp32")
+        self.local_max = local_max
+        self.n = radii_local.numel()
+        # clamp: a negative zero / negative value would order wrongly as an integer (depths are sums of w * depth >= 0)
+        tail = local_max.detach().clamp_min(0.0).reshape(1).view(torch.int32)
+        self.buf = torch.cat([radii_local.reshape(-1), tail])
+        self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.MAX, async_op=True) if collectives_on() else None
+
+    def finish(self):
+        """-> (radii max over every rank's views [P] int32, global depth maximum attached to the autograd graph)."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        g = self.buf[self.n:].view(torch.float32).reshape(())
+        radii = self.buf[:self.n]
+        if collectives_on():
+            return radii, _GlobalMaxKnown.apply(self.local_max, g)
+        return radii, self.local_max
 
 
 class _ScaleGrad(torch.autograd.Function):
@@ -122,7 +176,7 @@ class GradBucket:
 
     def all_reduce_mean_(self, tensors: Sequence[torch.Tensor]) -> None:
         ws = world_size()
-        if ws == 1:
+        if not collectives_on():
             return
         views = self.flat.split(self.numels)
         torch._foreach_copy_(list(views), [t.reshape(-1) for t in tensors])
@@ -134,14 +188,15 @@ class GradBucket:
 def all_reduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     """In-place all-reduce(sum) x 1/N of an already flat, contiguous buffer (``GaussianModel.grad_bucket``)."""
     ws = world_size()
-    if ws > 1:
+    if collectives_on():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.mul_(1.0 / ws)
+        if ws > 1:
+            flat.mul_(1.0 / ws)
     return flat
 
 
 def all_reduce_max_(t: torch.Tensor) -> torch.Tensor:
-    if world_size() > 1:
+    if collectives_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 

@@ -33,6 +33,10 @@ class _RenderOut(dict):
     materialised only if somebody reads it -- the loop's sparsity loss uses the fused head (nn_ops.sparsity_loss)."""
 
     def __missing__(self, key):
+        if key in ("depth_max", "radii_all") and dict.__contains__(self, "_pending_max"):
+            # sharded run: the asynchronous [radii | depth maximum] collective started by render_views ends here
+            self["radii_all"], self["depth_max"] = dict.pop(self, "_pending_max").finish()
+            return self[key]
         if key == "opacity":
             v = self["depth"] / (self["depth_max"] + 1e-5)
             self[key] = v
@@ -125,9 +129,15 @@ class SDSLoop:
         pkg = self.render_batch_fn(CameraBatch(cams, dev), self.gaussians, self.bg)
         images = pkg["render"].permute(0, 2, 3, 1)      # [V,H,W,3]
         depths = pkg["depth_3dgs"].permute(0, 2, 3, 1)  # [V,H,W,1]
-        dmax = gdist.global_max(depths.max())
-        return _RenderOut({**pkg, "comp_rgb": images, "depth": depths, "depth_max": dmax,
-                           "alphas": pkg["alpha"].permute(0, 2, 3, 1)})
+        out = _RenderOut({**pkg, "comp_rgb": images, "depth": depths, "alphas": pkg["alpha"].permute(0, 2, 3, 1)})
+        local_max = depths.max()
+        if gdist.collectives_on():
+            # ONE asynchronous max over the ranks for [radii | depth maximum]; finished in step() after the guidance
+            # forward, which it overlaps (dist.PendingMax)
+            out["_pending_max"] = gdist.PendingMax(pkg["radii"].max(dim=0).values, local_max)
+        else:
+            out["depth_max"] = local_max
+        return out
 
     # -- one iteration ----------------------------------------------------------------------------
     def step(self, batch: Dict, noise=None, timesteps=None, vae_noise=None) -> Dict:
@@ -149,6 +159,7 @@ class SDSLoop:
                               timesteps=timesteps, vae_noise=vae_noise)
         loss_sds = g_out["loss_sds"]
         from . import nn_ops
+        radii_all = out.get("radii_all")       # sharded run: max over every rank's views (finishes the pending collective)
         loss_sparsity = nn_ops.sparsity_loss(out["depth"], out["depth_max"])   # mean(sqrt(opacity^2 + 0.01)), :253
         loss = loss_sds * self.lambda_sds + loss_sparsity * self.lambda_sparsity
         if self.native_scene:
@@ -159,15 +170,14 @@ class SDSLoop:
 
         densified = False
         with torch.no_grad():
-            radii = out["radii"].max(dim=0).values
+            radii = out["radii"].max(dim=0).values if radii_all is None else radii_all
             if self.native_scene:
                 # every parameter's .grad is a view into the scene's bucket; the view-summed viewspace gradient
                 # lands in its tail, so ONE in-place all-reduce carries everything (no staging copies)
                 vs_grad = self.gaussians.viewspace_grad
                 torch.sum(out["viewspace_points"].grad, dim=0, out=vs_grad)
-                if gdist.world_size() > 1:
+                if gdist.collectives_on():
                     gdist.all_reduce_mean_(self.gaussians.grad_bucket)
-                    gdist.all_reduce_max_(radii)
                 if self.global_step < 900:
                     self.gaussians.add_densification_stats(vs_grad, radii)
                     if self.densify and self.global_step > 300 and self.global_step % 100 == 0:
@@ -180,12 +190,11 @@ class SDSLoop:
                 grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
                 for p, g in zip(self.params, grads):
                     p.grad = g
-                if gdist.world_size() > 1:
+                if gdist.collectives_on():
                     tensors = grads + [vs_grad]
                     if self._bucket is None or not self._bucket.matches(tensors):
                         self._bucket = gdist.GradBucket(tensors)
                     self._bucket.all_reduce_mean_(tensors)
-                    gdist.all_reduce_max_(radii)
                 self._densification_stats(vs_grad, radii)
         if self.native_scene:
             # after densify_and_prune the gradient buffer is fresh (zeros) and the Adam moments of the surviving

@@ -143,6 +143,14 @@ def _gmax_worker(rank, world, port, ret):
     loss = (x / (m + 1e-5)).sum()
     loss.backward()
     ret[rank] = (float(m), x.grad.clone())
+    # the same maximum riding in the tail slot of the asynchronous radii collective (PendingMax)
+    x2 = x.detach().clone().requires_grad_(True)
+    radii = torch.tensor([3, 0, 7, 1] if rank == 0 else [2, 9, 0, 1], dtype=torch.int32)
+    pend = gdist.PendingMax(radii, x2.max())
+    side = (x2 * 2.0).sum()                       # work between start and finish
+    radii_all, m2 = pend.finish()
+    ((x2 / (m2 + 1e-5)).sum() + 0.0 * side).backward()
+    ret[f"p{rank}"] = (float(m2), x2.grad.clone(), radii_all.clone())
     b = gdist.GradBucket([torch.zeros(3), torch.zeros(2, 2)])
     a1, a2 = torch.full((3,), float(rank + 1)), torch.full((2, 2), 10.0 * (rank + 1))
     b.all_reduce_mean_([a1, a2])
@@ -159,6 +167,9 @@ def test_global_max_routes_gradient_to_owner_and_bucket_averages():
     (x / (x.max() + 1e-5)).sum().backward()
     assert ret[0][0] == 5.0 and ret[1][0] == 5.0
     assert torch.allclose(torch.cat([ret[0][1], ret[1][1]]), x.grad, rtol=1e-6)
+    for r in (0, 1):
+        m2, g2, radii_all = ret[f"p{r}"]
+        assert m2 == 5.0 and torch.equal(g2, ret[r][1]) and radii_all.tolist() == [3, 9, 7, 1]
     for r in (0, 1):
         a1, a2 = ret[f"b{r}"]
         assert torch.equal(a1, torch.full((3,), 1.5)) and torch.equal(a2, torch.full((2, 2), 15.0))
