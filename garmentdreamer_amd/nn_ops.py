@@ -58,6 +58,10 @@ SIGNATURES = {
     "gd_nn_conv3x3_wino_weights_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_wino_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_conv3x3_wino_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gd_nn_conv3x3_regw_supported": (_i, [_i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_regw_weights": (_i, [_vp, _vp, _vp]),
+    "gd_nn_conv3x3_regw_weights_bytes": (C.c_size_t, []),
+    "gd_nn_conv3x3_regw_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_conv3x3_wide_supported": (_i, [_i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_wide_weights": (_i, [_vp, _vp, _vp, _i, _i]),
     "gd_nn_conv3x3_wide_weights_bytes": (C.c_size_t, [_i, _i]),
@@ -401,6 +405,37 @@ def _wino_launch(x, w_khwc, bias, residual, out_channels, stat_part=None):
                                            None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
                                            out_channels, None if stat_part is None else stat_part.data_ptr())
     _check(ret, "gd_nn_conv3x3_wino_forward", "gd_nn_conv_last_error")
+    return y
+
+
+def _regw(weight):
+    """Cached re-packing of a frozen 128 -> 128 conv weight as the register fragments of csrc/nn_conv_regw.h."""
+    u = getattr(weight, "_gd_regw", None)
+    key = (weight.data_ptr(), weight._version)
+    if u is None or u.device != weight.device or getattr(weight, "_gd_regw_key", None) != key:
+        u = torch.empty(lib().gd_nn_conv3x3_regw_weights_bytes() // 2, dtype=torch.bfloat16, device=weight.device)
+        with torch.cuda.device(weight.device):
+            ret = lib().gd_nn_conv3x3_regw_weights(torch.cuda.current_stream(weight.device).cuda_stream,
+                                                   weight.data_ptr(), u.data_ptr())
+        _check(ret, "gd_nn_conv3x3_regw_weights", "gd_nn_conv_last_error")
+        weight._gd_regw, weight._gd_regw_key = u, key
+    return u
+
+
+def _regw_launch(x, w_khwc, bias, residual, out_channels, stat_part=None):
+    """3x3/s1/p1 convolution, 128 -> 128 channels, filter bank resident in registers (csrc/nn_conv_regw.h).  Not on the
+    default route (parity with the wide tile); tools/regw_conv_bench.py and the GPU tests call it."""
+    N, Cin, H, W = x.shape
+    L = lib()
+    y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    bias, stride = _bias_and_stride(bias)
+    u = _regw(w_khwc)
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_conv3x3_regw_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), u.data_ptr(),
+                                           None if bias is None else bias.data_ptr(), stride,
+                                           None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
+                                           out_channels, None if stat_part is None else stat_part.data_ptr())
+    _check(ret, "gd_nn_conv3x3_regw_forward", "gd_nn_conv_last_error")
     return y
 
 

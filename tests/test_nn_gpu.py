@@ -1091,6 +1091,44 @@ def test_winograd_and_wide_tile_convolutions_match_fp32_reference(kernel, N, Cin
     assert ((got - want).abs().max() / want.abs().max()).item() < 1e-5
 
 
+
+@pytest.mark.parametrize("N,H,W,per_image_bias,stats", [(1, 16, 32, False, False), (2, 48, 96, True, True), (3, 80, 64, False, True),
+                                                        (8, 128, 128, False, False), (1, 272, 160, True, True)])
+def test_register_resident_filter_convolution_matches_fp32_reference(N, H, W, per_image_bias, stats):
+    """The 128 -> 128 convolution with the filter bank resident in registers (csrc/nn_conv_regw.h; an entry point that is
+    NOT on the default route) through the C-ABI against fp32 PyTorch: one and several vertical segments,
+    image-edge strips, per-image bias, and the epilogue's GroupNorm partial sums (every row written, sums of the stored
+    tensor).  Bar: the direct bf16 kernels' (2e-2 of scale, cos > 0.9995)."""
+    from garmentdreamer_amd import nn_ops
+    C = 128
+    assert nn_ops.lib().gd_nn_conv3x3_regw_supported(N, H, W, C, C) == 1
+    assert nn_ops.lib().gd_nn_conv3x3_regw_supported(N, H, W + 8, C, C) == 0
+    g = torch.Generator(DEV).manual_seed(N * 131 + H)
+    cl = torch.channels_last
+    x = (torch.randn(N, C, H, W, device=DEV, generator=g) * 1.5 + 0.3).to(torch.bfloat16).contiguous(memory_format=cl)
+    w = (torch.randn(C, C, 3, 3, device=DEV, generator=g) / (3 * C ** 0.5)).to(torch.bfloat16).contiguous(memory_format=cl)
+    b = (torch.randn(N, C, device=DEV, generator=g) if per_image_bias else torch.randn(C, device=DEV, generator=g)).to(torch.bfloat16)
+    rows = (H // 16) * ((W + 15) // 16) * 8
+    part = torch.full((N * (C // 4) * rows * 2,), float("nan"), dtype=torch.float32, device=DEV) if stats else None
+    with torch.no_grad():
+        ref = F.conv2d(x.float(), w.float(), None, padding=1)
+        ref = ref + (b.float()[:, :, None, None] if per_image_bias else b.float()[None, :, None, None])
+        y = nn_ops._regw_launch(x, w, b, None, C, part)
+        y2 = nn_ops._regw_launch(x, w, b, None, C, part)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=cl) and torch.equal(y, y2)
+    err = ((y.float() - ref).abs().max() / ref.abs().max()).item()
+    cos = F.cosine_similarity(y.float().flatten(), ref.flatten(), dim=0).item()
+    assert err < 2e-2 and cos > 0.9995, (err, cos)
+    if stats:
+        assert torch.isfinite(part).all()
+        got = part.view(N, C // 4, rows, 2).double().sum(2)
+        yq = y.float().double().view(N, C // 4, 4, H * W)
+        want = torch.stack([yq.sum((2, 3)), (yq * yq).sum((2, 3))], -1)
+        assert ((got - want).abs().max() / want.abs().max()).item() < 1e-5
+    with pytest.raises(RuntimeError):
+        nn_ops._regw_launch(x, w, b, x, C)           # no residual form
+
+
 def test_conv_routing_picks_the_measured_kernel_and_all_routes_agree():
     """nn_ops._conv_route (the per-shape table of tools/wino_route_bench.py) and the three kernels behind it give the
     same convolution: direct (GD_NN_WINO=0 behaviour), Winograd, wide tile on one shape each route serves."""
