@@ -792,14 +792,58 @@ class _SchedulerConfig:
 
 class DDIMScheduler:
     """The subset the guidance uses: ``alphas_cumprod``, ``config.num_train_timesteps``, ``add_noise``
-    (stable_diffusion_guidance.py:129-131,238).  scaled_linear betas, 1000 steps."""
+    (stable_diffusion_guidance.py:129-131,238) and, for the ``guidance_eval`` previews (:505-579), ``set_timesteps`` /
+    ``timesteps`` / ``step`` -- the published DDIM update (Song et al. 2021, eq. 12) with the SD-2.1 scheduler config
+    (scaled_linear betas, 1000 steps, "leading" spacing, ``steps_offset`` 1, ``set_alpha_to_one`` False, no sample
+    clipping).  diffusers is absent: scheduler numerics are restated, not pinned."""
 
-    def __init__(self, beta_start=0.00085, beta_end=0.012, num_train_timesteps=1000, prediction_type="epsilon"):
+    def __init__(self, beta_start=0.00085, beta_end=0.012, num_train_timesteps=1000, prediction_type="epsilon",
+                 steps_offset=1):
         self.config = _SchedulerConfig()
         self.config.num_train_timesteps = num_train_timesteps
         self.config.prediction_type = prediction_type
+        self.config.steps_offset = steps_offset
         betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]         # set_alpha_to_one = False
+        self.num_inference_steps = None
+        self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1, dtype=torch.long)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        """"leading" spacing: multiples of T / n, descending, shifted by ``steps_offset``."""
+        self.num_inference_steps = int(num_inference_steps)
+        ratio = self.config.num_train_timesteps // self.num_inference_steps
+        ts = (torch.arange(0, self.num_inference_steps, dtype=torch.long) * ratio).flip(0) + self.config.steps_offset
+        self.timesteps = ts.to(device) if device is not None else ts
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, generator=None, variance_noise=None):
+        """One reverse step x_t -> x_{t - T/n}: ``{"prev_sample", "pred_original_sample"}``.  ``eta`` scales the DDIM
+        variance sigma_t^2 = (1 - abar_prev) / (1 - abar_t) (1 - abar_t / abar_prev); eta = 1 is the DDPM-like sampler."""
+        if self.num_inference_steps is None:
+            raise ValueError("DDIMScheduler.step: call set_timesteps first")
+        t = int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        ac = self.alphas_cumprod.to(device=sample.device, dtype=torch.float32)
+        a_t = ac[t]
+        a_prev = ac[prev_t] if prev_t >= 0 else self.final_alpha_cumprod.to(sample.device)
+        b_t = 1 - a_t
+        if self.config.prediction_type == "epsilon":
+            x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+            eps = model_output
+        elif self.config.prediction_type == "v_prediction":
+            x0 = a_t ** 0.5 * sample - b_t ** 0.5 * model_output
+            eps = a_t ** 0.5 * model_output + b_t ** 0.5 * sample
+        else:
+            raise ValueError(f"prediction_type {self.config.prediction_type}")
+        variance = (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)
+        std = eta * variance ** 0.5
+        prev = a_prev ** 0.5 * x0 + (1 - a_prev - std ** 2) ** 0.5 * eps
+        if eta > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator, device=model_output.device,
+                                             dtype=model_output.dtype)
+            prev = prev + std * variance_noise
+        return {"prev_sample": prev.to(sample.dtype), "pred_original_sample": x0.to(sample.dtype)}
 
     def add_noise(self, original_samples, noise, timesteps):
         ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)

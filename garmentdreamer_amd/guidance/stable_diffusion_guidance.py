@@ -367,9 +367,87 @@ class StableDiffusionGuidance(nn.Module):
         guidance_out = {"loss_sds": loss_sds, "grad_norm": grad.norm(), "min_step": self.min_step,
                         "max_step": self.max_step}
         if guidance_eval:
-            raise NotImplementedError("guidance_eval previews need the VAE decoder, which is off GarmentDreamer's "
-                                      "path (GaussianDreamer.py:244 passes guidance_eval=False)")
+            # debugging previews (:436-446; GaussianDreamer.py:244 passes guidance_eval=False)
+            guidance_eval_out = self.guidance_eval(**guidance_eval_utils, generator=kwargs.get("eval_generator"))
+            texts = []
+            for n, e, a, c in zip(guidance_eval_out["noise_levels"], elevation, azimuth, camera_distances):
+                texts.append(f"n{n:.02f}\ne{e.item():.01f}\na{a.item():.01f}\nc{c.item():.02f}")
+            guidance_eval_out.update({"texts": texts})
+            guidance_out.update({"eval": guidance_eval_out})
         return guidance_out
+
+    def decode_latents(self, latents, latent_height: int = 64, latent_width: int = 64):
+        """latents -> [B, 3, 8 h, 8 w] image in [0, 1] (:170-183).  The VAE DECODER is not part of the per-iteration path and
+        not restated in sd21: a VAE object that has ``decode`` (e.g. diffusers' AutoencoderKL) must be supplied."""
+        if not hasattr(self.vae, "decode"):
+            raise RuntimeError("guidance_eval needs a VAE with a decoder (pass vae=<object with .decode>); the restated "
+                               "AutoencoderKLEncoder has the encoder half only")
+        input_dtype = latents.dtype
+        latents = F.interpolate(latents, (latent_height, latent_width), mode="bilinear", align_corners=False)
+        latents = 1 / self.vae.config.scaling_factor * latents
+        image = self.vae.decode(latents.to(self.weights_dtype)).sample
+        image = (image * 0.5 + 0.5).clamp(0, 1)
+        return image.to(input_dtype)
+
+    @torch.no_grad()
+    def get_noise_pred(self, latents_noisy, t, text_embeddings, use_perp_neg=False, neg_guidance_weights=None):
+        """Guided noise prediction of ONE timestep for the preview sampler (:452-501)."""
+        batch_size = latents_noisy.shape[0]
+        reps = 4 if use_perp_neg else 2
+        noise_pred = self.forward_unet(torch.cat([latents_noisy] * reps, dim=0),
+                                       torch.cat([t.reshape(1)] * reps).to(self.device),
+                                       encoder_hidden_states=text_embeddings)
+        if use_perp_neg:
+            noise_pred_text = noise_pred[:batch_size]
+            noise_pred_uncond = noise_pred[batch_size:batch_size * 2]
+            noise_pred_neg = noise_pred[batch_size * 2:]
+            e_pos = noise_pred_text - noise_pred_uncond
+            accum_grad = 0
+            n_negative_prompts = neg_guidance_weights.shape[-1]
+            for i in range(n_negative_prompts):
+                e_i_neg = noise_pred_neg[i::n_negative_prompts] - noise_pred_uncond
+                accum_grad = accum_grad + neg_guidance_weights[:, i].view(-1, 1, 1, 1).to(e_pos) * \
+                    perpendicular_component(e_i_neg, e_pos)
+            return noise_pred_uncond + self.cfg.guidance_scale * (e_pos + accum_grad)
+        noise_pred_text, noise_pred_uncond = noise_pred.chunk(2)
+        return noise_pred_text + self.cfg.guidance_scale * (noise_pred_text - noise_pred_uncond)
+
+    @torch.no_grad()
+    def guidance_eval(self, t_orig, text_embeddings, latents_noisy, noise_pred, use_perp_neg=False,
+                      neg_guidance_weights=None, generator=None):
+        """Previews of what the guidance "sees" (:505-579): the noisy latent, its one-step denoising, the predicted clean
+        image, and the result of running the 50-step sampler (eta = 1) to the end from the nearest of its timesteps."""
+        self.scheduler.set_timesteps(50)
+        timesteps_dev = self.scheduler.timesteps.to(self.device)
+        bs = min(self.cfg.max_items_eval, latents_noisy.shape[0]) if self.cfg.max_items_eval > 0 else latents_noisy.shape[0]
+        large_enough_idxs = timesteps_dev.expand([bs, -1]) > t_orig[:bs].unsqueeze(-1)      # [bs, 50] > [bs, 1]
+        idxs = torch.min(large_enough_idxs, dim=1)[1]
+        t = timesteps_dev[idxs]
+        fracs = list((t / self.scheduler.config.num_train_timesteps).cpu().numpy())
+        imgs_noisy = self.decode_latents(latents_noisy[:bs]).permute(0, 2, 3, 1)
+        latents_1step, pred_1orig = [], []
+        for b in range(bs):
+            step_output = self.scheduler.step(noise_pred[b:b + 1], t[b], latents_noisy[b:b + 1], eta=1, generator=generator)
+            latents_1step.append(step_output["prev_sample"])
+            pred_1orig.append(step_output["pred_original_sample"])
+        latents_1step = torch.cat(latents_1step)
+        pred_1orig = torch.cat(pred_1orig)
+        imgs_1step = self.decode_latents(latents_1step).permute(0, 2, 3, 1)
+        imgs_1orig = self.decode_latents(pred_1orig).permute(0, 2, 3, 1)
+        latents_final = []
+        for b, i in enumerate(idxs):
+            latents = latents_1step[b:b + 1]
+            sel = [b, b + len(idxs), b + 2 * len(idxs), b + 3 * len(idxs)] if use_perp_neg else [b, b + len(idxs)]
+            text_emb = text_embeddings[sel, ...]
+            neg_guid = neg_guidance_weights[b:b + 1] if use_perp_neg else None
+            for tt in self.scheduler.timesteps[int(i) + 1:]:
+                npred = self.get_noise_pred(latents, tt, text_emb, use_perp_neg, neg_guid)
+                latents = self.scheduler.step(npred, tt, latents, eta=1, generator=generator)["prev_sample"]
+            latents_final.append(latents)
+        latents_final = torch.cat(latents_final)
+        imgs_final = self.decode_latents(latents_final).permute(0, 2, 3, 1)
+        return {"bs": bs, "noise_levels": fracs, "imgs_noisy": imgs_noisy, "imgs_1step": imgs_1step,
+                "imgs_1orig": imgs_1orig, "imgs_final": imgs_final}
 
     def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
         if self.cfg.grad_clip is not None:

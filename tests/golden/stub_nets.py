@@ -25,3 +25,12 @@ def q_unet_fn(x, t, ctx, pose, shading):
     """Stand-in for the pose-conditioned LoRA UNet of the NeTF stage (v-prediction output)."""
     s = {"albedo": 1.0, "normal": 0.5, "textureless": 0.25}.get(shading, 2.0)
     return (0.6 * unet_fn(x, t, ctx).float() - 0.1 * x.float() + 0.05 * s * pose.float().mean(dim=1).view(-1, 1, 1, 1)).to(x.dtype)
+
+
+_UNMIX = torch.tensor([[0.6, 0.1, -0.3, 0.2], [-0.2, 0.7, 0.1, 0.2], [0.3, -0.4, 0.5, 0.2]])
+
+
+def vae_decode(latents):
+    """Stand-in decoder for the guidance_eval previews: a 4 -> 3 channel mix, tanh, 8x nearest upsampling ([-1, 1] image)."""
+    img = torch.tanh(torch.einsum("oc,bchw->bohw", _UNMIX.to(latents.float()), latents.float()))
+    return torch.nn.functional.interpolate(img, scale_factor=8, mode="nearest").to(latents.dtype)

@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from garmentdreamer_amd import cameras as gcam
@@ -280,6 +281,46 @@ def test_guidance_sjc_branch_reproduces_the_reference_code():
         assert abs(out["grad_norm"].item() - float(z[name + "/grad_norm"])) <= 2e-5 * float(z[name + "/grad_norm"]), name
         ref_g = z[name + "/dloss_drgb"]
         assert np.abs(rgb.grad.numpy() - ref_g).max() <= 5e-5 * np.abs(ref_g).max(), name
+
+
+def test_guidance_eval_previews_reproduce_the_reference_code():
+    """``guidance_eval=True``: nearest-of-50 timestep search, one-step and full eta = 1 sampling per sample, the embedding
+    rows picked per sample (plain and Perp-Neg), ``max_items_eval``, ``decode_latents`` and the preview dict with its texts
+    against the reference's own ``guidance_eval`` / ``get_noise_pred`` (stable_diffusion_guidance.py:436-446, 452-579) run
+    on the stub networks with an independently written DDIM step (tests/golden/make_golden_guidance_eval.py)."""
+    from garmentdreamer_amd.guidance.stable_diffusion_guidance import PromptEmbeddings, StableDiffusionGuidance
+    from tests.golden import stub_nets
+    import types
+    z0, z = _guidance_pins(), np.load(os.path.join(G, "guidance_eval_pins.npz"))
+    el, az, dist = (torch.from_numpy(z0[k]) for k in ("elevation", "azimuth", "camera_distances"))
+
+    class VAE(_PinVAE):
+        def decode(self, lat):
+            return types.SimpleNamespace(sample=stub_nets.vae_decode(lat))
+    for name in ("eval_cfg", "eval_perpneg"):
+        gd = StableDiffusionGuidance({"guidance_scale": 7.5, "half_precision_weights": False,
+                                      "max_items_eval": int(z[name + "/max_items_eval"])},
+                                     device="cpu", unet=_PinUNet(), vae=VAE())
+        prompt = PromptEmbeddings(torch.from_numpy(z[name + "/text_vd"]), torch.from_numpy(z[name + "/uncond_vd"]))
+        prompt.use_perp_neg = name.endswith("perpneg")
+        noise = torch.from_numpy(z[name + "/noise"])
+        out = gd(torch.from_numpy(z0["rgb"]).clone(), prompt, el, az, dist, noise=noise, timesteps=torch.from_numpy(z[name + "/t"]),
+                 vae_noise=torch.zeros_like(noise), guidance_eval=True, eval_generator=torch.Generator().manual_seed(99))
+        ev = out["eval"]
+        assert ev["bs"] == int(z[name + "/bs"])
+        assert np.allclose(np.array([float(v) for v in ev["noise_levels"]]), z[name + "/noise_levels"], rtol=0, atol=1e-6)
+        assert list(ev["texts"]) == [str(t) for t in z[name + "/texts"]]
+        for key in ("imgs_noisy", "imgs_1step", "imgs_1orig", "imgs_final"):
+            assert list(ev[key].shape) == z[f"{name}/{key}_shape"].tolist(), key
+            got = ev[key][:, 3::32, 5::32, :].numpy()
+            # images in [0, 1]; the multi-step result goes through up to five guided sampler steps (fp32 here, the fixture's
+            # scheduler in fp64, Perp-Neg projections in between): measured 1.3e-3
+            bar = 5e-3 if key == "imgs_final" else 2e-4
+            assert np.abs(got - z[f"{name}/{key}_sub"]).max() < bar, (name, key, np.abs(got - z[f"{name}/{key}_sub"]).max())
+    # the restated encoder-only VAE has no decoder: a clear error, not an AttributeError deep inside
+    gd = StableDiffusionGuidance({"half_precision_weights": False}, device="cpu", unet=_PinUNet(), vae=_PinVAE())
+    with pytest.raises(RuntimeError, match="decoder"):
+        gd.decode_latents(torch.zeros(1, 4, 8, 8))
 
 
 def test_direction_rules_match_the_reference_prompt_processor():
