@@ -208,6 +208,7 @@ def vsd_main(args):
     with torch.device(device):
         lora = sd21.init_random_(sd21.LoraUNet2DConditionModel(), 2)
     lora = lora.to(torch.bfloat16).to(memory_format=torch.channels_last)
+    lora.adapters_to_fp32()          # the reference trains the rank-4 adapters in fp32 (sd_vsd_utils.py:35); base weights bf16
     train = lora.freeze_base()
     q = LoraUnet(lora)
     opt = torch.optim.AdamW(train, lr=1e-4)

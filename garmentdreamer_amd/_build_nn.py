@@ -9,6 +9,7 @@ NN_SOURCES = [
     ("nn_prologue.hip", ["-munsafe-fp-atomics"]),
     ("nn_fp8.hip", []),
     ("nn_linear.hip", []),
+    ("nn_lora.hip", []),
 ]
 
 

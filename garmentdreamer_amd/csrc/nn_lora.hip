@@ -1,0 +1,229 @@
+// nn_lora.hip -- the rank-4 adapter branch of the NeTF stage's LoRA UNet, forward and backward, fp32 accumulation throughout.
+//
+//   y = base + s * up(down(x))         diffusers 0.19 LoRALinearLayer behind LoRAAttnProcessor
+//                                      (Garment_Deformer_NeTF/netf/vsd/lora_unet.py:119-160, 415-422; trained by
+//                                      netf/trainer.py:215-256)
+// x: [M][K] bf16, down: [4][K] fp32, up: [N][4] fp32, base / y: [M][N] bf16.  With rank 4 neither product is a matrix-core
+// problem: `down` is four dot products per row (a skinny GEMM the library runs at 30 us per call on 16-wide tiles), `up` is
+// four FMAs per output element.  PyTorch ran cast -> GEMM -> GEMM -> cast -> scale -> add per adapted linear (128 of them per
+// UNet pass) and twice that in the backward pass; here:
+//   gd_nn_lora_rowdot      h[m][r] = s * sum_k a[m][k] w(r, k)          one wave per row; w as [4][K] (down) or [K][4] (up, for dh)
+//   gd_nn_lora_rank4_add   y[m][n] = base[m][n] + sum_r h[m][r] w(r, n) one thread per 8 outputs; w as [N][4] (up) or [4][N] (down, for dx)
+//   gd_nn_lora_colreduce   g(r, j) = s * sum_m a[m][j] v[m][r]          weight gradients: per 32-row chunk partial sums in registers,
+//                                                                      then a fixed-order sum over the chunks (no atomics:
+//                                                                      the LoRA gradients are bitwise reproducible)
+// All HBM streams of [M][K] / [M][N] bf16 tensors; 16-byte accesses.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gd_nn.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+int fail(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+struct alignas(16) u32x4 { uint32_t w[4]; };
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
+{
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float lo16(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi16(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+constexpr int kChunkRows = 32;
+
+// h[m] = scale * (a[m][:] . w(r, :)), r = 0..3.  WT = false: w is [4][K]; WT = true: w is [K][4].
+template <bool WT>
+__global__ __launch_bounds__(256) void lora_rowdot_kernel(const u32x4* __restrict__ a, const float* __restrict__ w,
+                                                          float4* __restrict__ h, int M, int K8, float scale)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int K = K8 * 8;
+    for (int k8 = lane; k8 < K8; k8 += 64) {
+        const u32x4 q = a[(size_t)m * K8 + k8];
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { x[2 * e] = lo16(q.w[e]); x[2 * e + 1] = hi16(q.w[e]); }
+        if (WT) {
+            const float4* wp = (const float4*)w + (size_t)k8 * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float4 t = wp[e];
+                acc[0] = fmaf(x[e], t.x, acc[0]); acc[1] = fmaf(x[e], t.y, acc[1]);
+                acc[2] = fmaf(x[e], t.z, acc[2]); acc[3] = fmaf(x[e], t.w, acc[3]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4 t0 = *(const float4*)(w + (size_t)r * K + k8 * 8), t1 = *(const float4*)(w + (size_t)r * K + k8 * 8 + 4);
+                acc[r] = fmaf(x[0], t0.x, fmaf(x[1], t0.y, fmaf(x[2], t0.z, fmaf(x[3], t0.w, acc[r]))));
+                acc[r] = fmaf(x[4], t1.x, fmaf(x[5], t1.y, fmaf(x[6], t1.z, fmaf(x[7], t1.w, acc[r]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off, 64);
+    if (lane == 0) h[m] = make_float4(scale * acc[0], scale * acc[1], scale * acc[2], scale * acc[3]);
+}
+
+// y[m][n..n+8) = (base ? base : 0) + sum_r h[m][r] * w(r, n).  WT = true: w is [N][4]; WT = false: w is [4][N].
+template <bool WT>
+__global__ __launch_bounds__(256) void lora_rank4_add_kernel(const float4* __restrict__ h, const float* __restrict__ w,
+                                                             const u32x4* __restrict__ base, u32x4* __restrict__ y,
+                                                             int64_t nvec, int N8)
+{
+    const int N = N8 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / N8;
+        const int n8 = (int)(i - m * N8);
+        const float4 hv = h[m];
+        float o[8];
+        if (WT) {
+            const float4* wp = (const float4*)w + (size_t)n8 * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float4 t = wp[e];
+                o[e] = fmaf(hv.x, t.x, fmaf(hv.y, t.y, fmaf(hv.z, t.z, hv.w * t.w)));
+            }
+        } else {
+            const float hr[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4 t0 = *(const float4*)(w + (size_t)r * N + n8 * 8), t1 = *(const float4*)(w + (size_t)r * N + n8 * 8 + 4);
+                o[0] = fmaf(hr[r], t0.x, o[0]); o[1] = fmaf(hr[r], t0.y, o[1]); o[2] = fmaf(hr[r], t0.z, o[2]); o[3] = fmaf(hr[r], t0.w, o[3]);
+                o[4] = fmaf(hr[r], t1.x, o[4]); o[5] = fmaf(hr[r], t1.y, o[5]); o[6] = fmaf(hr[r], t1.z, o[6]); o[7] = fmaf(hr[r], t1.w, o[7]);
+            }
+        }
+        if (base) {
+            const u32x4 b = base[i];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { o[2 * e] += lo16(b.w[e]); o[2 * e + 1] += hi16(b.w[e]); }
+        }
+        u32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; e++) out.w[e] = pack_bf16(o[2 * e], o[2 * e + 1]);
+        y[i] = out;
+    }
+}
+
+// part[chunk][r][j] = sum over the chunk's rows of a[m][j] * v[m][r]; thread = 8 columns, block = 256 threads = 2048 columns
+__global__ __launch_bounds__(256) void lora_colreduce_kernel(const u32x4* __restrict__ a, const float4* __restrict__ v,
+                                                             float* __restrict__ part, int M, int J8)
+{
+    const int j8 = blockIdx.x * 256 + threadIdx.x;
+    if (j8 >= J8) return;
+    const int m0 = blockIdx.y * kChunkRows, m1 = min(M, m0 + kChunkRows);
+    float acc[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[r][e] = 0.f;
+    for (int m = m0; m < m1; m++) {
+        const u32x4 q = a[(size_t)m * J8 + j8];
+        const float4 t = v[m];
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { x[2 * e] = lo16(q.w[e]); x[2 * e + 1] = hi16(q.w[e]); }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            acc[0][e] = fmaf(x[e], t.x, acc[0][e]); acc[1][e] = fmaf(x[e], t.y, acc[1][e]);
+            acc[2][e] = fmaf(x[e], t.z, acc[2][e]); acc[3][e] = fmaf(x[e], t.w, acc[3][e]);
+        }
+    }
+    const int J = J8 * 8;
+    float* p = part + ((size_t)blockIdx.y * 4) * J + (size_t)j8 * 8;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        *(float4*)(p + (size_t)r * J) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        *(float4*)(p + (size_t)r * J + 4) = make_float4(acc[r][4], acc[r][5], acc[r][6], acc[r][7]);
+    }
+}
+
+// g = scale * sum over chunks (in chunk order) of part[chunk][r][j]; out as [4][J] (transposed = 0) or [J][4] (transposed = 1)
+__global__ __launch_bounds__(256) void lora_colreduce_finish_kernel(const float* __restrict__ part, float* __restrict__ g,
+                                                                    int chunks, int J, float scale, int transposed)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;      // r * J + j
+    if (i >= 4 * J) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; c++) s += part[(size_t)c * 4 * J + i];
+    const int r = i / J, j = i - r * J;
+    g[transposed ? (size_t)j * 4 + r : (size_t)i] = scale * s;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gd_nn_lora_last_error(void) { return g_err; }
+
+int gd_nn_lora_rowdot(void* stream, const void* a, const float* w, float* h, int64_t M, int K, float scale, int w_is_k_by_4)
+{
+    if (!a || !w || !h) return fail(GD_NN_ERR_INVALID_ARG, "lora_rowdot: null pointer");
+    if (M <= 0 || M > 0x7fffffff / 4 || K <= 0 || (K & 7)) return fail(GD_NN_ERR_INVALID_ARG, "lora_rowdot: need M > 0 and K % 8 == 0");
+    const dim3 grid((unsigned)((M + 3) / 4));
+    if (w_is_k_by_4)
+        hipLaunchKernelGGL(lora_rowdot_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const u32x4*)a, w, (float4*)h, (int)M, K / 8, scale);
+    else
+        hipLaunchKernelGGL(lora_rowdot_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const u32x4*)a, w, (float4*)h, (int)M, K / 8, scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_lora_rank4_add(void* stream, const float* h, const float* w, const void* base, void* y, int64_t M, int N, int w_is_n_by_4)
+{
+    if (!h || !w || !y) return fail(GD_NN_ERR_INVALID_ARG, "lora_rank4_add: null pointer");
+    if (M <= 0 || N <= 0 || (N & 7)) return fail(GD_NN_ERR_INVALID_ARG, "lora_rank4_add: need M > 0 and N % 8 == 0");
+    const int64_t nvec = M * (N / 8);
+    const int64_t blocks = (nvec + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 16384 ? blocks : 16384));
+    if (w_is_n_by_4)
+        hipLaunchKernelGGL(lora_rank4_add_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)h, w, (const u32x4*)base, (u32x4*)y, nvec, N / 8);
+    else
+        hipLaunchKernelGGL(lora_rank4_add_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)h, w, (const u32x4*)base, (u32x4*)y, nvec, N / 8);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+size_t gd_nn_lora_colreduce_scratch_floats(int64_t M, int J)
+{
+    if (M <= 0 || J <= 0) return 0;
+    return (size_t)((M + kChunkRows - 1) / kChunkRows) * 4 * (size_t)J;
+}
+
+int gd_nn_lora_colreduce(void* stream, const void* a, const float* v, float* scratch, float* g, int64_t M, int J, float scale,
+                         int g_is_j_by_4)
+{
+    if (!a || !v || !scratch || !g) return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce: null pointer");
+    if (M <= 0 || M > 0x7fffffff / 4 || J <= 0 || (J & 7)) return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce: need M > 0 and J % 8 == 0");
+    const int chunks = (int)((M + kChunkRows - 1) / kChunkRows);
+    if (chunks > 65535) return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce: more than 65535 row chunks");
+    const int J8 = J / 8;
+    hipLaunchKernelGGL(lora_colreduce_kernel, dim3((J8 + 255) / 256, chunks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a,
+                       (const float4*)v, scratch, (int)M, J8);
+    hipLaunchKernelGGL(lora_colreduce_finish_kernel, dim3((4 * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, g, chunks, J,
+                       scale, g_is_j_by_4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+}  // extern "C"

@@ -45,6 +45,8 @@ import os as _os
 
 _FUSED_QKV = _os.environ.get("GD_FUSED_QKV", "1") != "0"   # A/B toggle of the fused self-attention projection
 _VT_GEMM = _os.environ.get("GD_VT_GEMM", "1") != "0"         # A/B toggle: V^T from a GEMM instead of the transposing pre-pass
+_LORA_FUSED = _os.environ.get("GD_LORA_FUSED", "1") != "0"   # A/B toggle: own rank-4 LoRA kernels (fwd + bwd) instead of torch ops
+from .. import nn_ops  # noqa: E402
 _FP8_ACTIVE = [None]   # the nn_ops.Fp8State of the UNet whose no-grad forward is running (set by its forward)
 
 
@@ -262,9 +264,9 @@ class Attention(nn.Module):
         else:
             q, k, v = _lin(self.to_q, x), _lin(self.to_k, ctx), _lin(self.to_v, ctx)
         if self.lora is not None:
-            q = q + self.lora_scale * self.lora["to_q_lora"](x)
-            k = k + self.lora_scale * self.lora["to_k_lora"](ctx)
-            v = v + self.lora_scale * self.lora["to_v_lora"](ctx)
+            q = self._lora_add(q, x, "to_q_lora")
+            k = self._lora_add(k, ctx, "to_k_lora")
+            v = self._lora_add(v, ctx, "to_v_lora")
         q = q.view(B, N, self.heads, -1)
         k = k.view(B, ctx.shape[1], self.heads, -1)
         v = v.view(B, ctx.shape[1], self.heads, -1)
@@ -277,8 +279,17 @@ class Attention(nn.Module):
             o = o.transpose(1, 2).reshape(B, N, -1)
         y = _lin(self.to_out[0], o)
         if self.lora is not None:
-            y = y + self.lora_scale * self.lora["to_out_lora"](o)
+            y = self._lora_add(y, o, "to_out_lora")
         return y
+
+    def _lora_add(self, base, x, name):
+        """``base + lora_scale * up(down(x))`` (LoRAAttnProcessor): own fused rank-4 kernels, forward and backward, for bf16
+        activations with fp32 adapters (nn_ops.lora_branch: 2 launches instead of cast, GEMM, GEMM, cast, scale, add)."""
+        layer = self.lora[name]
+        dw, uw = layer.down.weight, layer.up.weight
+        if _LORA_FUSED and nn_ops.lora_branch_supported(x, base, dw, uw):
+            return nn_ops.lora_branch(x, base, dw, uw, self.lora_scale)
+        return base + self.lora_scale * layer(x)
 
 
 class GEGLU(nn.Module):

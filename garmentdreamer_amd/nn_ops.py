@@ -101,6 +101,11 @@ SIGNATURES = {
     "gd_nn_fp8_last_error": (C.c_char_p, []),
     "gd_nn_conv_last_error": (C.c_char_p, []),
     "gd_nn_elementwise_last_error": (C.c_char_p, []),
+    "gd_nn_lora_rowdot": (_i, [_vp, _vp, _vp, _vp, C.c_int64, _i, C.c_float, _i]),
+    "gd_nn_lora_rank4_add": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
+    "gd_nn_lora_colreduce_scratch_floats": (C.c_size_t, [C.c_int64, _i]),
+    "gd_nn_lora_colreduce": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, C.c_float, _i]),
+    "gd_nn_lora_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
 }
 
@@ -1224,6 +1229,90 @@ class _SparsityHead(torch.autograd.Function):
                                              g32.data_ptr(), n, dd.data_ptr()), "gd_nn_sparsity_backward", "gd_nn_prologue_last_error")
         dmax_grad = (-(sums[1] / n).to(torch.float32) / (m[0] + 1e-5)) * g32[0]
         return dd, dmax_grad.reshape(())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rank-4 LoRA branch (csrc/nn_lora.hip): y = base + scale * up(down(x)), forward and backward, fp32 accumulation
+# ---------------------------------------------------------------------------------------------------------------------
+def _lora_check(ret, what):
+    if ret < 0:
+        raise RuntimeError(f"{what} failed ({ret}): {lib().gd_nn_lora_last_error().decode()}")
+
+
+def lora_branch_supported(x, base, down_w, up_w) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and base.dtype == torch.bfloat16 and down_w.dtype == torch.float32
+            and up_w.dtype == torch.float32 and down_w.shape[0] == 4 and up_w.shape[1] == 4 and x.shape[-1] % 8 == 0
+            and base.shape[-1] % 8 == 0 and down_w.is_contiguous() and up_w.is_contiguous())
+
+
+def _lora_rowdot(a2d, w, scale, w_is_k_by_4):
+    M, K = a2d.shape
+    h = torch.empty((M, 4), dtype=torch.float32, device=a2d.device)
+    with torch.cuda.device(a2d.device):
+        _lora_check(lib().gd_nn_lora_rowdot(torch.cuda.current_stream(a2d.device).cuda_stream, a2d.data_ptr(), w.data_ptr(),
+                                            h.data_ptr(), M, K, float(scale), int(w_is_k_by_4)), "gd_nn_lora_rowdot")
+    return h
+
+
+def _lora_rank4_add(h, w, base2d, N, w_is_n_by_4):
+    M = h.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=h.device)
+    with torch.cuda.device(h.device):
+        _lora_check(lib().gd_nn_lora_rank4_add(torch.cuda.current_stream(h.device).cuda_stream, h.data_ptr(), w.data_ptr(),
+                                               None if base2d is None else base2d.data_ptr(), y.data_ptr(), M, N,
+                                               int(w_is_n_by_4)), "gd_nn_lora_rank4_add")
+    return y
+
+
+def _lora_colreduce(a2d, v, scale, g_is_j_by_4):
+    M, J = a2d.shape
+    L = lib()
+    scratch = torch.empty(L.gd_nn_lora_colreduce_scratch_floats(M, J), dtype=torch.float32, device=a2d.device)
+    g = torch.empty((J, 4) if g_is_j_by_4 else (4, J), dtype=torch.float32, device=a2d.device)
+    with torch.cuda.device(a2d.device):
+        _lora_check(L.gd_nn_lora_colreduce(torch.cuda.current_stream(a2d.device).cuda_stream, a2d.data_ptr(), v.data_ptr(),
+                                           scratch.data_ptr(), g.data_ptr(), M, J, float(scale), int(g_is_j_by_4)),
+                    "gd_nn_lora_colreduce")
+    return g
+
+
+class _LoraBranch(torch.autograd.Function):
+    """y = base + scale * (x @ down^T) @ up^T with x [M, K] / base [M, N] bf16 and fp32 rank-4 adapters: two launches forward
+    (four dot products per row; four FMAs per output element on top of ``base``), five backward -- every sum in fp32."""
+
+    @staticmethod
+    def forward(ctx, x2d, base2d, down_w, up_w, scale):
+        hs = _lora_rowdot(x2d, down_w, scale, 0)                       # scale * down(x)
+        ctx.save_for_backward(x2d, hs, down_w, up_w)
+        ctx.scale = float(scale)
+        return _lora_rank4_add(hs, up_w, base2d, base2d.shape[1], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, hs, down_w, up_w = ctx.saved_tensors
+        dy = dy.contiguous()
+        need_x, need_base, need_down, need_up = ctx.needs_input_grad[:4]
+        dx = d_down = d_up = None
+        if need_up:
+            d_up = _lora_colreduce(dy, hs, 1.0, 1)                     # [N, 4]: sum_m dy[m, n] * scale * h[m, r]
+        if need_x or need_down:
+            dh = _lora_rowdot(dy, up_w, ctx.scale, 1)                  # scale * dy @ up
+            if need_down:
+                d_down = _lora_colreduce(x2d, dh, 1.0, 0)              # [4, K]
+            if need_x:
+                dx = _lora_rank4_add(dh, down_w, None, x2d.shape[1], 0)
+        return dx, (dy if need_base else None), d_down, d_up, None
+
+
+def lora_branch(x, base, down_w, up_w, scale):
+    """``base + scale * up(down(x))`` for [..., K] / [..., N] bf16 activations (the leading dimensions must agree)."""
+    x2d = x.reshape(-1, x.shape[-1])
+    b2d = base.reshape(-1, base.shape[-1])
+    if not x2d.is_contiguous():
+        x2d = x2d.contiguous()
+    if not b2d.is_contiguous():
+        b2d = b2d.contiguous()
+    return _LoraBranch.apply(x2d, b2d, down_w, up_w, scale).view(base.shape)
 
 
 def sparsity_loss(depth, dmax):

@@ -312,6 +312,23 @@ const char* gd_nn_fp8_last_error(void);
 
 const char* gd_nn_conv_last_error(void);
 const char* gd_nn_elementwise_last_error(void);
+/* ---- rank-4 LoRA branch of the NeTF stage's trainable UNet (csrc/nn_lora.hip), fp32 accumulation, forward + backward.
+ * Replaces diffusers 0.19 LoRALinearLayer.forward inside LoRAAttnProcessor -- hidden + scale * up(down(x)) -- and its
+ * autograd backward (Garment_Deformer_NeTF/netf/vsd/lora_unet.py:119-160, 415-422; netf/trainer.py:215-256).
+ *   rowdot:     h[m][r] = scale * sum_k a[m][k] w(r, k);   a [M][K] bf16, h [M][4] fp32, w fp32 as [4][K] (w_is_k_by_4 = 0:
+ *               `down`) or [K][4] (1: `up`, for the gradient of h).  K % 8 == 0.
+ *   rank4_add:  y[m][n] = base[m][n] + sum_r h[m][r] w(r, n);   base (may be NULL) / y [M][N] bf16, w fp32 as [N][4]
+ *               (w_is_n_by_4 = 1: `up`) or [4][N] (0: `down`, for the gradient of x).  N % 8 == 0.
+ *   colreduce:  g(r, j) = scale * sum_m a[m][j] v[m][r];   a [M][J] bf16, v [M][4] fp32, g fp32 as [4][J] (g_is_j_by_4 = 0:
+ *               d down) or [J][4] (1: d up); scratch = gd_nn_lora_colreduce_scratch_floats(M, J) floats.  Fixed summation
+ *               order (32-row chunks, then chunk order): bitwise reproducible, no atomics. */
+int gd_nn_lora_rowdot(void* stream, const void* a, const float* w, float* h, int64_t M, int K, float scale, int w_is_k_by_4);
+int gd_nn_lora_rank4_add(void* stream, const float* h, const float* w, const void* base, void* y, int64_t M, int N, int w_is_n_by_4);
+size_t gd_nn_lora_colreduce_scratch_floats(int64_t M, int J);
+int gd_nn_lora_colreduce(void* stream, const void* a, const float* v, float* scratch, float* g, int64_t M, int J, float scale,
+                         int g_is_j_by_4);
+const char* gd_nn_lora_last_error(void);
+
 const char* gd_nn_last_error(void);
 
 #ifdef __cplusplus
