@@ -9,7 +9,7 @@
 // UNet pass) and twice that in the backward pass; here:
 //   gd_nn_lora_rowdot      h[m][r] = s * sum_k a[m][k] w(r, k)          one wave per row; w as [4][K] (down) or [K][4] (up, for dh)
 //   gd_nn_lora_rank4_add   y[m][n] = base[m][n] + sum_r h[m][r] w(r, n) one thread per 8 outputs; w as [N][4] (up) or [4][N] (down, for dx)
-//   gd_nn_lora_colreduce   g(r, j) = s * sum_m a[m][j] v[m][r]          weight gradients: per 32-row chunk partial sums in registers,
+//   gd_nn_lora_colreduce   g(r, j) = s * sum_m a[m][j] v[m][r]          weight gradients: per row-chunk partial sums in registers,
 //                                                                      then a fixed-order sum over the chunks (no atomics:
 //                                                                      the LoRA gradients are bitwise reproducible)
 // All HBM streams of [M][K] / [M][N] bf16 tensors; 16-byte accesses.
@@ -39,7 +39,13 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
 __device__ __forceinline__ float lo16(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi16(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-constexpr int kChunkRows = 32;
+// rows per partial sum of the weight-gradient reduction: 32, or M / 64 for long token sequences (at most 64 chunks: the
+// fixed-order second stage is a serial loop over them)
+__host__ __device__ inline int chunk_rows(int64_t M)
+{
+    const int64_t r = ((M + 63) / 64 + 31) / 32 * 32;
+    return (int)(r < 32 ? 32 : r);
+}
 
 // h[m] = scale * (a[m][:] . w(r, :)), r = 0..3.  WT = false: w is [4][K]; WT = true: w is [K][4].
 template <bool WT>
@@ -122,18 +128,19 @@ __global__ __launch_bounds__(256) void lora_rank4_add_kernel(const float4* __res
     }
 }
 
-// part[chunk][r][j] = sum over the chunk's rows of a[m][j] * v[m][r]; thread = 8 columns, block = 256 threads = 2048 columns
-__global__ __launch_bounds__(256) void lora_colreduce_kernel(const u32x4* __restrict__ a, const float4* __restrict__ v,
-                                                             float* __restrict__ part, int M, int J8)
+// part[chunk][r][j] = sum over the chunk's rows of a[m][j] * v[m][r]; thread = 8 columns, one wave per 512 columns and chunk
+__global__ __launch_bounds__(64) void lora_colreduce_kernel(const u32x4* __restrict__ a, const float4* __restrict__ v,
+                                                             float* __restrict__ part, int M, int J8, int rows)
 {
-    const int j8 = blockIdx.x * 256 + threadIdx.x;
+    const int j8 = blockIdx.x * 64 + threadIdx.x;
     if (j8 >= J8) return;
-    const int m0 = blockIdx.y * kChunkRows, m1 = min(M, m0 + kChunkRows);
+    const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
     float acc[4][8];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[r][e] = 0.f;
+#pragma unroll 4
     for (int m = m0; m < m1; m++) {
         const u32x4 q = a[(size_t)m * J8 + j8];
         const float4 t = v[m];
@@ -206,7 +213,8 @@ int gd_nn_lora_rank4_add(void* stream, const float* h, const float* w, const voi
 size_t gd_nn_lora_colreduce_scratch_floats(int64_t M, int J)
 {
     if (M <= 0 || J <= 0) return 0;
-    return (size_t)((M + kChunkRows - 1) / kChunkRows) * 4 * (size_t)J;
+    const int rows = chunk_rows(M);
+    return (size_t)((M + rows - 1) / rows) * 4 * (size_t)J;
 }
 
 int gd_nn_lora_colreduce(void* stream, const void* a, const float* v, float* scratch, float* g, int64_t M, int J, float scale,
@@ -214,11 +222,11 @@ int gd_nn_lora_colreduce(void* stream, const void* a, const float* v, float* scr
 {
     if (!a || !v || !scratch || !g) return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce: null pointer");
     if (M <= 0 || M > 0x7fffffff / 4 || J <= 0 || (J & 7)) return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce: need M > 0 and J % 8 == 0");
-    const int chunks = (int)((M + kChunkRows - 1) / kChunkRows);
-    if (chunks > 65535) return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce: more than 65535 row chunks");
+    const int rows = chunk_rows(M);
+    const int chunks = (int)((M + rows - 1) / rows);
     const int J8 = J / 8;
-    hipLaunchKernelGGL(lora_colreduce_kernel, dim3((J8 + 255) / 256, chunks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a,
-                       (const float4*)v, scratch, (int)M, J8);
+    hipLaunchKernelGGL(lora_colreduce_kernel, dim3((J8 + 63) / 64, chunks), dim3(64), 0, (hipStream_t)stream, (const u32x4*)a,
+                       (const float4*)v, scratch, (int)M, J8, rows);
     hipLaunchKernelGGL(lora_colreduce_finish_kernel, dim3((4 * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, g, chunks, J,
                        scale, g_is_j_by_4);
     hipError_t e = hipGetLastError();

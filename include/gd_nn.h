@@ -321,7 +321,7 @@ const char* gd_nn_elementwise_last_error(void);
  *               (w_is_n_by_4 = 1: `up`) or [4][N] (0: `down`, for the gradient of x).  N % 8 == 0.
  *   colreduce:  g(r, j) = scale * sum_m a[m][j] v[m][r];   a [M][J] bf16, v [M][4] fp32, g fp32 as [4][J] (g_is_j_by_4 = 0:
  *               d down) or [J][4] (1: d up); scratch = gd_nn_lora_colreduce_scratch_floats(M, J) floats.  Fixed summation
- *               order (32-row chunks, then chunk order): bitwise reproducible, no atomics. */
+ *               order (row chunks, then chunk order): bitwise reproducible, no atomics. */
 int gd_nn_lora_rowdot(void* stream, const void* a, const float* w, float* h, int64_t M, int K, float scale, int w_is_k_by_4);
 int gd_nn_lora_rank4_add(void* stream, const float* h, const float* w, const void* base, void* y, int64_t M, int N, int w_is_n_by_4);
 size_t gd_nn_lora_colreduce_scratch_floats(int64_t M, int J);
