@@ -174,6 +174,67 @@ __global__ __launch_bounds__(256) void lora_colreduce_finish_kernel(const float*
     g[transposed ? (size_t)j * 4 + r : (size_t)i] = scale * s;
 }
 
+// The two weight gradients of one adapter in ONE launch each stage (blockIdx.z / the output index selects the problem):
+// problem 0 = d up [N][4] from (dy, scale * h), problem 1 = d down [4][K] from (x, dh).
+struct ColPair {
+    const u32x4* a[2];
+    const float4* v[2];
+    float* part[2];
+    float* g[2];
+    int J8[2];
+};
+
+__global__ __launch_bounds__(64) void lora_colreduce_pair_kernel(ColPair p, int M, int rows)
+{
+    const int z = blockIdx.z;
+    const int J8 = p.J8[z];
+    const int j8 = blockIdx.x * 64 + threadIdx.x;
+    if (j8 >= J8) return;
+    const u32x4* __restrict__ a = p.a[z];
+    const float4* __restrict__ v = p.v[z];
+    const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
+    float acc[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[r][e] = 0.f;
+#pragma unroll 4
+    for (int m = m0; m < m1; m++) {
+        const u32x4 q = a[(size_t)m * J8 + j8];
+        const float4 t = v[m];
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { x[2 * e] = lo16(q.w[e]); x[2 * e + 1] = hi16(q.w[e]); }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            acc[0][e] = fmaf(x[e], t.x, acc[0][e]); acc[1][e] = fmaf(x[e], t.y, acc[1][e]);
+            acc[2][e] = fmaf(x[e], t.z, acc[2][e]); acc[3][e] = fmaf(x[e], t.w, acc[3][e]);
+        }
+    }
+    const int J = J8 * 8;
+    float* q = p.part[z] + ((size_t)blockIdx.y * 4) * J + (size_t)j8 * 8;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        *(float4*)(q + (size_t)r * J) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        *(float4*)(q + (size_t)r * J + 4) = make_float4(acc[r][4], acc[r][5], acc[r][6], acc[r][7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void lora_colreduce_pair_finish_kernel(ColPair p, int chunks)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = 4 * 8 * p.J8[0], n1 = 4 * 8 * p.J8[1];
+    if (i >= n0 + n1) return;
+    const int z = i >= n0;
+    if (z) i -= n0;
+    const int J = 8 * p.J8[z];
+    const float* part = p.part[z];
+    float s = 0.f;
+    for (int c = 0; c < chunks; c++) s += part[(size_t)c * 4 * J + i];
+    const int r = i / J, j = i - r * J;
+    p.g[z][z == 0 ? (size_t)j * 4 + r : (size_t)i] = s;          // d up as [N][4], d down as [4][K]
+}
+
 }  // namespace
 
 extern "C" {
@@ -229,6 +290,30 @@ int gd_nn_lora_colreduce(void* stream, const void* a, const float* v, float* scr
                        (const float4*)v, scratch, (int)M, J8, rows);
     hipLaunchKernelGGL(lora_colreduce_finish_kernel, dim3((4 * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, g, chunks, J,
                        scale, g_is_j_by_4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+size_t gd_nn_lora_colreduce_pair_scratch_floats(int64_t M, int N, int K)
+{
+    return gd_nn_lora_colreduce_scratch_floats(M, N) + gd_nn_lora_colreduce_scratch_floats(M, K);
+}
+
+int gd_nn_lora_colreduce_pair(void* stream, const void* dy, const float* hs, const void* x, const float* dh, float* scratch,
+                              float* d_up, float* d_down, int64_t M, int N, int K)
+{
+    if (!dy || !hs || !x || !dh || !scratch || !d_up || !d_down) return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce_pair: null pointer");
+    if (M <= 0 || M > 0x7fffffff / 4 || N <= 0 || K <= 0 || (N & 7) || (K & 7))
+        return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce_pair: need M > 0, N % 8 == 0, K % 8 == 0");
+    const int rows = chunk_rows(M);
+    const int chunks = (int)((M + rows - 1) / rows);
+    ColPair p;
+    p.a[0] = (const u32x4*)dy; p.v[0] = (const float4*)hs; p.part[0] = scratch; p.g[0] = d_up; p.J8[0] = N / 8;
+    p.a[1] = (const u32x4*)x; p.v[1] = (const float4*)dh; p.part[1] = scratch + (size_t)chunks * 4 * N; p.g[1] = d_down; p.J8[1] = K / 8;
+    const int jmax = N > K ? N / 8 : K / 8;
+    hipLaunchKernelGGL(lora_colreduce_pair_kernel, dim3((jmax + 63) / 64, chunks, 2), dim3(64), 0, (hipStream_t)stream, p, (int)M, rows);
+    hipLaunchKernelGGL(lora_colreduce_pair_finish_kernel, dim3((4 * (N + K) + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, chunks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

@@ -105,6 +105,8 @@ SIGNATURES = {
     "gd_nn_lora_rank4_add": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
     "gd_nn_lora_colreduce_scratch_floats": (C.c_size_t, [C.c_int64, _i]),
     "gd_nn_lora_colreduce": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, C.c_float, _i]),
+    "gd_nn_lora_colreduce_pair_scratch_floats": (C.c_size_t, [C.c_int64, _i, _i]),
+    "gd_nn_lora_colreduce_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
     "gd_nn_lora_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
 }
@@ -1293,6 +1295,20 @@ class _LoraBranch(torch.autograd.Function):
         dy = dy.contiguous()
         need_x, need_base, need_down, need_up = ctx.needs_input_grad[:4]
         dx = d_down = d_up = None
+        if need_up and need_down:        # the training case: both weight gradients from one launch per stage
+            dh = _lora_rowdot(dy, up_w, ctx.scale, 1)
+            M, N, K = dy.shape[0], dy.shape[1], x2d.shape[1]
+            L = lib()
+            scratch = torch.empty(L.gd_nn_lora_colreduce_pair_scratch_floats(M, N, K), dtype=torch.float32, device=dy.device)
+            d_up = torch.empty((N, 4), dtype=torch.float32, device=dy.device)
+            d_down = torch.empty((4, K), dtype=torch.float32, device=dy.device)
+            with torch.cuda.device(dy.device):
+                _lora_check(L.gd_nn_lora_colreduce_pair(torch.cuda.current_stream(dy.device).cuda_stream, dy.data_ptr(), hs.data_ptr(),
+                                                        x2d.data_ptr(), dh.data_ptr(), scratch.data_ptr(), d_up.data_ptr(),
+                                                        d_down.data_ptr(), M, N, K), "gd_nn_lora_colreduce_pair")
+            if need_x:
+                dx = _lora_rank4_add(dh, down_w, None, K, 0)
+            return dx, (dy if need_base else None), d_down, d_up, None
         if need_up:
             d_up = _lora_colreduce(dy, hs, 1.0, 1)                     # [N, 4]: sum_m dy[m, n] * scale * h[m, r]
         if need_x or need_down:

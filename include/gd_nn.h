@@ -327,6 +327,11 @@ int gd_nn_lora_rank4_add(void* stream, const float* h, const float* w, const voi
 size_t gd_nn_lora_colreduce_scratch_floats(int64_t M, int J);
 int gd_nn_lora_colreduce(void* stream, const void* a, const float* v, float* scratch, float* g, int64_t M, int J, float scale,
                          int g_is_j_by_4);
+/* Both weight gradients of one adapter in one launch per stage: d_up [N][4] = sum_m dy[m][n] hs[m][r] (hs = scale * down(x) as
+ * rowdot returned it), d_down [4][K] = sum_m x[m][k] dh[m][r] (dh = scale * dy @ up); same summation order as two colreduce calls. */
+size_t gd_nn_lora_colreduce_pair_scratch_floats(int64_t M, int N, int K);
+int gd_nn_lora_colreduce_pair(void* stream, const void* dy, const float* hs, const void* x, const float* dh, float* scratch,
+                              float* d_up, float* d_down, int64_t M, int N, int K);
 const char* gd_nn_lora_last_error(void);
 
 const char* gd_nn_last_error(void);

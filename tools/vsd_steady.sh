@@ -11,11 +11,16 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # steady part: the last 6 iterations; an iteration ends with AdamW's multi-tensor kernel -> use time: last 60 % of the span is safe
 t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
-# find iteration marks by the VAE prologue kernel (one per iteration)
-marks = [i for i, r in enumerate(rows) if "vae_prologue_fwd" in r["Kernel_Name"] or "vae_prologue_forward" in r["Kernel_Name"]]
-if len(marks) < 4:
-    marks = [i for i, r in enumerate(rows) if "conv3x3_first" in r["Kernel_Name"]]
-rows = rows[marks[-7]:marks[-1]]; steps = 6
+# iteration marks: the first AdamW multi-tensor kernel of each optimizer step (successive ones > 5 ms apart)
+marks, last = [], -1e18
+for i, r in enumerate(rows):
+    if "multi_tensor_apply" in r["Kernel_Name"]:
+        t = int(r["Start_Timestamp"])
+        if t - last > 5e6:
+            marks.append(i)
+        last = t
+steps = min(6, len(marks) - 1)
+rows = rows[marks[-1 - steps]:marks[-1]]
 agg = collections.OrderedDict()
 for r in rows:
     d = agg.setdefault(r["Kernel_Name"], [0, 0]); d[0] += 1; d[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
