@@ -393,6 +393,9 @@ def test_config3_full_shape_two_ranks_x_4_views_vs_one_rank_x_8_views(tmp_path):
         parity_report.record("configs[3] full shape: 2 ranks x 4 views vs 1 rank x 8 views (gloo, one GPU, bf16 nets)",
                              f"step {s} grad bucket, batch-invariant kernel selection", cos=cos_bi,
                              max_err_over_scale=float((a - b).abs().max() / a.abs().max()))
-        # measured: step 0 cos 1 - 2e-13, max error 9e-8 of the largest entry (the fp32 all-reduce sums 2 x 4 views
-        # in another order than the single rank's 8); step 1, after an Adam step on those gradients, 1 - 3e-10
-        assert cos_bi > 0.999999, (s, cos_bi)
+        # measured: step 0 (same parameters on both sides) cos 1 - 2e-13, max error 9e-8 of the largest entry -- the fp32
+        # all-reduce sums 2 x 4 views in another order than the single rank's 8.  Step 1 follows an Adam step (eps 1e-15) on
+        # those gradients: an entry whose sign the 9e-8 decides moves its parameter by +-lr, and guidance_scale = 100
+        # amplifies that like any other perturbation -- usually 1 - 3e-10, but 0.99997 and 0.9987 were seen in 2 of 9
+        # repeated runs of the suite, so only step 0 carries the bit-level bar
+        assert cos_bi > (0.999999 if s == 0 else 0.995), (s, cos_bi)
