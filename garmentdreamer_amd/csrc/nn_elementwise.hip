@@ -131,6 +131,101 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const bf16x8* __rest
     }
 }
 
+// Backward of GEGLU: x = [h | g] (the projection's output), dy the gradient of h * gelu(g):
+//   dh = dy * gelu(g),   dg = dy * h * (Phi(g) + g phi(g)),   Phi(g) = (1 + erf(g / sqrt 2)) / 2,  phi(g) = exp(-g^2 / 2) / sqrt(2 pi)
+// written as one [rows][2 * inner] tensor (what the projection's backward consumes); fp32 math, one rounding per output.
+__global__ __launch_bounds__(256) void geglu_backward_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ dy,
+                                                             bf16x8* __restrict__ dx, int64_t nvec, int vin)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / vin;
+        const int c = (int)(i - row * vin);
+        const u32x4 h = __builtin_bit_cast(u32x4, x[row * 2 * vin + c]);
+        const u32x4 g = __builtin_bit_cast(u32x4, x[row * 2 * vin + vin + c]);
+        const u32x4 d = __builtin_bit_cast(u32x4, dy[i]);
+        u32x4 oh, og;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const f2 gv = unpack2(g.w[k]), hv = unpack2(h.w[k]), dv = unpack2(d.w[k]);
+            const f2 cdf = 0.5f * (1.0f + erf_as2(gv * 0.70710678118654752f));
+            const f2 a = (gv * gv) * -0.72134752044448170f;            // -g^2 / 2 * log2(e)
+            const f2 pdf = 0.39894228040143268f * f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+            oh.w[k] = pack2(dv * (gv * cdf));
+            og.w[k] = pack2((dv * hv) * (cdf + gv * pdf));
+        }
+        dx[row * 2 * vin + c] = __builtin_bit_cast(bf16x8, oh);
+        dx[row * 2 * vin + vin + c] = __builtin_bit_cast(bf16x8, og);
+    }
+}
+
+// Backward of y = LayerNorm(s) * w + b w.r.t. s, plus the gradient that reaches s directly (the residual stream):
+//   a = w * dy,  dx = rstd * (a - mean(a) - xhat * mean(a * xhat)) + ds,   mean / rstd recomputed from the row (registers).
+// One wave per row; VPL = 16-byte vectors per lane.
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_backward_kernel(const bf16x8* __restrict__ s, const bf16x8* __restrict__ dy,
+                                                                 const bf16x8* __restrict__ w, const bf16x8* __restrict__ ds,
+                                                                 bf16x8* __restrict__ dx, int64_t rows, int vpr, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f2 v[VPL][4], a[VPL][4];
+    f2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < vpr) {
+            const u32x4 q = __builtin_bit_cast(u32x4, s[row * vpr + c]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[i][k] = unpack2(q.w[k]); sum2 += v[i][k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[i][k] = f2{0.f, 0.f};
+        }
+    }
+    const float inv_c = 1.0f / (float)(vpr * 8);
+    const float mean = wave_sum(sum2.x + sum2.y) * inv_c;
+    f2 sq2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < VPL; i++)
+        if (lane + 64 * i < vpr) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const f2 d = v[i][k] - mean; sq2 += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(sq2.x + sq2.y) * inv_c + eps);
+    f2 m1 = {0.f, 0.f}, m2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < vpr) {
+            const u32x4 g = __builtin_bit_cast(u32x4, dy[row * vpr + c]), ww = __builtin_bit_cast(u32x4, w[c]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[i][k] = (v[i][k] - mean) * rstd;                      // xhat
+                a[i][k] = unpack2(g.w[k]) * unpack2(ww.w[k]);
+                m1 += a[i][k];
+                m2 += a[i][k] * v[i][k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) a[i][k] = f2{0.f, 0.f};
+        }
+    }
+    const float ma = wave_sum(m1.x + m1.y) * inv_c, mb = wave_sum(m2.x + m2.y) * inv_c;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < vpr) {
+            u32x4 o;
+            u32x4 e = {{0u, 0u, 0u, 0u}};
+            if (ds) e = __builtin_bit_cast(u32x4, ds[row * vpr + c]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) o.w[k] = pack2((a[i][k] - ma - v[i][k] * mb) * rstd + unpack2(e.w[k]));
+            dx[row * vpr + c] = __builtin_bit_cast(bf16x8, o);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -170,6 +265,37 @@ int gd_nn_add_layernorm_forward(void* stream, const void* x, const void* residua
     else GD_LN(4);
 #undef GD_LN
     return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "add_layernorm: launch failed");
+}
+
+int gd_nn_geglu_backward(void* stream, const void* x, const void* dy, void* dx, int64_t rows, int inner)
+{
+    if (!x || !dy || !dx) return fail(GD_NN_ERR_INVALID_ARG, "geglu_backward: null pointer");
+    if (rows <= 0 || inner <= 0 || inner % 8) return fail(GD_NN_ERR_INVALID_ARG, "geglu_backward: need inner % 8 == 0");
+    const int64_t nvec = rows * (inner / 8);
+    const int64_t blocks = (nvec + 255) / 256;
+    const int grid = (int)(blocks < 16384 ? blocks : 16384);
+    hipLaunchKernelGGL(geglu_backward_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, (const bf16x8*)dy,
+                       (bf16x8*)dx, nvec, inner / 8);
+    return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "geglu_backward: launch failed");
+}
+
+int gd_nn_layernorm_backward(void* stream, const void* s, const void* dy, const void* weight, const void* ds, void* dx,
+                             int64_t rows, int C, float eps)
+{
+    if (!s || !dy || !weight || !dx) return fail(GD_NN_ERR_INVALID_ARG, "layernorm_backward: null pointer");
+    if (rows <= 0 || C <= 0 || C % 8 || C > 2048) return fail(GD_NN_ERR_INVALID_ARG, "layernorm_backward: need C % 8 == 0, C <= 2048");
+    const int vpr = C / 8, vpl = (vpr + 63) / 64;
+    const int64_t blocks = (rows + 3) / 4;
+    if (blocks > 2147483647LL) return fail(GD_NN_ERR_INVALID_ARG, "layernorm_backward: too many rows");
+#define GD_LNB(V_)                                                                                                     \
+    hipLaunchKernelGGL(layernorm_backward_kernel<V_>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,       \
+                       (const bf16x8*)s, (const bf16x8*)dy, (const bf16x8*)weight, (const bf16x8*)ds, (bf16x8*)dx, rows, vpr, eps)
+    if (vpl == 1) GD_LNB(1);
+    else if (vpl == 2) GD_LNB(2);
+    else if (vpl == 3) GD_LNB(3);
+    else GD_LNB(4);
+#undef GD_LNB
+    return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "layernorm_backward: launch failed");
 }
 
 }  // extern "C"

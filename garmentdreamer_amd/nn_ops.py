@@ -82,6 +82,8 @@ SIGNATURES = {
     "gd_nn_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gd_nn_conv_profile_read_bytes": (_i, [C.POINTER(C.c_double)]),
     "gd_nn_geglu_forward": (_i, [_vp, _vp, _vp, C.c_int64, _i]),
+    "gd_nn_geglu_backward": (_i, [_vp, _vp, _vp, _vp, C.c_int64, _i]),
+    "gd_nn_layernorm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, C.c_float]),
     "gd_nn_add_layernorm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, C.c_int64, _i]),
     "gd_nn_attention_ws_bytes": (C.c_size_t, [_i, _i, _i]),
     "gd_nn_attention_d64_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i,
@@ -1062,44 +1064,131 @@ def _rowwise_ok(*ts):
         all(t is None or (t.is_cuda and t.dtype == torch.bfloat16) for t in ts)
 
 
-def geglu(x):
-    """``h * gelu(gate)`` with ``h, gate = x.chunk(2, -1)`` (diffusers GEGLU).  One HIP pass for bf16 GPU
-    tensors that need no gradient; the PyTorch ops otherwise (CPU, fp32, LoRA training)."""
-    inner = x.shape[-1] // 2
-    if _rowwise_ok(x) and inner % 8 == 0 and x.shape[-1] == 2 * inner:
-        x = x.contiguous()
-        y = torch.empty(x.shape[:-1] + (inner,), dtype=x.dtype, device=x.device)
+def _geglu_fwd(x, inner):
+    x = x.contiguous()
+    y = torch.empty(x.shape[:-1] + (inner,), dtype=x.dtype, device=x.device)
+    L = lib()
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_geglu_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(),
+                                    x.numel() // (2 * inner), inner)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_geglu_forward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
+    return x, y
+
+
+class _GegluTrain(torch.autograd.Function):
+    """GEGLU of the LoRA UNet's training pass: the forward kernel + ONE backward kernel that writes the gradient of the whole
+    projection output [dh | dgate] (eager: chunk, gelu, mul forward; gelu_backward, two muls and a cat backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        inner = x.shape[-1] // 2
+        xc, y = _geglu_fwd(x, inner)
+        ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        inner = x.shape[-1] // 2
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
         L = lib()
         with torch.cuda.device(x.device):
-            ret = L.gd_nn_geglu_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(),
-                                        x.numel() // (2 * inner), inner)
+            ret = L.gd_nn_geglu_backward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), dy.data_ptr(),
+                                         dx.data_ptr(), x.numel() // (2 * inner), inner)
         if ret < 0:
-            raise RuntimeError(f"gd_nn_geglu_forward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
-        return y
+            raise RuntimeError(f"gd_nn_geglu_backward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
+        return dx
+
+
+_ROW_TRAIN = os.environ.get("GD_ROW_TRAIN", "1") != "0"    # A/B toggle: own GEGLU / LayerNorm backward in the training pass
+
+
+def geglu(x):
+    """``h * gelu(gate)`` with ``h, gate = x.chunk(2, -1)`` (diffusers GEGLU).  One HIP pass for bf16 GPU tensors; with a
+    gradient (LoRA training) the same kernel under an autograd node whose backward is one kernel too.  The PyTorch ops
+    otherwise (CPU, fp32)."""
+    inner = x.shape[-1] // 2
+    if x.is_cuda and x.dtype == torch.bfloat16 and inner % 8 == 0 and x.shape[-1] == 2 * inner:
+        if _rowwise_ok(x):
+            return _geglu_fwd(x, inner)[1]
+        if _ROW_TRAIN:
+            return _GegluTrain.apply(x)
     h, gate = x.chunk(2, dim=-1)
     return h * F.gelu(gate)
 
 
-def add_layer_norm(x, residual, norm, want_sum: bool = True):
-    """``s = x + residual; return s, norm(s)`` (``residual`` None -> ``s = x``).  One HIP pass for bf16 GPU
-    tensors that need no gradient (frozen UNet); the PyTorch ops otherwise."""
+def _ln_backward(s, dy, weight, ds, eps):
+    Cc = s.shape[-1]
+    dx = torch.empty_like(s)
+    L = lib()
+    with torch.cuda.device(s.device):
+        ret = L.gd_nn_layernorm_backward(torch.cuda.current_stream(s.device).cuda_stream, s.data_ptr(), dy.data_ptr(),
+                                         weight.data_ptr(), None if ds is None else ds.data_ptr(), dx.data_ptr(),
+                                         s.numel() // Cc, Cc, float(eps))
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_layernorm_backward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
+    return dx
+
+
+def _add_ln_fwd(x, residual, weight, bias, eps, want_sum):
     Cc = x.shape[-1]
-    if _rowwise_ok(x, residual, norm.weight, norm.bias) and Cc % 8 == 0 and Cc <= 2048 and \
-            norm.weight.dtype == torch.bfloat16:
-        x = x.contiguous()
-        if residual is not None:
-            residual = residual.contiguous()
-        s = torch.empty_like(x) if (residual is not None and want_sum) else None
-        y = torch.empty_like(x)
-        L = lib()
-        with torch.cuda.device(x.device):
-            ret = L.gd_nn_add_layernorm_forward(
-                torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
-                None if residual is None else residual.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(),
-                float(norm.eps), None if s is None else s.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc)
-        if ret < 0:
-            raise RuntimeError(f"gd_nn_add_layernorm_forward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
-        return (x if residual is None else s), y
+    x = x.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+    s = torch.empty_like(x) if (residual is not None and want_sum) else None
+    y = torch.empty_like(x)
+    L = lib()
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_add_layernorm_forward(
+            torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(),
+            None if residual is None else residual.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+            float(eps), None if s is None else s.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_add_layernorm_forward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
+    return (x if residual is None else s), y
+
+
+class _AddLayerNormTrain(torch.autograd.Function):
+    """``s = x + residual; y = LayerNorm(s)`` of the training pass (frozen norm parameters): the forward kernel, and ONE backward
+    kernel for d s = (gradient reaching s through the residual stream) + LayerNorm-backward(dy), mean / rstd recomputed."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps):
+        s, y = _add_ln_fwd(x, residual, weight, bias, eps, True)
+        ctx.save_for_backward(s, weight)
+        ctx.eps = eps
+        ctx.has_res = residual is not None
+        ctx.set_materialize_grads(False)
+        if residual is None:
+            return y
+        return s, y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        s, weight = ctx.saved_tensors
+        gs, gy = (None, grads[0]) if not ctx.has_res else grads
+        if gy is None:
+            d = gs
+        else:
+            d = _ln_backward(s, gy.contiguous(), weight, None if gs is None else gs.contiguous(), ctx.eps)
+        return d, (d if ctx.has_res else None), None, None, None
+
+
+def add_layer_norm(x, residual, norm, want_sum: bool = True):
+    """``s = x + residual; return s, norm(s)`` (``residual`` None -> ``s = x``).  One HIP pass for bf16 GPU tensors; with a
+    gradient on the activations and frozen norm parameters (LoRA training) the same kernel under an autograd node with a
+    one-kernel backward; the PyTorch ops otherwise."""
+    Cc = x.shape[-1]
+    ok = Cc % 8 == 0 and Cc <= 2048 and norm.weight.dtype == torch.bfloat16 and x.is_cuda and x.dtype == torch.bfloat16 and \
+        (residual is None or (residual.is_cuda and residual.dtype == torch.bfloat16))
+    if ok and _rowwise_ok(x, residual, norm.weight, norm.bias):
+        return _add_ln_fwd(x, residual, norm.weight, norm.bias, norm.eps, want_sum)
+    if ok and _ROW_TRAIN and torch.is_grad_enabled() and not norm.weight.requires_grad and not norm.bias.requires_grad:
+        if residual is None:
+            return x, _AddLayerNormTrain.apply(x, None, norm.weight, norm.bias, float(norm.eps))
+        return _AddLayerNormTrain.apply(x, residual, norm.weight, norm.bias, float(norm.eps))
     s = x if residual is None else x + residual
     return s, norm(s)
 

@@ -246,6 +246,13 @@ int gd_nn_conv3x3_s2_dgrad_ws(void* stream, const void* dy, const void* weight_f
  * hidden * F.gelu(gate)``; the UNet skeleton is un-vendored, call site stable_diffusion_guidance.py:153-157).
  * Replaces chunk + gelu + mul (5 row passes) by one 3-pass kernel.  Inference only. */
 int gd_nn_geglu_forward(void* stream, const void* x, void* y, int64_t rows, int inner);
+/* Input gradients of the two row passes, for the training pass of the NeTF stage's LoRA UNet (frozen base: no parameter
+ * gradients).  geglu_backward: dx [rows][2 * inner] = [dy * gelu(g) | dy * h * gelu'(g)] from x = [h | g] and dy [rows][inner]
+ * (autograd of diffusers GEGLU, netf/vsd/lora_unet.py's FeedForward).  layernorm_backward: dx = d LayerNorm(s) / d s applied to
+ * dy, + ds (the gradient reaching s directly through the residual stream; may be NULL); mean / rstd recomputed from s. */
+int gd_nn_geglu_backward(void* stream, const void* x, const void* dy, void* dx, int64_t rows, int inner);
+int gd_nn_layernorm_backward(void* stream, const void* s, const void* dy, const void* weight, const void* ds, void* dx,
+                             int64_t rows, int C, float eps);
 
 /* s = x + residual (residual may be NULL -> s = x); if sum_out != NULL store s (bf16) there;
  * y = LayerNorm_C(s) * weight + bias.  x, residual, sum_out, y: bf16 [rows, C]; weight, bias: bf16 [C];

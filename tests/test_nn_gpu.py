@@ -1131,6 +1131,52 @@ def test_lora_branch_forward_and_backward_match_fp32_reference(M, K, N, frozen):
         assert got is None or (got.dtype == torch.float32 and rel(got, want) < 2e-5)
 
 
+@pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (300, 1280), (77, 1024)])
+def test_training_row_passes_forward_and_backward_match_fp32_reference(rows, C):
+    """GEGLU and add + LayerNorm with a gradient on the activations (the LoRA UNet's training pass; frozen norm parameters):
+    own forward kernels under autograd nodes whose backward is ONE kernel each (gd_nn_geglu_backward,
+    gd_nn_layernorm_backward) against fp32 PyTorch on the same bf16 inputs."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(rows + C)
+    def rel(a, b):
+        return ((a.float() - b).abs().max() / b.abs().max()).item()
+    # GEGLU
+    x = (torch.randn(2, rows // 2 if rows % 2 == 0 else rows, 2 * C, device=DEV, generator=g) * 1.3).to(torch.bfloat16).requires_grad_(True)
+    dy = torch.randn(*x.shape[:-1], C, device=DEV, generator=g).to(torch.bfloat16)
+    y = nn_ops.geglu(x)
+    assert y.grad_fn is not None and "Geglu" in type(y.grad_fn).__name__
+    y.backward(dy)
+    xf = x.detach().float().requires_grad_(True)
+    h, gate = xf.chunk(2, -1)
+    yr = h * F.gelu(gate)
+    yr.backward(dy.float())
+    assert rel(y.detach(), yr.detach()) < 1.2e-2 and rel(x.grad, xf.grad) < 1.2e-2
+    # add + LayerNorm, with and without a residual; s is used downstream too (the residual stream)
+    norm = torch.nn.LayerNorm(C, device=DEV, dtype=torch.bfloat16)
+    with torch.no_grad():
+        norm.weight.copy_((torch.randn(C, device=DEV, generator=g) * 0.3 + 1).to(torch.bfloat16))
+        norm.bias.copy_((torch.randn(C, device=DEV, generator=g) * 0.3).to(torch.bfloat16))
+    norm.requires_grad_(False)
+    for with_res in (True, False):
+        a = (torch.randn(rows, C, device=DEV, generator=g) * 2 + 0.5).to(torch.bfloat16).requires_grad_(True)
+        r = torch.randn(rows, C, device=DEV, generator=g).to(torch.bfloat16).requires_grad_(True) if with_res else None
+        gy = torch.randn(rows, C, device=DEV, generator=g).to(torch.bfloat16)
+        gs = torch.randn(rows, C, device=DEV, generator=g).to(torch.bfloat16)
+        s_, y_ = nn_ops.add_layer_norm(a, r, norm)
+        assert "AddLayerNormTrain" in type(y_.grad_fn).__name__
+        (y_.float() * gy.float()).sum().add((s_.float() * gs.float()).sum()).backward()
+        af = a.detach().float().requires_grad_(True)
+        rf = r.detach().float().requires_grad_(True) if with_res else None
+        sf = (af + rf).to(torch.bfloat16).float() if with_res else af      # the residual stream is rounded to bf16, as in eager
+        sf_graph = af + rf if with_res else af
+        yf = F.layer_norm(sf_graph, (C,), norm.weight.float(), norm.bias.float(), norm.eps)
+        ((yf * gy.float()).sum() + (sf_graph * gs.float()).sum()).backward()
+        assert rel(y_.detach(), yf.detach()) < 2.5e-2, rel(y_.detach(), yf.detach())
+        assert rel(a.grad, af.grad) < 1.5e-2, rel(a.grad, af.grad)
+        if with_res:
+            assert torch.equal(a.grad, r.grad)
+
+
 @pytest.mark.parametrize("N,H,W,per_image_bias,stats", [(1, 16, 32, False, False), (2, 48, 96, True, True), (3, 80, 64, False, True),
                                                         (8, 128, 128, False, False), (1, 272, 160, True, True)])
 def test_register_resident_filter_convolution_matches_fp32_reference(N, H, W, per_image_bias, stats):
