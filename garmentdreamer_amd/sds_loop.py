@@ -139,6 +139,13 @@ class SDSLoop:
             out["depth_max"] = local_max
         return out
 
+    def _guidance_graphs_ready(self) -> bool:
+        g = self.guidance
+        cfg = getattr(g, "cfg", None)
+        if cfg is None or not getattr(cfg, "use_hip_graphs", False):
+            return True                                   # eager launches: nothing is ever captured
+        return bool(getattr(g, "_unet_graphs", None)) and bool(getattr(g, "_vae_graphs", None))
+
     # -- one iteration ----------------------------------------------------------------------------
     def step(self, batch: Dict, noise=None, timesteps=None, vae_noise=None) -> Dict:
         """``batch``: this rank's shard of the camera batch (keys as uncond.py:395-408)."""
@@ -154,6 +161,11 @@ class SDSLoop:
         if self.global_step > 500:  # GaussianDreamer.py:233-234
             self.guidance.set_min_max_steps(min_step_percent=0.02, max_step_percent=0.55)
         out = self.render_views(batch)
+        if not self._guidance_graphs_ready():
+            # a call of the guidance that may still CAPTURE a hipGraph: no collective of this process is left in flight across a
+            # capture (the process group's watchdog thread polls pending work with event queries); once the graphs exist the
+            # [radii | depth maximum] collective overlaps their replays
+            out.get("depth_max")
         g_out = self.guidance(out["comp_rgb"], self.prompt_utils, batch["elevation"], batch["azimuth"],
                               batch["camera_distances"], rgb_as_latents=False, guidance_eval=False, noise=noise,
                               timesteps=timesteps, vae_noise=vae_noise)
