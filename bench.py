@@ -537,9 +537,9 @@ def main():
                                   "2*M*Cout*taps*Cin per launch whatever the kernel multiplies, summed over the launches of "
                                   "the timed region.  The MFMA stream alone (no loads / LDS reads / barriers) measures "
                                   "1.2-1.45 PFLOP/s on this chip with random data (power-limited clock, "
-                                  "profiles/r01_conv_ablation.txt; round 4: 1.62 PFLOP/s with the 128 -> 128 layer's whole filter bank resident in "
-                                  "registers and nothing but MFMAs in the kernel, profiles/r04_regw_ablation.txt), i.e. the practical "
-                                  "ceiling is ~0.55-0.65 of `peak`")}
+                                  "profiles/r01_conv_ablation.txt; round 4: two structurally different kernels of the 128 -> 128 layer both "
+                                  "deliver ~1.0 PFLOP/s at 1360-1400 W of the 1400 W cap, profiles/r04_regw_ablation.txt), i.e. the practical "
+                                  "ceiling is ~0.4-0.55 of `peak` by shape")}
     if bwd_n > 0:
         avg_s = bwd_ms / bwd_n * 1e-3
         ach = flops_launch / avg_s / 1e12
