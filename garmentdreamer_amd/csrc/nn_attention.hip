@@ -80,7 +80,8 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                            const uint16_t* __restrict__ vt, uint16_t* __restrict__ o, int S,
                                                            int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs,
-                                                           int64_t o_bs, int o_rs, float c /* scale * log2(e) */, int kv_len)
+                                                           int64_t o_bs, int o_rs, float c /* scale * log2(e) */, int kv_len,
+                                                           float* __restrict__ lse /* [B][H][S] natural-log sum-exp of the scaled scores, or NULL */)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                 // 3 stages
@@ -254,6 +255,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    // what a flash-attention backward pass recomputes P from: ln sum_k exp(scale * s_k) = m * scale + ln l (m is the deferred
+    // running reference, not necessarily the maximum: l is taken relative to it, so the sum is exact either way)
+    if (lse && fh == 0 && qrow < S) lse[((size_t)b * H + h) * S + qrow] = m_run * c * 0.69314718055994531f + __logf(l_tot);
     if (qrow < S) {
         uint16_t* op = o + b * o_bs + (int64_t)qrow * o_rs + h * kD;
 #pragma unroll
@@ -278,7 +282,8 @@ const char* gd_nn_attention_last_error(void) { return g_err; }
 size_t gd_nn_attention_ws_bytes(int B, int Skv, int H) { return (size_t)B * H * 64 * (size_t)Skv * 2; }
 
 static int launch_attention(hipStream_t s, const void* q, const void* k, const void* vt, void* o, int B, int S, int Skv, int H,
-                            int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t o_bs, int o_rs, float scale, int kv_len)
+                            int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t o_bs, int o_rs, float scale, int kv_len,
+                            float* lse = nullptr)
 {
     if (const char* e = getenv("GD_NN_ATTN_WAVES")) g_attn_waves = atoi(e);
     const float c = scale * 1.4426950408889634f;
@@ -287,11 +292,11 @@ static int launch_attention(hipStream_t s, const void* q, const void* k, const v
     if (waves == 8)
         hipLaunchKernelGGL(attn_fwd_d64_kernel<8>, dim3((S + 255) / 256, B * H), dim3(512), 6 * kTile, s, (const uint16_t*)q,
                            (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
-                           o_rs, c, kv_len);
+                           o_rs, c, kv_len, lse);
     else
         hipLaunchKernelGGL(attn_fwd_d64_kernel<4>, dim3((S + 127) / 128, B * H), dim3(256), 6 * kTile, s, (const uint16_t*)q,
                            (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
-                           o_rs, c, kv_len);
+                           o_rs, c, kv_len, lse);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
@@ -318,6 +323,18 @@ int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, cons
     hipLaunchKernelGGL(attn_vt_kernel, dim3(Skv / 64, H, B), dim3(256), 0, s, (const uint16_t*)v, (uint16_t*)vt_ws, Skv, H,
                        v_bs, v_rs, kv_len);
     return launch_attention(s, q, k, vt_ws, o, B, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs, o_rs, scale, kv_len);
+}
+
+int gd_nn_attention_d64_forward_lse(void* stream, const void* q, const void* k, const void* v, void* o, float* lse, void* vt_ws,
+                                    int B, int S, int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs,
+                                    int v_rs, int64_t o_bs, int o_rs, float scale, int kv_len)
+{
+    if (!vt_ws || !lse) return fail(GD_NN_ERR_INVALID_ARG, "attention: null pointer");
+    if (int e = check_attention(q, k, v, o, B, S, Skv, H, q_rs, k_rs, o_rs, kv_len)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_vt_kernel, dim3(Skv / 64, H, B), dim3(256), 0, s, (const uint16_t*)v, (uint16_t*)vt_ws, Skv, H,
+                       v_bs, v_rs, kv_len);
+    return launch_attention(s, q, k, vt_ws, o, B, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs, o_rs, scale, kv_len, lse);
 }
 
 int gd_nn_attention_d64_forward_vt(void* stream, const void* q, const void* k, const void* vt, void* o, int B, int S, int Skv,

@@ -270,7 +270,10 @@ class Attention(nn.Module):
         q = q.view(B, N, self.heads, -1)
         k = k.view(B, ctx.shape[1], self.heads, -1)
         v = v.view(B, ctx.shape[1], self.heads, -1)
-        if N >= 256 and q.shape[-1] == 64 and attention_d64_supported(q, k, v):
+        if N >= 256 and q.shape[-1] == 64 and nn_ops.attention_d64_train_supported(q, k, v):
+            # training pass (LoRA UNet): own forward kernel + the library's flash backward on its log-sum-exp
+            o = nn_ops.attention_d64_train(q, k, v)
+        elif N >= 256 and q.shape[-1] == 64 and attention_d64_supported(q, k, v):
             # spatial self-attention and (round 2) cross-attention over the 77 text tokens, head_dim 64, inference: own fused kernel (nn_ops.attention_d64; 1.1-1.3x SDPA at
             # batch 16, 1.8-2x at batch 2 on MI355X, tools/attn_bench.py)
             o = attention_d64(q, k, v)

@@ -88,6 +88,8 @@ SIGNATURES = {
     "gd_nn_attention_ws_bytes": (C.c_size_t, [_i, _i, _i]),
     "gd_nn_attention_d64_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i,
                                          C.c_int64, _i, C.c_int64, _i, _f, _i]),
+    "gd_nn_attention_d64_forward_lse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i,
+                                             C.c_int64, _i, C.c_int64, _i, _f, _i]),
     "gd_nn_attention_d64_forward_vt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i, C.c_int64, _i,
                                             _f]),
     "gd_nn_attention_last_error": (C.c_char_p, []),
@@ -1102,6 +1104,7 @@ class _GegluTrain(torch.autograd.Function):
         return dx
 
 
+_ATTN_TRAIN = os.environ.get("GD_ATTN_TRAIN", "1") != "0"    # A/B toggle: own attention forward kernel in the training pass
 _ROW_TRAIN = os.environ.get("GD_ROW_TRAIN", "1") != "0"    # A/B toggle: own GEGLU / LayerNorm backward in the training pass
 
 
@@ -1197,12 +1200,22 @@ def add_layer_norm(x, residual, norm, want_sum: bool = True):
 # fused self-attention forward (head_dim 64, inference)
 # ---------------------------------------------------------------------------------------------
 
-def attention_d64_supported(q, k, v) -> bool:
-    """q, k, v: [B, S, H, 64] views (any batch / row stride, head and channel dims contiguous)."""
+def _attention_d64_layout_ok(q, k, v) -> bool:
     ok = lambda t: (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[-1] == 64 and t.stride(-1) == 1
                     and t.stride(2) == 64 and t.stride(1) % 8 == 0)   # noqa: E731
-    return (ok(q) and ok(k) and ok(v) and k.shape == v.shape and q.shape[0] == k.shape[0]
-            and q.shape[2] == k.shape[2] and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)))
+    return ok(q) and ok(k) and ok(v) and k.shape == v.shape and q.shape[0] == k.shape[0] and q.shape[2] == k.shape[2]
+
+
+def attention_d64_supported(q, k, v) -> bool:
+    """q, k, v: [B, S, H, 64] views (any batch / row stride, head and channel dims contiguous), no gradient needed."""
+    return _attention_d64_layout_ok(q, k, v) and \
+        not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad))
+
+
+def attention_d64_train_supported(q, k, v) -> bool:
+    """The same layouts WITH a gradient (training pass of the LoRA UNet): ``attention_d64_train``."""
+    return _ATTN_TRAIN and torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad) and \
+        _attention_d64_layout_ok(q, k, v)
 
 
 def attention_d64(q, k, v):
@@ -1222,6 +1235,45 @@ def attention_d64(q, k, v):
     if ret < 0:
         raise RuntimeError(f"gd_nn_attention_d64_forward failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
     return o
+
+
+class _AttentionD64Train(torch.autograd.Function):
+    """Attention of the LoRA UNet's training pass: the own forward kernel (which also returns the per-query log-sum-exp) and the
+    library's flash-attention backward, which recomputes the probabilities from exactly that tensor (natural log of the
+    scaled scores' sum-exp, [B, H, S] fp32 -- tools/sdpa_lse_probe.py).  q, k, v: [B, S, H, 64] views."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        B, S, H, _ = q.shape
+        kv_len = k.shape[1]
+        Skv = (kv_len + 63) // 64 * 64
+        L = lib()
+        o = torch.empty((B, S, H * 64), dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+        ws = torch.empty(L.gd_nn_attention_ws_bytes(B, Skv, H), dtype=torch.uint8, device=q.device)
+        with torch.cuda.device(q.device):
+            ret = L.gd_nn_attention_d64_forward_lse(torch.cuda.current_stream(q.device).cuda_stream, q.data_ptr(), k.data_ptr(),
+                                                    v.data_ptr(), o.data_ptr(), lse.data_ptr(), ws.data_ptr(), B, S, Skv, H,
+                                                    q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                                    o.stride(0), o.stride(1), 64 ** -0.5, kv_len)
+        if ret < 0:
+            raise RuntimeError(f"gd_nn_attention_d64_forward_lse failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, S, H, _ = q.shape
+        z = torch.zeros((), dtype=torch.long, device=q.device)       # philox seed / offset: unused without dropout
+        dq, dk, dv = torch.ops.aten._scaled_dot_product_flash_attention_backward(
+            do.reshape(B, S, H, 64).transpose(1, 2), q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
+            o.view(B, S, H, 64).transpose(1, 2), lse, None, None, S, k.shape[1], 0.0, False, z, z, scale=64 ** -0.5)
+        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)
+
+
+def attention_d64_train(q, k, v):
+    return _AttentionD64Train.apply(q, k, v)
 
 
 def attention_d64_vt(q, k, vt):

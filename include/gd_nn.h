@@ -273,6 +273,12 @@ int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, cons
 /* The same kernel for a caller that already holds V TRANSPOSED: vt = [B][H][64][Skv] contiguous bf16, keys in natural
  * order, all Skv keys valid (Skv % 64 == 0) -- e.g. the output of the GEMM  W_v x^T, which replaces the V projection
  * AND the transposing pre-pass of the entry above. */
+/* The same forward pass, also returning lse [B][H][S] fp32 = ln sum_k exp(scale * q.k) per query -- what a flash-attention
+ * BACKWARD pass recomputes the probabilities from (training pass of the NeTF stage's LoRA UNet: the forward runs here, the
+ * backward on the library's flash kernels, which take this tensor). */
+int gd_nn_attention_d64_forward_lse(void* stream, const void* q, const void* k, const void* v, void* o, float* lse, void* vt_ws,
+                                    int B, int S, int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs,
+                                    int v_rs, int64_t o_bs, int o_rs, float scale, int kv_len);
 int gd_nn_attention_d64_forward_vt(void* stream, const void* q, const void* k, const void* vt, void* o, int B, int S, int Skv,
                                    int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t o_bs, int o_rs, float scale);
 const char* gd_nn_attention_last_error(void);

@@ -1177,6 +1177,35 @@ def test_training_row_passes_forward_and_backward_match_fp32_reference(rows, C):
             assert torch.equal(a.grad, r.grad)
 
 
+@pytest.mark.parametrize("B,S,Skv,H", [(2, 256, 256, 5), (1, 1024, 77, 10), (2, 4096, 4096, 5), (1, 320, 320, 20)])
+def test_attention_training_node_matches_fp32_reference(B, S, Skv, H):
+    """The own forward kernel with its log-sum-exp output + the library's flash backward (nn_ops.attention_d64_train: the LoRA
+    UNet's training pass) against fp32 PyTorch: output, the LSE tensor itself, and dq / dk / dv; self- and cross-attention
+    shapes, strided [B, S, H, 64] views of wider projections."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(S + Skv + H)
+    C = H * 64
+    wq = (torch.randn(B, S, C + 64, device=DEV, generator=g)).to(torch.bfloat16)
+    wkv = (torch.randn(B, Skv, 2 * C, device=DEV, generator=g)).to(torch.bfloat16)
+    q = wq[..., :C].view(B, S, H, 64).detach().requires_grad_(True)
+    k = wkv[..., :C].view(B, Skv, H, 64).detach().requires_grad_(True)
+    v = wkv[..., C:].view(B, Skv, H, 64).detach().requires_grad_(True)
+    assert nn_ops.attention_d64_train_supported(q, k, v)
+    do = torch.randn(B, S, C, device=DEV, generator=g).to(torch.bfloat16)
+    o = nn_ops.attention_d64_train(q, k, v)
+    lse = o.grad_fn.saved_tensors[4].clone()
+    o.backward(do)
+    qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    sc = torch.einsum("bshd,bthd->bhst", qf, kf) / 8.0
+    of = torch.einsum("bhst,bthd->bshd", torch.softmax(sc, -1), vf).reshape(B, S, C)
+    of.backward(do.float())
+    assert (lse - torch.logsumexp(sc.detach(), -1)).abs().max().item() < 2e-3
+    def rel(a, b):
+        return ((a.float() - b).abs().max() / b.abs().max()).item()
+    assert rel(o.detach(), of.detach()) < 2e-2
+    assert rel(q.grad, qf.grad) < 2e-2 and rel(k.grad, kf.grad) < 2e-2 and rel(v.grad, vf.grad) < 2e-2
+
+
 @pytest.mark.parametrize("N,H,W,per_image_bias,stats", [(1, 16, 32, False, False), (2, 48, 96, True, True), (3, 80, 64, False, True),
                                                         (8, 128, 128, False, False), (1, 272, 160, True, True)])
 def test_register_resident_filter_convolution_matches_fp32_reference(N, H, W, per_image_bias, stats):
