@@ -273,6 +273,222 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward pass (training pass of the NeTF stage's LoRA UNet), built from the forward kernel's pieces: transposed score
+// tiles with one "row-side" element per lane, P / dS packed to bf16 in place as the B operand of the next product.
+//   MODE 0 (dQ):      lanes own QUERIES, 64-key tiles stream.   S^T = K Q^T,  dP^T = V dO^T,  P^T = exp2(S^T c - L[q]),
+//                     dS^T = P^T (dP^T - D[q]),  dQ^T += K^T dS^T            (L, D: one value per lane)
+//   MODE 1 (dK, dV):  lanes own KEYS, 64-query tiles stream.    S = Q K^T,  dP = dO V^T,  P = exp2(S c - L[q]),
+//                     dS = P (dP - D[q]),  dV^T += dO^T P,  dK^T += Q^T dS   (L, D: per streamed row, 16 float4 per tile)
+// L = lse log2(e) with the forward pass's log-sum-exp (no running maximum here), D = rowsum(dO o O) (attn_dsum_kernel).
+// The transposed streamed operands (K^T; dO^T, Q^T) come from attn_vt_kernel, like V^T in the forward pass.  Two LDS
+// stages, loads of tile t + 1 in flight during tile t.  P and dS are rounded to bf16 where they enter an MFMA, as in every
+// flash backward.
+__global__ __launch_bounds__(256) void attn_dsum_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ dout,
+                                                        float* __restrict__ dsum, int B, int S, int H, int64_t o_bs, int o_rs,
+                                                        int64_t d_bs, int d_rs)
+{
+    // one thread per 8 channels, 8 threads per (b, s, h) row of 64
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int part = (int)(i & 7);
+    const int64_t row = i >> 3;                      // (b * S + s) * H + h
+    const int h = (int)(row % H);
+    const int64_t bs = row / H;
+    const int sidx = (int)(bs % S), b = (int)(bs / S);
+    float acc = 0.f;
+    if (b < B) {
+        const uint4 a = *(const uint4*)(o + b * o_bs + (int64_t)sidx * o_rs + h * 64 + part * 8);
+        const uint4 g = *(const uint4*)(dout + b * d_bs + (int64_t)sidx * d_rs + h * 64 + part * 8);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            acc += __uint_as_float(aw[e] << 16) * __uint_as_float(gw[e] << 16) +
+                   __uint_as_float(aw[e] & 0xffff0000u) * __uint_as_float(gw[e] & 0xffff0000u);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (part == 0 && b < B) dsum[((size_t)b * H + h) * S + sidx] = acc;
+}
+
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void attn_bwd_d64_kernel(
+    const uint16_t* __restrict__ r1, int64_t r1_bs, int r1_rs, const uint16_t* __restrict__ r2, int64_t r2_bs, int r2_rs,
+    const uint16_t* __restrict__ x1, int64_t x1_bs, int x1_rs, const uint16_t* __restrict__ x2, int64_t x2_bs, int x2_rs,
+    const uint16_t* __restrict__ t1, const uint16_t* __restrict__ t2, const float* __restrict__ lse,
+    const float* __restrict__ dsum, uint16_t* __restrict__ out1, int64_t o1_bs, int o1_rs, uint16_t* __restrict__ out2,
+    int64_t o2_bs, int o2_rs, int Sr, int Sc, int H, float c, float scale, int r_len, int c_len, int Sq)
+{
+    constexpr int NT = MODE == 0 ? 3 : 4;            // tiles per stage: x1, x2, t1 (, t2)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y / H, h = blockIdx.y - b * H;
+    const int fh = lane >> 5, fn = lane & 31;
+    constexpr int THREADS = 64 * WAVES, NP = 512 / THREADS;     // 16-byte pieces of a 64 x 64 tile per thread
+    const int rrow = blockIdx.x * (32 * WAVES) + wave * 32 + fn;
+    const int rld = rrow < r_len ? rrow : r_len - 1;
+    const float log2e = 1.4426950408889634f;
+
+    bf16x8_t f1[4], f2[4];      // row-side fragments (B operands): lane (row fn, half fh) holds d = 16 kk + 8 fh .. + 7
+    {
+        const uint16_t* p1 = r1 + b * r1_bs + (int64_t)rld * r1_rs + h * kD + 8 * fh;
+        const uint16_t* p2 = r2 + b * r2_bs + (int64_t)rld * r2_rs + h * kD + 8 * fh;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) { f1[kk] = *(const bf16x8_t*)(p1 + 16 * kk); f2[kk] = *(const bf16x8_t*)(p2 + 16 * kk); }
+    }
+    const size_t stat_base = ((size_t)b * H + h) * Sq;
+    float Lr = 0.f, Dr = 0.f;
+    if (MODE == 0) { Lr = lse[stat_base + rld] * log2e; Dr = dsum[stat_base + rld]; }
+
+    const uint32_t x1_row = (uint32_t)x1_rs * 2u, x2_row = (uint32_t)x2_rs * 2u, t_row = (uint32_t)Sc * 2u;
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)(x1 + b * x1_bs + h * kD), 0, (int)((uint32_t)c_len * x1_row), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(x2 + b * x2_bs + h * kD), 0, (int)((uint32_t)c_len * x2_row), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t1 = __builtin_amdgcn_make_buffer_rsrc((void*)(t1 + (((int64_t)b * H + h) * kD) * Sc), 0, (int)((uint32_t)kD * t_row), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t2 = __builtin_amdgcn_make_buffer_rsrc((void*)((MODE == 1 ? t2 : t1) + (((int64_t)b * H + h) * kD) * Sc), 0, (int)((uint32_t)kD * t_row), 0x00020000);
+    uint32_t a_off[NP], b_off[NP], t_off[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int cidx = tid + THREADS * i;
+        const int line = cidx >> 4, cc = (cidx & 15) ^ (line & 15);
+        const int r = 2 * line + (cc >> 3);
+        a_off[i] = (uint32_t)r * x1_row + (uint32_t)(cc & 7) * 16u;
+        b_off[i] = (uint32_t)r * x2_row + (uint32_t)(cc & 7) * 16u;
+        t_off[i] = (uint32_t)r * t_row + (uint32_t)(cc & 7) * 16u;
+    }
+    auto issue = [&](int buf, int t) {
+        char* st = smem + buf * (NT * kTile);
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            bload_lds16(rs_x1, a_off[i], (uint32_t)t * kTk * x1_row, st + (wave * 64 + THREADS * i) * 16);
+            bload_lds16(rs_x2, b_off[i], (uint32_t)t * kTk * x2_row, st + kTile + (wave * 64 + THREADS * i) * 16);
+            bload_lds16(rs_t1, t_off[i], (uint32_t)t * (kTk * 2), st + 2 * kTile + (wave * 64 + THREADS * i) * 16);
+            if (MODE == 1) bload_lds16(rs_t2, t_off[i], (uint32_t)t * (kTk * 2), st + 3 * kTile + (wave * 64 + THREADS * i) * 16);
+        }
+    };
+    uint32_t krd[2], vrd[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int p16 = fn & 15, key16 = p16 < 4 ? p16 : (p16 < 8 ? p16 + 4 : (p16 < 12 ? p16 - 4 : p16));
+        krd[j] = (uint32_t)swz(32 * j + (fn & 16) + key16, fh);
+        vrd[j] = (uint32_t)swz(32 * j + fn, fh);
+    }
+    f32x16 g0, g1, e0, e1;      // out1 (d blocks 0 / 1), out2 (MODE 1)
+#pragma unroll
+    for (int r = 0; r < 16; r++) g0[r] = g1[r] = e0[r] = e1[r] = 0.f;
+
+    const int ntiles = Sc / kTk;
+    issue(0, 0);
+    for (int t = 0; t < ntiles; t++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntiles) issue((t + 1) & 1, t + 1);
+        const char* st = smem + (t & 1) * (NT * kTile);
+        f32x16 s0, s1, p0, p1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s0[r] = s1[r] = p0[r] = p1[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const bf16x8_t a0 = *(const bf16x8_t*)(st + (krd[0] ^ (uint32_t)(kk << 5)));
+            const bf16x8_t a1 = *(const bf16x8_t*)(st + (krd[1] ^ (uint32_t)(kk << 5)));
+            const bf16x8_t b0 = *(const bf16x8_t*)(st + kTile + (krd[0] ^ (uint32_t)(kk << 5)));
+            const bf16x8_t b1 = *(const bf16x8_t*)(st + kTile + (krd[1] ^ (uint32_t)(kk << 5)));
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, f1[kk], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, f1[kk], s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, f2[kk], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, f2[kk], p1, 0, 0, 0);
+        }
+        // accumulator row r of block j holds streamed element 32 j + 16 (r >> 3) + 8 fh + 4 ((r >> 2) & 1) + (r & 3)
+        float Lq[2][16], Dq[2][16];
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {       // g = (r >> 2): u = g >> 1, w = g & 1
+                    const size_t idx = stat_base + (size_t)t * kTk + 32 * j + 16 * (g >> 1) + 8 * fh + 4 * (g & 1);
+                    const float4 l4 = *(const float4*)(lse + idx), d4 = *(const float4*)(dsum + idx);
+                    Lq[j][4 * g] = l4.x * log2e; Lq[j][4 * g + 1] = l4.y * log2e; Lq[j][4 * g + 2] = l4.z * log2e; Lq[j][4 * g + 3] = l4.w * log2e;
+                    Dq[j][4 * g] = d4.x; Dq[j][4 * g + 1] = d4.y; Dq[j][4 * g + 2] = d4.z; Dq[j][4 * g + 3] = d4.w;
+                }
+        }
+        // P (into s*) and dS (into p*)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float m0 = 0.f, m1 = 0.f;      // masks of streamed padding (MODE 0: keys beyond c_len)
+            if (MODE == 0) {
+                const int key = t * kTk + 16 * (r >> 3) + 8 * fh + 4 * ((r >> 2) & 1) + (r & 3);
+                m0 = key >= c_len ? -INFINITY : 0.f;
+                m1 = key + 32 >= c_len ? -INFINITY : 0.f;
+            }
+            const float l0 = MODE == 0 ? Lr : Lq[0][r], l1 = MODE == 0 ? Lr : Lq[1][r];
+            const float d0 = MODE == 0 ? Dr : Dq[0][r], d1 = MODE == 0 ? Dr : Dq[1][r];
+            const float pa = __builtin_amdgcn_exp2f(s0[r] * c - l0 + m0), pb_ = __builtin_amdgcn_exp2f(s1[r] * c - l1 + m1);
+            s0[r] = pa; s1[r] = pb_;
+            p0[r] = pa * (p0[r] - d0);
+            p1[r] = pb_ * (p1[r] - d1);
+        }
+        bf16x8_t pP[4], pS[4];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            uint32_t w0[4], w1[4], z0[4], z1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                w0[i] = pack_bf16(s0[8 * u + 2 * i], s0[8 * u + 2 * i + 1]);
+                w1[i] = pack_bf16(s1[8 * u + 2 * i], s1[8 * u + 2 * i + 1]);
+                z0[i] = pack_bf16(p0[8 * u + 2 * i], p0[8 * u + 2 * i + 1]);
+                z1[i] = pack_bf16(p1[8 * u + 2 * i], p1[8 * u + 2 * i + 1]);
+            }
+            pP[u] = __builtin_bit_cast(bf16x8_t, make_uint4(w0[0], w0[1], w0[2], w0[3]));
+            pP[2 + u] = __builtin_bit_cast(bf16x8_t, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+            pS[u] = __builtin_bit_cast(bf16x8_t, make_uint4(z0[0], z0[1], z0[2], z0[3]));
+            pS[2 + u] = __builtin_bit_cast(bf16x8_t, make_uint4(z1[0], z1[1], z1[2], z1[3]));
+        }
+#pragma unroll
+        for (int g16 = 0; g16 < 4; g16++) {
+            const bf16x8_t v0 = *(const bf16x8_t*)(st + 2 * kTile + (vrd[0] ^ (uint32_t)(g16 << 5)));
+            const bf16x8_t v1 = *(const bf16x8_t*)(st + 2 * kTile + (vrd[1] ^ (uint32_t)(g16 << 5)));
+            if (MODE == 0) {            // dQ^T += K^T dS^T
+                g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pS[g16], g0, 0, 0, 0);
+                g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pS[g16], g1, 0, 0, 0);
+            } else {                    // dV^T += dO^T P,  dK^T += Q^T dS
+                const bf16x8_t q0 = *(const bf16x8_t*)(st + 3 * kTile + (vrd[0] ^ (uint32_t)(g16 << 5)));
+                const bf16x8_t q1 = *(const bf16x8_t*)(st + 3 * kTile + (vrd[1] ^ (uint32_t)(g16 << 5)));
+                g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pP[g16], g0, 0, 0, 0);
+                g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pP[g16], g1, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, pS[g16], e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1, pS[g16], e1, 0, 0, 0);
+            }
+        }
+    }
+    if (rrow < r_len) {
+        const float s1f = MODE == 0 ? scale : 1.0f;
+        uint16_t* op = out1 + b * o1_bs + (int64_t)rrow * o1_rs + h * kD;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {         // rows d = (r & 3) + 8 (r >> 2) + 4 fh of each 32-d block
+            uint2 a, bq;
+            a.x = pack_bf16(g0[4 * g4] * s1f, g0[4 * g4 + 1] * s1f);
+            a.y = pack_bf16(g0[4 * g4 + 2] * s1f, g0[4 * g4 + 3] * s1f);
+            bq.x = pack_bf16(g1[4 * g4] * s1f, g1[4 * g4 + 1] * s1f);
+            bq.y = pack_bf16(g1[4 * g4 + 2] * s1f, g1[4 * g4 + 3] * s1f);
+            *(uint2*)(op + 8 * g4 + 4 * fh) = a;
+            *(uint2*)(op + 32 + 8 * g4 + 4 * fh) = bq;
+        }
+        if (MODE == 1) {
+            uint16_t* op2 = out2 + b * o2_bs + (int64_t)rrow * o2_rs + h * kD;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                uint2 a, bq;
+                a.x = pack_bf16(e0[4 * g4] * scale, e0[4 * g4 + 1] * scale);
+                a.y = pack_bf16(e0[4 * g4 + 2] * scale, e0[4 * g4 + 3] * scale);
+                bq.x = pack_bf16(e1[4 * g4] * scale, e1[4 * g4 + 1] * scale);
+                bq.y = pack_bf16(e1[4 * g4 + 2] * scale, e1[4 * g4 + 3] * scale);
+                *(uint2*)(op2 + 8 * g4 + 4 * fh) = a;
+                *(uint2*)(op2 + 32 + 8 * g4 + 4 * fh) = bq;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -342,6 +558,59 @@ int gd_nn_attention_d64_forward_vt(void* stream, const void* q, const void* k, c
 {
     if (int e = check_attention(q, k, vt, o, B, S, Skv, H, q_rs, k_rs, o_rs, Skv)) return e;
     return launch_attention((hipStream_t)stream, q, k, vt, o, B, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs, o_rs, scale, Skv);
+}
+
+// Workspace of the backward pass: K^T [B][H][64][Skv], Q^T and dO^T [B][H][64][S] (bf16), D [B][H][S] (fp32).
+size_t gd_nn_attention_bwd_ws_bytes(int B, int S, int Skv, int H)
+{
+    return (size_t)B * H * 64 * ((size_t)Skv + 2 * (size_t)S) * 2 + (size_t)B * H * S * 4;
+}
+
+int gd_nn_attention_d64_backward(void* stream, const void* q, const void* k, const void* v, const void* o, const void* dout,
+                                 const float* lse, void* dq, void* dk, void* dv, void* ws, int B, int S, int Skv, int H,
+                                 int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs, int v_rs, int64_t o_bs, int o_rs,
+                                 int64_t do_bs, int do_rs, int64_t dq_bs, int dq_rs, int64_t dk_bs, int dk_rs, int64_t dv_bs,
+                                 int dv_rs, float scale, int kv_len)
+{
+    if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !ws) return fail(GD_NN_ERR_INVALID_ARG, "attention_backward: null pointer");
+    if (B <= 0 || S <= 0 || H <= 0 || Skv <= 0 || (S & 63) || (Skv & 63) || kv_len <= Skv - 64 || kv_len > Skv)
+        return fail(GD_NN_ERR_INVALID_ARG, "attention_backward: need S % 64 == 0, Skv % 64 == 0, Skv - 64 < kv_len <= Skv");
+    if (q_rs % 8 || k_rs % 8 || v_rs % 8 || o_rs % 8 || do_rs % 8 || dq_rs % 4 || dk_rs % 4 || dv_rs % 4 ||
+        (double)Skv * k_rs * 2.0 >= 2147483648.0 || (double)S * q_rs * 2.0 >= 2147483648.0)
+        return fail(GD_NN_ERR_INVALID_ARG, "attention_backward: row strides must keep 16-byte / 8-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    uint16_t* kt = (uint16_t*)ws;
+    uint16_t* qt = kt + (size_t)B * H * 64 * Skv;
+    uint16_t* dot = qt + (size_t)B * H * 64 * S;
+    float* dsum = (float*)(dot + (size_t)B * H * 64 * S);
+    hipLaunchKernelGGL(attn_vt_kernel, dim3(Skv / 64, H, B), dim3(256), 0, s, (const uint16_t*)k, kt, Skv, H, k_bs, k_rs, kv_len);
+    hipLaunchKernelGGL(attn_vt_kernel, dim3(S / 64, H, B), dim3(256), 0, s, (const uint16_t*)q, qt, S, H, q_bs, q_rs, S);
+    hipLaunchKernelGGL(attn_vt_kernel, dim3(S / 64, H, B), dim3(256), 0, s, (const uint16_t*)dout, dot, S, H, do_bs, do_rs, S);
+    const int64_t rows8 = (int64_t)B * S * H * 8;
+    hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((rows8 + 255) / 256)), dim3(256), 0, s, (const uint16_t*)o,
+                       (const uint16_t*)dout, dsum, B, S, H, o_bs, o_rs, do_bs, do_rs);
+    const float c = scale * 1.4426950408889634f;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_d64_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * kTile);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_d64_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * kTile);
+        attr_set = true;
+    }
+    // (64 row-side elements per workgroup -- the two-wave instantiation -- measured SLOWER on the one-latent grids it was meant
+    // for: 309 against 260 us at S = 4096, 5 heads, tools/attn_bwd_bench.py; four waves always)
+    // dQ: lanes = queries, keys stream
+    hipLaunchKernelGGL((attn_bwd_d64_kernel<0, 4>), dim3((S + 127) / 128, B * H), dim3(256), 2 * 3 * kTile, s, (const uint16_t*)q,
+                       q_bs, q_rs, (const uint16_t*)dout, do_bs, do_rs, (const uint16_t*)k, k_bs, k_rs, (const uint16_t*)v, v_bs,
+                       v_rs, kt, (const uint16_t*)nullptr, lse, dsum, (uint16_t*)dq, dq_bs, dq_rs, (uint16_t*)nullptr, (int64_t)0,
+                       0, S, Skv, H, c, scale, S, kv_len, S);
+    // dK, dV: lanes = keys, queries stream
+    hipLaunchKernelGGL((attn_bwd_d64_kernel<1, 4>), dim3((kv_len + 127) / 128, B * H), dim3(256), 2 * 4 * kTile, s,
+                       (const uint16_t*)k, k_bs, k_rs, (const uint16_t*)v, v_bs, v_rs, (const uint16_t*)q, q_bs, q_rs,
+                       (const uint16_t*)dout, do_bs, do_rs, dot, qt, lse, dsum, (uint16_t*)dv, dv_bs, dv_rs, (uint16_t*)dk, dk_bs,
+                       dk_rs, kv_len, S, H, c, scale, kv_len, S, S);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
 }
 
 }  // extern "C"

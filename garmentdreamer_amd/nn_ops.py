@@ -90,6 +90,8 @@ SIGNATURES = {
                                          C.c_int64, _i, C.c_int64, _i, _f, _i]),
     "gd_nn_attention_d64_forward_lse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i,
                                              C.c_int64, _i, C.c_int64, _i, _f, _i]),
+    "gd_nn_attention_bwd_ws_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "gd_nn_attention_d64_backward": (_i, [_vp] * 11 + [_i, _i, _i, _i] + [C.c_int64, _i] * 8 + [_f, _i]),
     "gd_nn_attention_d64_forward_vt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i, C.c_int64, _i,
                                             _f]),
     "gd_nn_attention_last_error": (C.c_char_p, []),
@@ -1105,6 +1107,8 @@ class _GegluTrain(torch.autograd.Function):
 
 
 _ATTN_TRAIN = os.environ.get("GD_ATTN_TRAIN", "1") != "0"    # A/B toggle: own attention forward kernel in the training pass
+_ATTN_BWD = os.environ.get("GD_ATTN_BWD", "1") != "0"        # A/B toggle: own attention backward kernels (else the library's flash backward)
+_ATTN_BWD_MIN_KEYS = 256                                     # fewer keys (cross-attention): library backward (tests lower it)
 _ROW_TRAIN = os.environ.get("GD_ROW_TRAIN", "1") != "0"    # A/B toggle: own GEGLU / LayerNorm backward in the training pass
 
 
@@ -1265,6 +1269,27 @@ class _AttentionD64Train(torch.autograd.Function):
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
         B, S, H, _ = q.shape
+        kv_len = k.shape[1]
+        # own backward kernels for self-attention; with a handful of keys (the 77 text tokens) the key-owning kernel has one
+        # workgroup per head and the library's flash backward is faster (0.8x at S = 4096, tools/attn_bwd_bench.py)
+        if _ATTN_BWD and S % 64 == 0 and kv_len >= _ATTN_BWD_MIN_KEYS:
+            Skv = (kv_len + 63) // 64 * 64
+            do = do.contiguous()
+            L = lib()
+            dq = torch.empty((B, S, H, 64), dtype=torch.bfloat16, device=q.device)
+            dk = torch.empty((B, kv_len, H, 64), dtype=torch.bfloat16, device=q.device)
+            dv = torch.empty((B, kv_len, H, 64), dtype=torch.bfloat16, device=q.device)
+            ws = torch.empty(L.gd_nn_attention_bwd_ws_bytes(B, S, Skv, H), dtype=torch.uint8, device=q.device)
+            with torch.cuda.device(q.device):
+                ret = L.gd_nn_attention_d64_backward(
+                    torch.cuda.current_stream(q.device).cuda_stream, q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
+                    do.data_ptr(), lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, S, Skv, H,
+                    q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1),
+                    do.stride(0), do.stride(1), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1), dv.stride(0),
+                    dv.stride(1), 64 ** -0.5, kv_len)
+            if ret < 0:
+                raise RuntimeError(f"gd_nn_attention_d64_backward failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
+            return dq, dk, dv
         z = torch.zeros((), dtype=torch.long, device=q.device)       # philox seed / offset: unused without dropout
         dq, dk, dv = torch.ops.aten._scaled_dot_product_flash_attention_backward(
             do.reshape(B, S, H, 64).transpose(1, 2), q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),

@@ -279,6 +279,17 @@ int gd_nn_attention_d64_forward(void* stream, const void* q, const void* k, cons
 int gd_nn_attention_d64_forward_lse(void* stream, const void* q, const void* k, const void* v, void* o, float* lse, void* vt_ws,
                                     int B, int S, int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs,
                                     int v_rs, int64_t o_bs, int o_rs, float scale, int kv_len);
+/* Backward of the same attention (head_dim 64) from q, k, v, the forward output o, its gradient dout and lse: dq, dk, dv in the
+ * layouts of q, k, v ([B][S | Skv][H * 64] rows with their own strides).  S % 64 == 0; Skv = the key count rounded up to 64,
+ * kv_len the true count.  ws = gd_nn_attention_bwd_ws_bytes(B, S, Skv, H) bytes (K^T, Q^T, dO^T, rowsum(dO o O)).  Replaces
+ * autograd's backward of F.scaled_dot_product_attention in the training pass of the NeTF stage's LoRA UNet
+ * (netf/vsd/lora_unet.py's attention processors; netf/trainer.py:215-256). */
+size_t gd_nn_attention_bwd_ws_bytes(int B, int S, int Skv, int H);
+int gd_nn_attention_d64_backward(void* stream, const void* q, const void* k, const void* v, const void* o, const void* dout,
+                                 const float* lse, void* dq, void* dk, void* dv, void* ws, int B, int S, int Skv, int H,
+                                 int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t v_bs, int v_rs, int64_t o_bs, int o_rs,
+                                 int64_t do_bs, int do_rs, int64_t dq_bs, int dq_rs, int64_t dk_bs, int dk_rs, int64_t dv_bs,
+                                 int dv_rs, float scale, int kv_len);
 int gd_nn_attention_d64_forward_vt(void* stream, const void* q, const void* k, const void* vt, void* o, int B, int S, int Skv,
                                    int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t o_bs, int o_rs, float scale);
 const char* gd_nn_attention_last_error(void);
