@@ -211,7 +211,10 @@ def vsd_main(args):
     lora.adapters_to_fp32()          # the reference trains the rank-4 adapters in fp32 (sd_vsd_utils.py:35); base weights bf16
     train = lora.freeze_base()
     q = LoraUnet(lora)
-    opt = torch.optim.AdamW(train, lr=1e-4)
+    # trainer.py:137 steps torch.optim.Adam over the adapters + embeddings: here one launch over the flat fp32 adapter buffer
+    # (garmentdreamer_amd/flat_adam.py; constructed BEFORE the training graphs are captured -- it re-seats the adapters)
+    from garmentdreamer_amd.flat_adam import FlatAdam
+    opt = FlatAdam(train, lr=1e-4) if os.environ.get("GD_FLAT_ADAM", "1") != "0" else torch.optim.Adam(train, lr=1e-4)
     g = torch.Generator(device=device).manual_seed(7 + rk)
     gd.set_text_embeds(torch.randn(1, 77, 1024, device=device, generator=g),
                        torch.randn(1, 77, 1024, device=device, generator=g))

@@ -12,6 +12,12 @@
 //   gd_nn_lora_colreduce   g(r, j) = s * sum_m a[m][j] v[m][r]          weight gradients: per row-chunk partial sums in registers,
 //                                                                      then a fixed-order sum over the chunks (no atomics:
 //                                                                      the LoRA gradients are bitwise reproducible)
+//   gd_nn_lora_row_fused  rowdot and rank4_add of one row by the SAME wave in one launch: h never makes the round trip through
+//                          HBM before its use, and the pair costs one kernel floor (~4.7 us inside a hipGraph) instead of two --
+//                          the branch is 128 adapted projections per UNet pass.  Forward: w1 = down, w2 = up, base = the frozen
+//                          projection; backward: a = dy, w1 = up, w2 = down, base = the frozen projection's own dx (so autograd's
+//                          add of the two input gradients is gone as well).  Same operations in the same order as the two
+//                          kernels: bit-identical results.
 // All HBM streams of [M][K] / [M][N] bf16 tensors; 16-byte accesses.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -128,6 +134,81 @@ __global__ __launch_bounds__(256) void lora_rank4_add_kernel(const float4* __res
     }
 }
 
+// One wave per row m: h = scale * (a[m][:] . w1(r, :)) exactly as lora_rowdot_kernel<BWD> sums it (every lane ends the xor
+// butterfly with the same bits), stored for the weight-gradient reductions / the backward pass, then
+// y[m][:] = base[m][:] + sum_r h_r w2(r, :) exactly as lora_rank4_add_kernel<!BWD> evaluates it.
+// BWD = false: w1 = down [4][K], w2 = up [N][4].  BWD = true: w1 = up [K][4], w2 = down [4][N].
+template <bool BWD>
+__global__ __launch_bounds__(256) void lora_row_fused_kernel(const u32x4* __restrict__ a, const float* __restrict__ w1,
+                                                             const float* __restrict__ w2, const u32x4* __restrict__ base,
+                                                             float4* __restrict__ h, u32x4* __restrict__ y, int M, int K8, int N8,
+                                                             float scale)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int K = K8 * 8, N = N8 * 8;
+    for (int k8 = lane; k8 < K8; k8 += 64) {
+        const u32x4 q = a[(size_t)m * K8 + k8];
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { x[2 * e] = lo16(q.w[e]); x[2 * e + 1] = hi16(q.w[e]); }
+        if (BWD) {
+            const float4* wp = (const float4*)w1 + (size_t)k8 * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float4 t = wp[e];
+                acc[0] = fmaf(x[e], t.x, acc[0]); acc[1] = fmaf(x[e], t.y, acc[1]);
+                acc[2] = fmaf(x[e], t.z, acc[2]); acc[3] = fmaf(x[e], t.w, acc[3]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4 t0 = *(const float4*)(w1 + (size_t)r * K + k8 * 8), t1 = *(const float4*)(w1 + (size_t)r * K + k8 * 8 + 4);
+                acc[r] = fmaf(x[0], t0.x, fmaf(x[1], t0.y, fmaf(x[2], t0.z, fmaf(x[3], t0.w, acc[r]))));
+                acc[r] = fmaf(x[4], t1.x, fmaf(x[5], t1.y, fmaf(x[6], t1.z, fmaf(x[7], t1.w, acc[r]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off, 64);
+    const float hr[4] = {scale * acc[0], scale * acc[1], scale * acc[2], scale * acc[3]};
+    if (h && lane == 0) h[m] = make_float4(hr[0], hr[1], hr[2], hr[3]);
+    for (int n8 = lane; n8 < N8; n8 += 64) {
+        const size_t i = (size_t)m * N8 + n8;
+        float o[8];
+        if (!BWD) {
+            const float4* wp = (const float4*)w2 + (size_t)n8 * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float4 t = wp[e];
+                o[e] = fmaf(hr[0], t.x, fmaf(hr[1], t.y, fmaf(hr[2], t.z, hr[3] * t.w)));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4 t0 = *(const float4*)(w2 + (size_t)r * N + n8 * 8), t1 = *(const float4*)(w2 + (size_t)r * N + n8 * 8 + 4);
+                o[0] = fmaf(hr[r], t0.x, o[0]); o[1] = fmaf(hr[r], t0.y, o[1]); o[2] = fmaf(hr[r], t0.z, o[2]); o[3] = fmaf(hr[r], t0.w, o[3]);
+                o[4] = fmaf(hr[r], t1.x, o[4]); o[5] = fmaf(hr[r], t1.y, o[5]); o[6] = fmaf(hr[r], t1.z, o[6]); o[7] = fmaf(hr[r], t1.w, o[7]);
+            }
+        }
+        if (base) {
+            const u32x4 b = base[i];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { o[2 * e] += lo16(b.w[e]); o[2 * e + 1] += hi16(b.w[e]); }
+        }
+        u32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; e++) out.w[e] = pack_bf16(o[2 * e], o[2 * e + 1]);
+        y[i] = out;
+    }
+}
+
 // part[chunk][r][j] = sum over the chunk's rows of a[m][j] * v[m][r]; thread = 8 columns, one wave per 512 columns and chunk
 __global__ __launch_bounds__(64) void lora_colreduce_kernel(const u32x4* __restrict__ a, const float4* __restrict__ v,
                                                              float* __restrict__ part, int M, int J8, int rows)
@@ -182,6 +263,7 @@ struct ColPair {
     float* part[2];
     float* g[2];
     int J8[2];
+    int acc;      // 1: g += the sum (a gradient buffer that accumulates over backward passes, torch's .grad convention)
 };
 
 __global__ __launch_bounds__(64) void lora_colreduce_pair_kernel(ColPair p, int M, int rows)
@@ -232,7 +314,8 @@ __global__ __launch_bounds__(256) void lora_colreduce_pair_finish_kernel(ColPair
     float s = 0.f;
     for (int c = 0; c < chunks; c++) s += part[(size_t)c * 4 * J + i];
     const int r = i / J, j = i - r * J;
-    p.g[z][z == 0 ? (size_t)j * 4 + r : (size_t)i] = s;          // d up as [N][4], d down as [4][K]
+    float* dst = p.g[z] + (z == 0 ? (size_t)j * 4 + r : (size_t)i);          // d up as [N][4], d down as [4][K]
+    *dst = p.acc ? *dst + s : s;
 }
 
 }  // namespace
@@ -271,6 +354,24 @@ int gd_nn_lora_rank4_add(void* stream, const float* h, const float* w, const voi
     return GD_NN_OK;
 }
 
+int gd_nn_lora_row_fused(void* stream, const void* a, const float* w1, const float* w2, const void* base, float* h, void* y,
+                         int64_t M, int K, int N, float scale, int backward)
+{
+    if (!a || !w1 || !w2 || !y) return fail(GD_NN_ERR_INVALID_ARG, "lora_row_fused: null pointer");
+    if (M <= 0 || M > 0x7fffffff / 4 || K <= 0 || N <= 0 || (K & 7) || (N & 7))
+        return fail(GD_NN_ERR_INVALID_ARG, "lora_row_fused: need M > 0, K % 8 == 0, N % 8 == 0");
+    const dim3 grid((unsigned)((M + 3) / 4));
+    if (backward)
+        hipLaunchKernelGGL(lora_row_fused_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const u32x4*)a, w1, w2,
+                           (const u32x4*)base, (float4*)h, (u32x4*)y, (int)M, K / 8, N / 8, scale);
+    else
+        hipLaunchKernelGGL(lora_row_fused_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const u32x4*)a, w1, w2,
+                           (const u32x4*)base, (float4*)h, (u32x4*)y, (int)M, K / 8, N / 8, scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
 size_t gd_nn_lora_colreduce_scratch_floats(int64_t M, int J)
 {
     if (M <= 0 || J <= 0) return 0;
@@ -303,6 +404,12 @@ size_t gd_nn_lora_colreduce_pair_scratch_floats(int64_t M, int N, int K)
 int gd_nn_lora_colreduce_pair(void* stream, const void* dy, const float* hs, const void* x, const float* dh, float* scratch,
                               float* d_up, float* d_down, int64_t M, int N, int K)
 {
+    return gd_nn_lora_colreduce_pair_into(stream, dy, hs, x, dh, scratch, d_up, d_down, M, N, K, 0);
+}
+
+int gd_nn_lora_colreduce_pair_into(void* stream, const void* dy, const float* hs, const void* x, const float* dh, float* scratch,
+                                   float* d_up, float* d_down, int64_t M, int N, int K, int accumulate)
+{
     if (!dy || !hs || !x || !dh || !scratch || !d_up || !d_down) return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce_pair: null pointer");
     if (M <= 0 || M > 0x7fffffff / 4 || N <= 0 || K <= 0 || (N & 7) || (K & 7))
         return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce_pair: need M > 0, N % 8 == 0, K % 8 == 0");
@@ -311,6 +418,7 @@ int gd_nn_lora_colreduce_pair(void* stream, const void* dy, const float* hs, con
     ColPair p;
     p.a[0] = (const u32x4*)dy; p.v[0] = (const float4*)hs; p.part[0] = scratch; p.g[0] = d_up; p.J8[0] = N / 8;
     p.a[1] = (const u32x4*)x; p.v[1] = (const float4*)dh; p.part[1] = scratch + (size_t)chunks * 4 * N; p.g[1] = d_down; p.J8[1] = K / 8;
+    p.acc = accumulate ? 1 : 0;
     const int jmax = N > K ? N / 8 : K / 8;
     hipLaunchKernelGGL(lora_colreduce_pair_kernel, dim3((jmax + 63) / 64, chunks, 2), dim3(64), 0, (hipStream_t)stream, p, (int)M, rows);
     hipLaunchKernelGGL(lora_colreduce_pair_finish_kernel, dim3((4 * (N + K) + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, chunks);

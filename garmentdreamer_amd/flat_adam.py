@@ -1,0 +1,113 @@
+"""``torch.optim.Adam`` for MANY SMALL tensors as one launch -- the optimizer of the NeTF stage's LoRA UNet.
+
+The reference steps ``torch.optim.Adam(params, lr=unet_lr)`` over the 256 rank-4 adapter matrices, the camera
+embedding and three shading embeddings (Garment_Deformer_NeTF/netf/trainer.py:129-137, stepped at :256).  On
+MI355X that step is host work, not device work: the foreach implementation walks ~260 parameters in Python and
+issues a dozen multi-tensor launches, and the GPU sits idle for ~3 ms of a 42 ms iteration while it does
+(``tools/vsd_gaps.sh``: 2.4 ms between the last kernel of the backward pass and the first of the optimizer,
+0.55 ms inside it; and the gap is not the optimizer's arithmetic but the host handling 260 gradient tensors after the
+backward graph).  Here the fp32 parameters are re-seated as views of ONE flat buffer and their ``.grad`` are, for
+good, views of ONE flat gradient buffer: the LoRA backward kernels add the adapter gradients straight into those
+views (``Parameter._gd_grad_sink``, read by nn_ops._LoraLinear / _LoraBranch; ``gd_nn_lora_colreduce_pair_into``)
+and return nothing to autograd; any other producer's gradient is accumulated in place by autograd as usual.  A step
+is then ONE ``gd_scene_adam_step`` launch (include/gd_scene.h, the kernel the Gaussian scene's optimizer uses: same
+update rule, same double-precision bias-correction scalars as torch's) and ``zero_grad`` ONE memset.
+
+Semantics: ``.grad`` accumulates over backward passes until ``zero_grad()``, as in torch.  One difference, stated:
+``torch.optim.Adam`` skips a parameter whose ``.grad`` is None (no moment decay, its own step count); a flat-set
+parameter always has a gradient here (zeros if nothing wrote one), so its moments decay on every step.  The flat set
+is the fp32 GPU parameters -- the adapters, which receive a gradient on every step; parameters that are not fp32
+(camera / shading embeddings in the base dtype) or that the caller lists in ``exclude`` are left to a plain
+``torch.optim.Adam`` over just those few tensors, with torch's skipping.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional
+
+import torch
+
+from . import _native
+
+
+class FlatAdam:
+    def __init__(self, params: Iterable[torch.Tensor], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 exclude: Iterable[torch.Tensor] = (), check_views: bool = True):
+        """Re-seats every fp32 GPU parameter (not in ``exclude``) in the flat buffer NOW: construct it before any hipGraph
+        that reads those parameters is captured (a graph keeps the addresses it was captured with)."""
+        self.params: List[torch.Tensor] = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatAdam: empty parameter list")
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.step_count = 0
+        self._check_views = bool(check_views)    # a Python walk over the flat set per step (~50 us for 256 tensors)
+        skip = {id(p) for p in exclude}
+        flat = [p for p in self.params if p.is_cuda and p.dtype == torch.float32 and id(p) not in skip]
+        ids = {id(p) for p in flat}
+        rest = [p for p in self.params if id(p) not in ids]
+        self._flat_set = flat
+        self._rest = torch.optim.Adam(rest, lr=self.lr, betas=self.betas, eps=self.eps) if rest else None
+        if not flat:
+            return
+        dev = flat[0].device
+        if any(p.device != dev for p in flat):
+            raise ValueError("FlatAdam: the fp32 parameters must live on one device")
+        pad = lambda k: (k + 63) // 64 * 64      # every view starts 256-byte aligned (the LoRA kernels read 16-byte vectors)
+        n = sum(pad(p.numel()) for p in flat)
+        self._flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._grad = torch.zeros(n, dtype=torch.float32, device=dev)       # padding stays 0: its update is 0 / (0 + eps)
+        self._exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._grad_views = []
+        off = 0
+        with torch.no_grad():
+            for p in flat:
+                k = p.numel()
+                view = self._flat[off:off + k].view(p.shape)
+                view.copy_(p.data)
+                p.data = view                     # the module keeps its Parameter objects; their storage is the flat buffer
+                gview = self._grad[off:off + k].view(p.shape)
+                p.grad = gview                    # for good: zero_grad() clears the buffer, it does not drop the views
+                p._gd_grad_sink = gview           # the LoRA backward kernels add into it (nn_ops._grad_sinks)
+                self._grad_views.append(gview)
+                off += pad(k)
+        self._ends = (C.c_int64 * 1)(n)
+
+    # ---- torch.optim.Optimizer surface the training loops use ---------------------------------------------------
+    def zero_grad(self, set_to_none: bool = True):
+        if self._flat_set:
+            self._grad.zero_()
+        if self._rest is not None:
+            self._rest.zero_grad(set_to_none=set_to_none)
+
+    @property
+    def param_groups(self):
+        return [{"params": self.params, "lr": self.lr, "betas": self.betas, "eps": self.eps}]
+
+    @torch.no_grad()
+    def step(self):
+        self.step_count += 1
+        flat = self._flat_set
+        if flat:
+            if self._check_views:       # someone replaced a .grad (e.g. a foreign zero_grad(set_to_none=True)): put the view back
+                for p, v in zip(flat, self._grad_views):
+                    if p.grad is not v:
+                        if p.grad is not None:
+                            v.add_(p.grad)
+                        p.grad = v
+            lrs = (C.c_double * 1)(self.lr)
+            dev = self._flat.device
+            with torch.cuda.device(dev):
+                _native.check_scene(_native.lib().gd_scene_adam_step(
+                    torch.cuda.current_stream(dev).cuda_stream, self._flat.data_ptr(), self._grad.data_ptr(),
+                    self._exp_avg.data_ptr(), self._exp_avg_sq.data_ptr(), self._flat.numel(), 1, self._ends, lrs,
+                    self.betas[0], self.betas[1], self.eps, self.step_count), "gd_scene_adam_step")
+        if self._rest is not None:
+            for grp in self._rest.param_groups:
+                grp["lr"] = self.lr
+            self._rest.step()
+
+    @property
+    def flat_grad(self) -> Optional[torch.Tensor]:
+        """The gathered gradient of the flat set as ONE tensor (what a data-parallel all-reduce would send)."""
+        return getattr(self, "_grad", None)

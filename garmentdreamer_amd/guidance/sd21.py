@@ -46,6 +46,7 @@ import os as _os
 _FUSED_QKV = _os.environ.get("GD_FUSED_QKV", "1") != "0"   # A/B toggle of the fused self-attention projection
 _VT_GEMM = _os.environ.get("GD_VT_GEMM", "1") != "0"         # A/B toggle: V^T from a GEMM instead of the transposing pre-pass
 _LORA_FUSED = _os.environ.get("GD_LORA_FUSED", "1") != "0"   # A/B toggle: own rank-4 LoRA kernels (fwd + bwd) instead of torch ops
+_LORA_LINEAR = _os.environ.get("GD_LORA_LINEAR", "1") != "0"  # A/B toggle: adapted projection as ONE autograd node (nn_ops.lora_linear)
 from .. import nn_ops  # noqa: E402
 _FP8_ACTIVE = [None]   # the nn_ops.Fp8State of the UNet whose no-grad forward is running (set by its forward)
 
@@ -261,12 +262,12 @@ class Attention(nn.Module):
                 return _lin(self.to_out[0], attention_d64_vt(q, k, vt))
             v = _lin(self.to_v, x)
             q, k = q.reshape(B, N, -1), k.reshape(B, N, -1)
+        elif self.lora is not None:
+            q = self._lora_lin(self.to_q, x, "to_q_lora")
+            k = self._lora_lin(self.to_k, ctx, "to_k_lora")
+            v = self._lora_lin(self.to_v, ctx, "to_v_lora")
         else:
             q, k, v = _lin(self.to_q, x), _lin(self.to_k, ctx), _lin(self.to_v, ctx)
-        if self.lora is not None:
-            q = self._lora_add(q, x, "to_q_lora")
-            k = self._lora_add(k, ctx, "to_k_lora")
-            v = self._lora_add(v, ctx, "to_v_lora")
         q = q.view(B, N, self.heads, -1)
         k = k.view(B, ctx.shape[1], self.heads, -1)
         v = v.view(B, ctx.shape[1], self.heads, -1)
@@ -280,14 +281,27 @@ class Attention(nn.Module):
         else:
             o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
             o = o.transpose(1, 2).reshape(B, N, -1)
-        y = _lin(self.to_out[0], o)
         if self.lora is not None:
-            y = self._lora_add(y, o, "to_out_lora")
-        return y
+            return self._lora_lin(self.to_out[0], o, "to_out_lora")
+        return _lin(self.to_out[0], o)
+
+    def _lora_lin(self, mod: nn.Linear, x, name):
+        """``mod(x) + lora_scale * up(down(x))`` (LoRAAttnProcessor, lora_unet.py:415-422).  Frozen projection, bf16 activations,
+        fp32 adapters: ONE autograd node (nn_ops.lora_linear) -- the projection on its inference routing, the adapter branch
+        added by one launch, and a backward pass whose input gradient already holds both branches."""
+        layer = self.lora[name]
+        dw, uw = layer.down.weight, layer.up.weight
+        w, b = mod.weight, mod.bias
+        if _LORA_FUSED and _LORA_LINEAR and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and \
+                not w.requires_grad and (b is None or not b.requires_grad) and dw.dtype == torch.float32 and \
+                uw.dtype == torch.float32 and dw.shape[0] == 4 and uw.shape[1] == 4 and x.shape[-1] % 8 == 0 and \
+                w.shape[0] % 8 == 0 and dw.is_contiguous() and uw.is_contiguous():
+            return nn_ops.lora_linear(x, w, dw, uw, self.lora_scale, lambda t: _lin(mod, t))
+        return self._lora_add(_lin(mod, x), x, name)
 
     def _lora_add(self, base, x, name):
         """``base + lora_scale * up(down(x))`` (LoRAAttnProcessor): own fused rank-4 kernels, forward and backward, for bf16
-        activations with fp32 adapters (nn_ops.lora_branch: 2 launches instead of cast, GEMM, GEMM, cast, scale, add)."""
+        activations with fp32 adapters (nn_ops.lora_branch: one launch instead of cast, GEMM, GEMM, cast, scale, add)."""
         layer = self.lora[name]
         dw, uw = layer.down.weight, layer.up.weight
         if _LORA_FUSED and nn_ops.lora_branch_supported(x, base, dw, uw):

@@ -127,7 +127,20 @@ class StableDiffusionVSD(nn.Module):
         fn = self._graphs.get(key)
         if fn is None:
             sample = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in tensors)
-            fn = self._graphs[key] = torch.cuda.make_graphed_callables(make_module(), sample, allow_unused_input=True)
+            module = make_module()
+            # gradient sinks (flat_adam.FlatAdam: the LoRA backward kernels ADD the adapter gradients into them) would
+            # collect the gradients of the warm-up passes torch runs before the capture: put their contents back afterwards
+            bases = {}
+            for prm in module.parameters():
+                sink = getattr(prm, "_gd_grad_sink", None)
+                if sink is not None:
+                    base = sink._base if sink._base is not None else sink
+                    bases[id(base)] = base
+            saved = [(b, b.clone()) for b in bases.values()]
+            fn = self._graphs[key] = torch.cuda.make_graphed_callables(module, sample, allow_unused_input=True)
+            with torch.no_grad():
+                for b, c in saved:
+                    b.copy_(c)
         return fn(*tensors)
 
     def encode_imgs(self, imgs, vae_noise=None):

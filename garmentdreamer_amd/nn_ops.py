@@ -109,10 +109,12 @@ SIGNATURES = {
     "gd_nn_elementwise_last_error": (C.c_char_p, []),
     "gd_nn_lora_rowdot": (_i, [_vp, _vp, _vp, _vp, C.c_int64, _i, C.c_float, _i]),
     "gd_nn_lora_rank4_add": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
+    "gd_nn_lora_row_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_float, _i]),
     "gd_nn_lora_colreduce_scratch_floats": (C.c_size_t, [C.c_int64, _i]),
     "gd_nn_lora_colreduce": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, C.c_float, _i]),
     "gd_nn_lora_colreduce_pair_scratch_floats": (C.c_size_t, [C.c_int64, _i, _i]),
     "gd_nn_lora_colreduce_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
+    "gd_nn_lora_colreduce_pair_into": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _i]),
     "gd_nn_lora_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
 }
@@ -1444,46 +1446,128 @@ def _lora_colreduce(a2d, v, scale, g_is_j_by_4):
     return g
 
 
+_LORA_ROW_FUSED = os.environ.get("GD_LORA_ROW_FUSED", "1") != "0"
+
+
+def _lora_row_fused(a2d, w1, w2, base2d, N, scale, backward, want_h=True):
+    """One launch: h = scale * a . w1 and y = base + h . w2 (gd_nn_lora_row_fused; bit-identical to rowdot + rank4_add)."""
+    M, K = a2d.shape
+    if not _LORA_ROW_FUSED:     # same-box A/B only (tools/): the two launches the fused pass replaces, bit-identical
+        h = _lora_rowdot(a2d, w1, scale, int(backward))
+        return _lora_rank4_add(h, w2, base2d, N, int(not backward)), (h if want_h else None)
+    h = torch.empty((M, 4), dtype=torch.float32, device=a2d.device) if want_h else None
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=a2d.device)
+    with torch.cuda.device(a2d.device):
+        _lora_check(lib().gd_nn_lora_row_fused(torch.cuda.current_stream(a2d.device).cuda_stream, a2d.data_ptr(), w1.data_ptr(),
+                                               w2.data_ptr(), None if base2d is None else base2d.data_ptr(),
+                                               None if h is None else h.data_ptr(), y.data_ptr(), M, K, N, float(scale),
+                                               int(backward)), "gd_nn_lora_row_fused")
+    return y, h
+
+
+def _grad_sinks(down_w, up_w):
+    """(sink of down, sink of up): fp32 tensors of the weights' shapes that RECEIVE the weight gradients in place
+    (``Parameter._gd_grad_sink``, set by flat_adam.FlatAdam), or (None, None)."""
+    sd, su = getattr(down_w, "_gd_grad_sink", None), getattr(up_w, "_gd_grad_sink", None)
+    if sd is None or su is None or sd.shape != down_w.shape or su.shape != up_w.shape or not sd.is_contiguous() or \
+            not su.is_contiguous():
+        return None, None
+    return sd, su
+
+
+def _lora_backward(ctx, dy, dx_base, need_x, need_down, need_up):
+    """The adapter's share of the backward pass: dx (= dx_base + dh . down if a frozen projection's gradient is handed in),
+    d down, d up.  Training case (both adapter halves): 3 launches -- the fused row pass, the paired reduction, its finish."""
+    x2d, hs, down_w, up_w = ctx.saved_tensors[:4]
+    dx = d_down = d_up = None
+    K = x2d.shape[1]
+    dh = None
+    if need_x:
+        dx, dh = _lora_row_fused(dy, up_w, down_w, dx_base, K, ctx.scale, 1, want_h=need_down)
+    elif need_down:
+        dh = _lora_rowdot(dy, up_w, ctx.scale, 1)                      # scale * dy @ up
+    if need_up and need_down:        # both weight gradients from one launch per stage
+        M, N = dy.shape
+        L = lib()
+        scratch = torch.empty(L.gd_nn_lora_colreduce_pair_scratch_floats(M, N, K), dtype=torch.float32, device=dy.device)
+        sink_down, sink_up = getattr(ctx, "sinks", (None, None))
+        if sink_down is not None and sink_up is not None:
+            # the adapters' .grad are slices of ONE flat gradient buffer (flat_adam.FlatAdam): added in place by the kernel,
+            # nothing returned to autograd -- no 256 gradient tensors, AccumulateGrad calls and gathers per UNet backward
+            with torch.cuda.device(dy.device):
+                _lora_check(L.gd_nn_lora_colreduce_pair_into(torch.cuda.current_stream(dy.device).cuda_stream, dy.data_ptr(),
+                                                             hs.data_ptr(), x2d.data_ptr(), dh.data_ptr(), scratch.data_ptr(),
+                                                             sink_up.data_ptr(), sink_down.data_ptr(), M, N, K, 1),
+                            "gd_nn_lora_colreduce_pair_into")
+            return dx, None, None
+        d_up = torch.empty((N, 4), dtype=torch.float32, device=dy.device)
+        d_down = torch.empty((4, K), dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lora_check(L.gd_nn_lora_colreduce_pair(torch.cuda.current_stream(dy.device).cuda_stream, dy.data_ptr(), hs.data_ptr(),
+                                                    x2d.data_ptr(), dh.data_ptr(), scratch.data_ptr(), d_up.data_ptr(),
+                                                    d_down.data_ptr(), M, N, K), "gd_nn_lora_colreduce_pair")
+    elif need_up:
+        d_up = _lora_colreduce(dy, hs, 1.0, 1)                         # [N, 4]: sum_m dy[m, n] * scale * h[m, r]
+    elif need_down:
+        d_down = _lora_colreduce(x2d, dh, 1.0, 0)                      # [4, K]
+    return dx, d_down, d_up
+
+
 class _LoraBranch(torch.autograd.Function):
-    """y = base + scale * (x @ down^T) @ up^T with x [M, K] / base [M, N] bf16 and fp32 rank-4 adapters: two launches forward
-    (four dot products per row; four FMAs per output element on top of ``base``), five backward -- every sum in fp32."""
+    """y = base + scale * (x @ down^T) @ up^T with x [M, K] / base [M, N] bf16 and fp32 rank-4 adapters: ONE launch forward
+    (four dot products per row, then four FMAs per output element on top of ``base``, by the same wave), three backward --
+    every sum in fp32."""
 
     @staticmethod
     def forward(ctx, x2d, base2d, down_w, up_w, scale):
-        hs = _lora_rowdot(x2d, down_w, scale, 0)                       # scale * down(x)
+        y, hs = _lora_row_fused(x2d, down_w, up_w, base2d, base2d.shape[1], scale, 0)   # hs = scale * down(x)
         ctx.save_for_backward(x2d, hs, down_w, up_w)
         ctx.scale = float(scale)
-        return _lora_rank4_add(hs, up_w, base2d, base2d.shape[1], 1)
+        ctx.sinks = _grad_sinks(down_w, up_w)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x2d, hs, down_w, up_w = ctx.saved_tensors
         dy = dy.contiguous()
         need_x, need_base, need_down, need_up = ctx.needs_input_grad[:4]
-        dx = d_down = d_up = None
-        if need_up and need_down:        # the training case: both weight gradients from one launch per stage
-            dh = _lora_rowdot(dy, up_w, ctx.scale, 1)
-            M, N, K = dy.shape[0], dy.shape[1], x2d.shape[1]
-            L = lib()
-            scratch = torch.empty(L.gd_nn_lora_colreduce_pair_scratch_floats(M, N, K), dtype=torch.float32, device=dy.device)
-            d_up = torch.empty((N, 4), dtype=torch.float32, device=dy.device)
-            d_down = torch.empty((4, K), dtype=torch.float32, device=dy.device)
-            with torch.cuda.device(dy.device):
-                _lora_check(L.gd_nn_lora_colreduce_pair(torch.cuda.current_stream(dy.device).cuda_stream, dy.data_ptr(), hs.data_ptr(),
-                                                        x2d.data_ptr(), dh.data_ptr(), scratch.data_ptr(), d_up.data_ptr(),
-                                                        d_down.data_ptr(), M, N, K), "gd_nn_lora_colreduce_pair")
-            if need_x:
-                dx = _lora_rank4_add(dh, down_w, None, K, 0)
-            return dx, (dy if need_base else None), d_down, d_up, None
-        if need_up:
-            d_up = _lora_colreduce(dy, hs, 1.0, 1)                     # [N, 4]: sum_m dy[m, n] * scale * h[m, r]
-        if need_x or need_down:
-            dh = _lora_rowdot(dy, up_w, ctx.scale, 1)                  # scale * dy @ up
-            if need_down:
-                d_down = _lora_colreduce(x2d, dh, 1.0, 0)              # [4, K]
-            if need_x:
-                dx = _lora_rank4_add(dh, down_w, None, x2d.shape[1], 0)
+        dx, d_down, d_up = _lora_backward(ctx, dy, None, need_x, need_down, need_up)
         return dx, (dy if need_base else None), d_down, d_up, None
+
+
+class _LoraLinear(torch.autograd.Function):
+    """The adapted projection as ONE autograd node: y = base_fn(x) + scale * up(down(x)) with the frozen projection inside
+    (``base_fn`` runs under no_grad, so the inference routing applies -- the own K = 320 streaming GEMM on the 64x64-token
+    blocks).  Backward: the frozen projection's dx = dy @ W from the library, handed to the fused row pass as its base, so
+    the input gradient leaves complete -- autograd's add of the two branches' gradients (one elementwise pass per adapted
+    projection, 128 per UNet backward) is gone."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, down_w, up_w, scale, base_fn):
+        base2d = base_fn(x2d)
+        y, hs = _lora_row_fused(x2d, down_w, up_w, base2d, base2d.shape[1], scale, 0)
+        ctx.save_for_backward(x2d, hs, down_w, up_w, weight)
+        ctx.scale = float(scale)
+        ctx.sinks = _grad_sinks(down_w, up_w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        need_x, _, need_down, need_up = ctx.needs_input_grad[:4]
+        dx_base = torch.mm(dy, ctx.saved_tensors[4]) if need_x else None
+        dx, d_down, d_up = _lora_backward(ctx, dy, dx_base, need_x, need_down, need_up)
+        return dx, None, d_down, d_up, None, None
+
+
+def lora_linear(x, weight, down_w, up_w, scale, base_fn):
+    """``base_fn(x) + scale * up(down(x))`` where ``base_fn`` is the FROZEN projection ``F.linear(., weight, bias)`` (any routing of
+    it): one autograd node, complete input gradient (see _LoraLinear)."""
+    assert not weight.requires_grad
+    x2d = x.reshape(-1, x.shape[-1])
+    if not x2d.is_contiguous():
+        x2d = x2d.contiguous()
+    y = _LoraLinear.apply(x2d, weight, down_w, up_w, scale, base_fn)
+    return y.view(*x.shape[:-1], y.shape[-1])
 
 
 def lora_branch(x, base, down_w, up_w, scale):

@@ -348,6 +348,13 @@ const char* gd_nn_elementwise_last_error(void);
  *               order (row chunks, then chunk order): bitwise reproducible, no atomics. */
 int gd_nn_lora_rowdot(void* stream, const void* a, const float* w, float* h, int64_t M, int K, float scale, int w_is_k_by_4);
 int gd_nn_lora_rank4_add(void* stream, const float* h, const float* w, const void* base, void* y, int64_t M, int N, int w_is_n_by_4);
+/* rowdot + rank4_add of a row by one wave, ONE launch (bit-identical to the two calls): h[m] = scale * a[m] . w1, then
+ * y[m] = base[m] + h[m] . w2; h (may be NULL) receives the [M][4] intermediate the backward pass / the weight gradients need.
+ * backward = 0 (LoRAAttnProcessor forward, lora_unet.py:415-422): a = x [M][K], w1 = down [4][K], w2 = up [N][4], base = the frozen
+ * projection.  backward = 1 (its autograd backward w.r.t. x): a = dy [M][K], w1 = up [K][4], w2 = down [4][N], base = the frozen
+ * projection's own input gradient dy W (or NULL): dx leaves complete, no separate add of the two branches' gradients. */
+int gd_nn_lora_row_fused(void* stream, const void* a, const float* w1, const float* w2, const void* base, float* h, void* y,
+                         int64_t M, int K, int N, float scale, int backward);
 size_t gd_nn_lora_colreduce_scratch_floats(int64_t M, int J);
 int gd_nn_lora_colreduce(void* stream, const void* a, const float* v, float* scratch, float* g, int64_t M, int J, float scale,
                          int g_is_j_by_4);
@@ -356,6 +363,12 @@ int gd_nn_lora_colreduce(void* stream, const void* a, const float* v, float* scr
 size_t gd_nn_lora_colreduce_pair_scratch_floats(int64_t M, int N, int K);
 int gd_nn_lora_colreduce_pair(void* stream, const void* dy, const float* hs, const void* x, const float* dh, float* scratch,
                               float* d_up, float* d_down, int64_t M, int N, int K);
+/* The same with the two results ADDED onto d_up / d_down when accumulate != 0 (the sums are formed first, in the same fixed
+ * order, then added once): the destination is a gradient buffer that accumulates over backward passes like torch's .grad --
+ * here slices of the flat gradient buffer of garmentdreamer_amd.flat_adam.FlatAdam, so the 256 adapter gradients of a UNet
+ * backward never become 256 tensors on the host (netf/trainer.py:252-256: loss.backward(); lora_unet_optimizer.step()). */
+int gd_nn_lora_colreduce_pair_into(void* stream, const void* dy, const float* hs, const void* x, const float* dh, float* scratch,
+                                   float* d_up, float* d_down, int64_t M, int N, int K, int accumulate);
 const char* gd_nn_lora_last_error(void);
 
 const char* gd_nn_last_error(void);

@@ -1131,6 +1131,119 @@ def test_lora_branch_forward_and_backward_match_fp32_reference(M, K, N, frozen):
         assert got is None or (got.dtype == torch.float32 and rel(got, want) < 2e-5)
 
 
+@pytest.mark.parametrize("M,K,N", [(154, 1024, 320), (4096, 320, 320), (1001, 640, 1280), (33, 1280, 640)])
+def test_lora_row_fused_is_bit_identical_to_rowdot_plus_rank4_add(M, K, N):
+    """gd_nn_lora_row_fused (one wave computes a row's four dot products AND adds the rank-4 update) against the two
+    launches it replaces, forward form (down, up, base) and backward form (up, down, optional base): the same bits in y
+    and in the [M][4] intermediate."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(3 * M + K + N)
+    x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    base = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    down = torch.randn(4, K, device=DEV, generator=g) / 4
+    up = torch.randn(N, 4, device=DEV, generator=g) * 0.3
+    hs = nn_ops._lora_rowdot(x, down, 0.75, 0)
+    want = nn_ops._lora_rank4_add(hs, up, base, N, 1)
+    got, h = nn_ops._lora_row_fused(x, down, up, base, N, 0.75, 0)
+    assert torch.equal(got, want) and torch.equal(h, hs)
+    got2, h2 = nn_ops._lora_row_fused(x, down, up, base, N, 0.75, 0, want_h=False)
+    assert h2 is None and torch.equal(got2, want)
+    # backward form: a = dy [M][N], w1 = up [N][4], w2 = down [4][K]
+    dy = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    dxb = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    dh = nn_ops._lora_rowdot(dy, up, 0.75, 1)
+    for b in (None, dxb):
+        want = nn_ops._lora_rank4_add(dh, down, b, K, 0)
+        got, h = nn_ops._lora_row_fused(dy, up, down, b, K, 0.75, 1)
+        assert torch.equal(got, want) and torch.equal(h, dh)
+
+
+@pytest.mark.parametrize("shape,K,N,bias,x_grad", [((2, 2048, 320), 320, 320, False, True), ((2, 77, 1024), 1024, 640, False, False),
+                                                   ((1, 1000, 640), 640, 640, True, True), ((3, 11, 1280), 1280, 1280, True, True)])
+def test_lora_linear_node_matches_fp32_reference_and_the_two_node_path(shape, K, N, bias, x_grad):
+    """nn_ops.lora_linear -- frozen projection + rank-4 adapter as ONE autograd node whose input gradient already holds both
+    branches -- against fp32 PyTorch on the same bf16 inputs, and against F.linear + nn_ops.lora_branch (two nodes +
+    autograd's add).  x without a gradient (the text tokens of the cross-attention's k / v) takes the no-dx path."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(K + N + shape[1])
+    x = torch.randn(*shape, device=DEV, generator=g).to(torch.bfloat16).requires_grad_(x_grad)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV, generator=g).to(torch.bfloat16) if bias else None
+    down = (torch.randn(4, K, device=DEV, generator=g) / 4).requires_grad_(True)
+    up = (torch.randn(N, 4, device=DEV, generator=g) * 0.3).requires_grad_(True)
+    dy = torch.randn(*shape[:-1], N, device=DEV, generator=g).to(torch.bfloat16)
+    scale = 1.0
+    res = {}
+    for mode in ("node", "node", "two"):
+        for t in (x, down, up):
+            t.grad = None
+        if mode == "node":
+            y = nn_ops.lora_linear(x, w, down, up, scale, lambda t: F.linear(t, w, b))
+        else:
+            y = nn_ops.lora_branch(x, F.linear(x, w, b), down, up, scale)
+        y.backward(dy)
+        cur = [y.detach().clone(), None if x.grad is None else x.grad.clone(), down.grad.clone(), up.grad.clone()]
+        if mode in res:          # bitwise reproducible
+            assert all((p is None and q is None) or torch.equal(p, q) for p, q in zip(res[mode], cur))
+        res[mode] = cur
+    xf, wf, df, uf = x.detach().float().requires_grad_(x_grad), w.float(), down.detach().float().requires_grad_(True), up.detach().float().requires_grad_(True)
+    yr = F.linear(xf, wf, None if b is None else b.float()) + scale * (xf @ df.t()) @ uf.t()
+    yr.backward(dy.float())
+    def rel(a, c):
+        return ((a.float() - c).abs().max() / c.abs().max()).item()
+    y, gx, gd_, gu = res["node"]
+    assert y.shape == yr.shape and y.dtype == torch.bfloat16
+    assert rel(y, yr.detach()) < 1.2e-2          # bf16 projection output + one bf16 rounding of the sum
+    assert (gx is None) == (not x_grad)
+    if x_grad:
+        assert gx.shape == x.shape and rel(gx, xf.grad) < 1.2e-2
+        # one rounding (fp32 sum of the two branches) where the two-node path rounds each branch and their sum
+        assert rel(gx, xf.grad) <= rel(res["two"][1], xf.grad) * 1.5 + 1e-3
+    assert rel(gd_, df.grad) < 2e-5 and rel(gu, uf.grad) < 2e-5
+    assert torch.equal(y, res["two"][0]) and torch.equal(gd_, res["two"][2]) and torch.equal(gu, res["two"][3])
+
+
+def test_lora_gradients_land_in_the_flat_adam_sinks():
+    """With flat_adam.FlatAdam the adapters' .grad are slices of one flat buffer and the LoRA backward kernels add into them
+    (gd_nn_lora_colreduce_pair_into): the same bits as the gradients the node returns without sinks, twice that after a
+    second backward pass (accumulation), nothing handed to autograd; the update equals torch.optim.Adam's on those gradients."""
+    from garmentdreamer_amd import nn_ops
+    from garmentdreamer_amd.flat_adam import FlatAdam
+    g = torch.Generator(DEV).manual_seed(5)
+    M, K, N = 2048, 320, 640
+    x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    dy = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    down0, up0 = torch.randn(4, K, device=DEV, generator=g) / 4, torch.randn(N, 4, device=DEV, generator=g) * 0.3
+    def run(down, up, node):
+        if node:
+            y = nn_ops.lora_linear(x, w, down, up, 0.5, lambda t: F.linear(t, w))
+        else:
+            y = nn_ops.lora_branch(x, F.linear(x, w), down, up, 0.5)
+        x.grad = None
+        y.backward(dy)
+        return y.detach(), x.grad.clone()
+    for node in (True, False):
+        down_r, up_r = torch.nn.Parameter(down0.clone()), torch.nn.Parameter(up0.clone())
+        y_r, gx_r = run(down_r, up_r, node)
+        down, up = torch.nn.Parameter(down0.clone()), torch.nn.Parameter(up0.clone())
+        opt = FlatAdam([down, up], lr=1e-2)
+        y, gx = run(down, up, node)
+        assert torch.equal(y, y_r) and torch.equal(gx, gx_r)
+        assert down.grad is down._gd_grad_sink and up.grad is up._gd_grad_sink
+        assert torch.equal(down.grad, down_r.grad) and torch.equal(up.grad, up_r.grad)
+        run(down, up, node)
+        assert torch.equal(down.grad, 2 * down_r.grad) and torch.equal(up.grad, 2 * up_r.grad)
+        opt.zero_grad()
+        assert float(down.grad.abs().sum()) == 0.0 and float(up.grad.abs().sum()) == 0.0
+        run(down, up, node)
+        ropt = torch.optim.Adam([down_r, up_r], lr=1e-2)
+        opt.step()
+        ropt.step()
+        assert torch.allclose(down.detach(), down_r.detach(), rtol=2e-6, atol=2e-7)
+        assert torch.allclose(up.detach(), up_r.detach(), rtol=2e-6, atol=2e-7)
+
+
 @pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (300, 1280), (77, 1024)])
 def test_training_row_passes_forward_and_backward_match_fp32_reference(rows, C):
     """GEGLU and add + LayerNorm with a gradient on the activations (the LoRA UNet's training pass; frozen norm parameters):

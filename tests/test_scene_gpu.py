@@ -83,6 +83,51 @@ def test_flat_adam_matches_torch_adam_over_several_steps():
                           atol=1e-6 * ev.abs().max().item())
 
 
+def test_flat_adam_over_many_small_tensors_matches_torch_adam():
+    """garmentdreamer_amd.flat_adam.FlatAdam (the LoRA UNet's optimizer, trainer.py:137: torch.optim.Adam over ~260 small
+    tensors): the fp32 parameters and their .grad are views of two flat buffers, a step is one gd_scene_adam_step launch,
+    zero_grad one memset; gradients accumulate in place like torch's; bf16 / excluded parameters go through torch.optim.Adam."""
+    from garmentdreamer_amd.flat_adam import FlatAdam
+    g = torch.Generator(DEV).manual_seed(11)
+    shapes = [(4, 320), (320, 4), (4, 1024), (640, 4), (7,), (3, 5, 2), (1280, 4)]
+    mine = [torch.nn.Parameter(torch.randn(*sh, device=DEV, generator=g)) for sh in shapes]
+    mine.append(torch.nn.Parameter(torch.randn(16, 8, device=DEV, generator=g).to(torch.bfloat16)))      # -> torch.optim.Adam
+    sparse = torch.nn.Parameter(torch.randn(9, device=DEV, generator=g))                                    # excluded, never a gradient
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    opt = FlatAdam(mine + [sparse], lr=3e-3, exclude=[sparse])
+    ropt = torch.optim.Adam(ref, lr=3e-3)
+    assert all(p.data_ptr() % 256 == 0 and p.grad is p._gd_grad_sink for p in mine[:-1])    # re-seated, aligned views of one buffer
+    assert mine[-1].grad is None and not hasattr(sparse, "_gd_grad_sink")
+    assert torch.equal(torch.cat([p.detach().flatten().float() for p in mine]), torch.cat([p.detach().flatten().float() for p in ref]))
+    sparse0 = sparse.detach().clone()
+    for it in range(6):
+        opt.zero_grad()
+        ropt.zero_grad()
+        assert float(opt.flat_grad.abs().sum()) == 0.0
+        for p, q in zip(mine, ref):
+            gr = (torch.randn(p.shape, device=DEV, generator=g) * 10.0 ** (it - 3)).to(p.dtype)
+            q.grad = gr.clone()
+            if p.dtype != torch.float32 or it == 2:
+                p.grad = gr.clone()              # a foreign tensor in .grad: step() folds it into the view and re-seats it
+            elif it % 2:
+                p.grad.add_(gr)                  # what autograd's AccumulateGrad does with an existing .grad
+            else:
+                p._gd_grad_sink.add_(gr / 2)     # what the LoRA backward kernels do, twice (accumulation)
+                p._gd_grad_sink.add_(gr / 2)
+        if it == 4:
+            opt.lr = 1e-3
+            for grp in ropt.param_groups:
+                grp["lr"] = 1e-3
+        opt.step()
+        ropt.step()
+        for p, q in zip(mine, ref):
+            tol = dict(rtol=2e-6, atol=2e-7) if p.dtype == torch.float32 else dict(rtol=0, atol=0)
+            assert torch.allclose(p.detach().float(), q.detach().float(), **tol), (it, p.shape)
+        assert all(p.grad is p._gd_grad_sink for p in mine[:-1])
+    assert torch.equal(sparse.detach(), sparse0)
+    assert opt.flat_grad.numel() == sum((p.numel() + 63) // 64 * 64 for p in mine[:-1])
+
+
 def test_densify_stats_kernel_matches_torch_ops():
     P = 5000
     m = _model(P)
