@@ -228,6 +228,41 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const bf16x8* _
 
 }  // namespace
 
+// AutoencoderKL.quant_conv: nn.Conv2d(8, 8, 1) on the encoder's [B, 8, 64, 64] moments (diffusers AutoencoderKL.encode, reached
+// through StableDiffusionGuidance.encode_images, stable_diffusion_guidance.py:160-167).  NHWC: a pixel is ONE 16-byte vector;
+// thread = pixel, the 8 x 8 weights + bias are wave-uniform (scalar loads), 64 FMAs per pixel in fp32.  TRANSPOSED = the input
+// gradient, dx[ci] = sum_co w[co][ci] dy[co] (no bias).  (MIOpen ran this layer on its naive fp64-accumulating kernel, the last
+// library convolution of the step.)
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void conv1x1_c8_kernel(const u32x4* __restrict__ x, const uint16_t* __restrict__ w,
+                                                         const uint16_t* __restrict__ bias, u32x4* __restrict__ y, int64_t npix)
+{
+    float wf[8][8], bf[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        bf[o] = (!TRANSPOSED && bias) ? bf2f(bias[o]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) wf[o][i] = bf2f(TRANSPOSED ? w[i * 8 + o] : w[o * 8 + i]);
+    }
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4 q = x[p];
+        float v[8], o[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[2 * e] = __uint_as_float(q.w[e] << 16); v[2 * e + 1] = __uint_as_float(q.w[e] & 0xffff0000u); }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            float a = bf[c];
+#pragma unroll
+            for (int i = 0; i < 8; i++) a = fmaf(wf[c][i], v[i], a);
+            o[c] = a;
+        }
+        u32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; e++) out.w[e] = pack2(f2{o[2 * e], o[2 * e + 1]});
+        y[p] = out;
+    }
+}
+
 extern "C" {
 
 const char* gd_nn_elementwise_last_error(void) { return g_err; }
@@ -296,6 +331,21 @@ int gd_nn_layernorm_backward(void* stream, const void* s, const void* dy, const 
     else GD_LNB(4);
 #undef GD_LNB
     return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "layernorm_backward: launch failed");
+}
+
+int gd_nn_conv1x1_c8(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t npix, int transposed)
+{
+    if (!x || !weight || !y) return fail(GD_NN_ERR_INVALID_ARG, "conv1x1_c8: null pointer");
+    if (npix <= 0) return fail(GD_NN_ERR_INVALID_ARG, "conv1x1_c8: need npix > 0");
+    const int64_t blocks = (npix + 255) / 256;
+    const int grid = (int)(blocks < 16384 ? blocks : 16384);
+    if (transposed)
+        hipLaunchKernelGGL(conv1x1_c8_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x,
+                           (const uint16_t*)weight, (const uint16_t*)nullptr, (u32x4*)y, npix);
+    else
+        hipLaunchKernelGGL(conv1x1_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x,
+                           (const uint16_t*)weight, (const uint16_t*)bias, (u32x4*)y, npix);
+    return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "conv1x1_c8: launch failed");
 }
 
 }  // extern "C"

@@ -792,6 +792,17 @@ class _VAEConfig:
     scaling_factor = 0.18215
 
 
+class _QuantConv(nn.Conv2d):
+    """``AutoencoderKL.quant_conv`` = ``nn.Conv2d(8, 8, 1)`` (same parameters and state_dict keys): frozen bf16 weights on the
+    GPU run on the own one-vector-per-pixel kernel, forward and input gradient (nn_ops.conv1x1_c8) -- MIOpen chose its naive
+    fp64-accumulating kernel for this layer, the last library convolution of the step; anything else is ``F.conv2d``."""
+
+    def forward(self, x):
+        if nn_ops.conv1x1_c8_supported(x, self.weight, self.bias):
+            return nn_ops.conv1x1_c8(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class AutoencoderKLEncoder(nn.Module):
     """Encoder half of AutoencoderKL: ``encode(x).latent_dist.sample()`` as the reference calls it
     (stable_diffusion_guidance.py:165-166).  The decoder is only used by ``guidance_eval`` previews
@@ -802,7 +813,7 @@ class AutoencoderKLEncoder(nn.Module):
     def __init__(self, block_out_channels=(128, 256, 512, 512)):
         super().__init__()
         self.encoder = Encoder(block_out_channels=block_out_channels)
-        self.quant_conv = nn.Conv2d(8, 8, 1)
+        self.quant_conv = _QuantConv(8, 8, 1)
 
     def encode(self, x):
         return _EncodeOutput(DiagonalGaussianDistribution(self.quant_conv(self.encoder(x.to(self.quant_conv.weight.dtype)))))

@@ -83,6 +83,7 @@ SIGNATURES = {
     "gd_nn_conv_profile_read_bytes": (_i, [C.POINTER(C.c_double)]),
     "gd_nn_geglu_forward": (_i, [_vp, _vp, _vp, C.c_int64, _i]),
     "gd_nn_geglu_backward": (_i, [_vp, _vp, _vp, _vp, C.c_int64, _i]),
+    "gd_nn_conv1x1_c8": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i]),
     "gd_nn_layernorm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, C.c_float]),
     "gd_nn_add_layernorm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, C.c_int64, _i]),
     "gd_nn_attention_ws_bytes": (C.c_size_t, [_i, _i, _i]),
@@ -1106,6 +1107,47 @@ class _GegluTrain(torch.autograd.Function):
         if ret < 0:
             raise RuntimeError(f"gd_nn_geglu_backward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
         return dx
+
+
+def _conv1x1_c8_launch(x, weight, bias, transposed):
+    """x: [B, 8, H, W] bf16 in channels_last memory (NHWC) -> the same shape and layout."""
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    L = lib()
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_conv1x1_c8(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), weight.data_ptr(),
+                                 None if bias is None else bias.data_ptr(), y.data_ptr(), x.numel() // 8, int(transposed))
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_conv1x1_c8 failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
+    return y
+
+
+class _Conv1x1C8(torch.autograd.Function):
+    """``F.conv2d(x, weight, bias)`` for the VAE's frozen quant_conv (8 -> 8 channels, 1x1): one pixel = one 16-byte vector
+    forward, and the same kernel on the transposed weights for the input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(weight)
+        return _conv1x1_c8_launch(x, weight, bias, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        return _conv1x1_c8_launch(dy.contiguous(memory_format=torch.channels_last), weight, None, True), None, None
+
+
+def conv1x1_c8_supported(x, weight, bias) -> bool:
+    return (x.is_cuda and x.dim() == 4 and x.shape[1] == 8 and x.dtype == torch.bfloat16 and tuple(weight.shape) == (8, 8, 1, 1)
+            and weight.dtype == torch.bfloat16 and weight.is_contiguous() and not weight.requires_grad
+            and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and not bias.requires_grad))
+            and x.data_ptr() % 16 == 0 and x.numel() > 0)
+
+
+def conv1x1_c8(x, weight, bias=None):
+    """The VAE's ``quant_conv`` on the own kernel (gd_nn_conv1x1_c8), with the input gradient; frozen weights only."""
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    return _Conv1x1C8.apply(x, weight, bias)
 
 
 _ATTN_TRAIN = os.environ.get("GD_ATTN_TRAIN", "1") != "0"    # A/B toggle: own attention forward kernel in the training pass

@@ -335,6 +335,11 @@ int gd_nn_fp8_conv3x3_forward(void* stream, const void* x_fp8, const void* w_fp8
 const char* gd_nn_fp8_last_error(void);
 
 const char* gd_nn_conv_last_error(void);
+/* AutoencoderKL.quant_conv -- nn.Conv2d(8, 8, kernel_size=1) on the encoder's moments (diffusers AutoencoderKL.encode, called by
+ * StableDiffusionGuidance.encode_images, threestudio/models/guidance/stable_diffusion_guidance.py:160-167): x, y NHWC bf16
+ * [npix][8], weight bf16 [8][8] (Cout, Cin), bias bf16 [8] or NULL; fp32 accumulation.  transposed != 0: the input gradient
+ * dx[p][ci] = sum_co weight[co][ci] dy[p][co] (bias ignored). */
+int gd_nn_conv1x1_c8(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t npix, int transposed);
 const char* gd_nn_elementwise_last_error(void);
 /* ---- rank-4 LoRA branch of the NeTF stage's trainable UNet (csrc/nn_lora.hip), fp32 accumulation, forward + backward.
  * Replaces diffusers 0.19 LoRALinearLayer.forward inside LoRAAttnProcessor -- hidden + scale * up(down(x)) -- and its

@@ -1203,6 +1203,37 @@ def test_lora_linear_node_matches_fp32_reference_and_the_two_node_path(shape, K,
     assert torch.equal(y, res["two"][0]) and torch.equal(gd_, res["two"][2]) and torch.equal(gu, res["two"][3])
 
 
+@pytest.mark.parametrize("B,H,W,bias", [(8, 64, 64, True), (1, 64, 64, True), (3, 17, 5, False)])
+def test_quant_conv_1x1_forward_and_input_gradient_match_fp32_reference(B, H, W, bias):
+    """gd_nn_conv1x1_c8 (AutoencoderKL.quant_conv, nn.Conv2d(8, 8, 1)) through the module the VAE holds: output and input
+    gradient against fp32 F.conv2d on the same bf16 values; NCHW-contiguous input takes the layout conversion."""
+    from garmentdreamer_amd.guidance import sd21
+    g = torch.Generator(DEV).manual_seed(B + H)
+    conv = sd21._QuantConv(8, 8, 1).to(DEV).to(torch.bfloat16).requires_grad_(False)
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn(8, 8, 1, 1, device=DEV, generator=g) * 0.5).to(torch.bfloat16))
+        if bias:
+            conv.bias.copy_(torch.randn(8, device=DEV, generator=g).to(torch.bfloat16))
+        else:
+            conv.bias = None
+    for fmt in (torch.channels_last, torch.contiguous_format):
+        x = torch.randn(B, 8, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=fmt).requires_grad_(True)
+        dy = torch.randn(B, 8, H, W, device=DEV, generator=g).to(torch.bfloat16)
+        from garmentdreamer_amd import nn_ops
+        assert nn_ops.conv1x1_c8_supported(x, conv.weight, conv.bias)
+        y = conv(x)
+        assert "Conv1x1C8" in type(y.grad_fn).__name__
+        y.backward(dy)
+        xf = x.detach().float().requires_grad_(True)
+        yr = F.conv2d(xf, conv.weight.float(), None if conv.bias is None else conv.bias.float())
+        yr.backward(dy.float())
+        assert y.shape == yr.shape and x.grad.shape == x.shape
+        assert (y.float() - yr).abs().max().item() <= 4e-3 * yr.abs().max().item() + 1e-6      # one bf16 rounding
+        assert (x.grad.float() - xf.grad).abs().max().item() <= 4e-3 * xf.grad.abs().max().item() + 1e-6
+    conv.weight.requires_grad_(True)          # a trainable quant_conv stays on F.conv2d
+    assert not nn_ops.conv1x1_c8_supported(x, conv.weight, conv.bias)
+
+
 def test_lora_gradients_land_in_the_flat_adam_sinks():
     """With flat_adam.FlatAdam the adapters' .grad are slices of one flat buffer and the LoRA backward kernels add into them
     (gd_nn_lora_colreduce_pair_into): the same bits as the gradients the node returns without sinks, twice that after a
