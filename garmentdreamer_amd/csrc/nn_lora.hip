@@ -9,7 +9,8 @@
 // UNet pass) and twice that in the backward pass; here:
 //   gd_nn_lora_rowdot      h[m][r] = s * sum_k a[m][k] w(r, k)          one wave per row; w as [4][K] (down) or [K][4] (up, for dh)
 //   gd_nn_lora_rank4_add   y[m][n] = base[m][n] + sum_r h[m][r] w(r, n) one thread per 8 outputs; w as [N][4] (up) or [4][N] (down, for dx)
-//   gd_nn_lora_colreduce   g(r, j) = s * sum_m a[m][j] v[m][r]          weight gradients: per row-chunk partial sums in registers,
+//   gd_nn_lora_colreduce   g(r, j) = s * sum_m a[m][j] v[m][r]          weight gradients: per row-chunk partial sums in registers (four
+//                                                                      waves per chunk, combined in wave order through LDS),
 //                                                                      then a fixed-order sum over the chunks (no atomics:
 //                                                                      the LoRA gradients are bitwise reproducible)
 //   gd_nn_lora_row_fused  rowdot and rank4_add of one row by the SAME wave in one launch: h never makes the round trip through
@@ -149,6 +150,28 @@ __global__ __launch_bounds__(256) void lora_row_fused_kernel(const u32x4* __rest
     if (m >= M) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const int K = K8 * 8, N = N8 * 8;
+    // the eight weight vectors of output chunk n8: !BWD: w2[n8 * 8 + e][0..3]; BWD: w2[r][n8 * 8 .. + 7] as (2 r, 2 r + 1)
+    auto load_w2 = [&](int n8, float4 (&wv)[8]) {
+        if (!BWD) {
+            const float4* wp = (const float4*)w2 + (size_t)n8 * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) wv[e] = wp[e];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                wv[2 * r] = *(const float4*)(w2 + (size_t)r * N + n8 * 8);
+                wv[2 * r + 1] = *(const float4*)(w2 + (size_t)r * N + n8 * 8 + 4);
+            }
+        }
+    };
+    // the launch is a latency chain (a row is a few hundred bytes): the first output chunk's base vector and weights are
+    // requested BEFORE the dot products, so the two memory round trips of a row overlap
+    u32x4 b0 = {{0u, 0u, 0u, 0u}};
+    float4 w0[8];
+    if (lane < N8) {
+        if (base) b0 = base[(size_t)m * N8 + lane];
+        load_w2(lane, w0);
+    }
     for (int k8 = lane; k8 < K8; k8 += 64) {
         const u32x4 q = a[(size_t)m * K8 + k8];
         float x[8];
@@ -179,26 +202,30 @@ __global__ __launch_bounds__(256) void lora_row_fused_kernel(const u32x4* __rest
     if (h && lane == 0) h[m] = make_float4(hr[0], hr[1], hr[2], hr[3]);
     for (int n8 = lane; n8 < N8; n8 += 64) {
         const size_t i = (size_t)m * N8 + n8;
+        float4 wv[8];
+        u32x4 b = b0;
+        if (n8 == lane) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) wv[e] = w0[e];
+        } else {
+            load_w2(n8, wv);
+            if (base) b = base[i];
+        }
         float o[8];
         if (!BWD) {
-            const float4* wp = (const float4*)w2 + (size_t)n8 * 8;
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float4 t = wp[e];
-                o[e] = fmaf(hr[0], t.x, fmaf(hr[1], t.y, fmaf(hr[2], t.z, hr[3] * t.w)));
-            }
+            for (int e = 0; e < 8; e++) o[e] = fmaf(hr[0], wv[e].x, fmaf(hr[1], wv[e].y, fmaf(hr[2], wv[e].z, hr[3] * wv[e].w)));
         } else {
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float4 t0 = *(const float4*)(w2 + (size_t)r * N + n8 * 8), t1 = *(const float4*)(w2 + (size_t)r * N + n8 * 8 + 4);
+                const float4 t0 = wv[2 * r], t1 = wv[2 * r + 1];
                 o[0] = fmaf(hr[r], t0.x, o[0]); o[1] = fmaf(hr[r], t0.y, o[1]); o[2] = fmaf(hr[r], t0.z, o[2]); o[3] = fmaf(hr[r], t0.w, o[3]);
                 o[4] = fmaf(hr[r], t1.x, o[4]); o[5] = fmaf(hr[r], t1.y, o[5]); o[6] = fmaf(hr[r], t1.z, o[6]); o[7] = fmaf(hr[r], t1.w, o[7]);
             }
         }
         if (base) {
-            const u32x4 b = base[i];
 #pragma unroll
             for (int e = 0; e < 4; e++) { o[2 * e] += lo16(b.w[e]); o[2 * e + 1] += hi16(b.w[e]); }
         }
@@ -209,38 +236,82 @@ __global__ __launch_bounds__(256) void lora_row_fused_kernel(const u32x4* __rest
     }
 }
 
-// part[chunk][r][j] = sum over the chunk's rows of a[m][j] * v[m][r]; thread = 8 columns, one wave per 512 columns and chunk
-__global__ __launch_bounds__(64) void lora_colreduce_kernel(const u32x4* __restrict__ a, const float4* __restrict__ v,
-                                                             float* __restrict__ part, int M, int J8, int rows)
+// part[chunk][r][j] = sum over the chunk's rows of a[m][j] * v[m][r].  A workgroup = 512 columns x one row chunk; thread = 8
+// columns; its four waves take the rows m0 + w, m0 + w + 4, ... (a quarter of the serial row loop each -- these launches are
+// latency chains, not bandwidth) and their 32 partial sums per thread are added in wave order 0, 1, 2, 3 through LDS: a fixed
+// order, so the gradients stay bitwise reproducible.
+__device__ __forceinline__ void colreduce_body(const u32x4* __restrict__ a, const float4* __restrict__ v, float* __restrict__ part,
+                                               int M, int J8, int rows, int chunk, int colblock, float (*sred)[32][64])
 {
-    const int j8 = blockIdx.x * 64 + threadIdx.x;
-    if (j8 >= J8) return;
-    const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j8 = colblock * 64 + lane;
+    const bool live = j8 < J8;
+    const int m0 = chunk * rows, m1 = min(M, m0 + rows);
     float acc[4][8];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[r][e] = 0.f;
+    if (live) {
 #pragma unroll 4
-    for (int m = m0; m < m1; m++) {
-        const u32x4 q = a[(size_t)m * J8 + j8];
-        const float4 t = v[m];
-        float x[8];
+        for (int m = m0 + wave; m < m1; m += 4) {
+            const u32x4 q = a[(size_t)m * J8 + j8];
+            const float4 t = v[m];
+            float x[8];
 #pragma unroll
-        for (int e = 0; e < 4; e++) { x[2 * e] = lo16(q.w[e]); x[2 * e + 1] = hi16(q.w[e]); }
+            for (int e = 0; e < 4; e++) { x[2 * e] = lo16(q.w[e]); x[2 * e + 1] = hi16(q.w[e]); }
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            acc[0][e] = fmaf(x[e], t.x, acc[0][e]); acc[1][e] = fmaf(x[e], t.y, acc[1][e]);
-            acc[2][e] = fmaf(x[e], t.z, acc[2][e]); acc[3][e] = fmaf(x[e], t.w, acc[3][e]);
+            for (int e = 0; e < 8; e++) {
+                acc[0][e] = fmaf(x[e], t.x, acc[0][e]); acc[1][e] = fmaf(x[e], t.y, acc[1][e]);
+                acc[2][e] = fmaf(x[e], t.z, acc[2][e]); acc[3][e] = fmaf(x[e], t.w, acc[3][e]);
+            }
         }
     }
-    const int J = J8 * 8;
-    float* p = part + ((size_t)blockIdx.y * 4) * J + (size_t)j8 * 8;
+    if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        *(float4*)(p + (size_t)r * J) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-        *(float4*)(p + (size_t)r * J + 4) = make_float4(acc[r][4], acc[r][5], acc[r][6], acc[r][7]);
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) sred[wave - 1][r * 8 + e][lane] = acc[r][e];
     }
+    __syncthreads();
+    if (wave == 0 && live) {
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[r][e] += sred[w][r * 8 + e][lane];
+        const int J = J8 * 8;
+        float* p = part + ((size_t)chunk * 4) * J + (size_t)j8 * 8;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            *(float4*)(p + (size_t)r * J) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+            *(float4*)(p + (size_t)r * J + 4) = make_float4(acc[r][4], acc[r][5], acc[r][6], acc[r][7]);
+        }
+    }
+}
+
+// sum over the chunks, IN CHUNK ORDER, of part[c * stride + i]: eight independent loads in flight, added one after the other
+__device__ __forceinline__ float chunk_sum(const float* __restrict__ part, size_t stride, int i, int chunks)
+{
+    float s = 0.f;
+    int c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = part[(size_t)(c + u) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += t[u];
+    }
+    for (; c < chunks; c++) s += part[(size_t)c * stride + i];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void lora_colreduce_kernel(const u32x4* __restrict__ a, const float4* __restrict__ v,
+                                                              float* __restrict__ part, int M, int J8, int rows)
+{
+    __shared__ float sred[3][32][64];
+    colreduce_body(a, v, part, M, J8, rows, blockIdx.y, blockIdx.x, sred);
 }
 
 // g = scale * sum over chunks (in chunk order) of part[chunk][r][j]; out as [4][J] (transposed = 0) or [J][4] (transposed = 1)
@@ -249,8 +320,7 @@ __global__ __launch_bounds__(256) void lora_colreduce_finish_kernel(const float*
 {
     const int i = blockIdx.x * 256 + threadIdx.x;      // r * J + j
     if (i >= 4 * J) return;
-    float s = 0.f;
-    for (int c = 0; c < chunks; c++) s += part[(size_t)c * 4 * J + i];
+    const float s = chunk_sum(part, (size_t)4 * J, i, chunks);
     const int r = i / J, j = i - r * J;
     g[transposed ? (size_t)j * 4 + r : (size_t)i] = scale * s;
 }
@@ -266,40 +336,12 @@ struct ColPair {
     int acc;      // 1: g += the sum (a gradient buffer that accumulates over backward passes, torch's .grad convention)
 };
 
-__global__ __launch_bounds__(64) void lora_colreduce_pair_kernel(ColPair p, int M, int rows)
+__global__ __launch_bounds__(256) void lora_colreduce_pair_kernel(ColPair p, int M, int rows)
 {
+    __shared__ float sred[3][32][64];
     const int z = blockIdx.z;
-    const int J8 = p.J8[z];
-    const int j8 = blockIdx.x * 64 + threadIdx.x;
-    if (j8 >= J8) return;
-    const u32x4* __restrict__ a = p.a[z];
-    const float4* __restrict__ v = p.v[z];
-    const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
-    float acc[4][8];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) acc[r][e] = 0.f;
-#pragma unroll 4
-    for (int m = m0; m < m1; m++) {
-        const u32x4 q = a[(size_t)m * J8 + j8];
-        const float4 t = v[m];
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 4; e++) { x[2 * e] = lo16(q.w[e]); x[2 * e + 1] = hi16(q.w[e]); }
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            acc[0][e] = fmaf(x[e], t.x, acc[0][e]); acc[1][e] = fmaf(x[e], t.y, acc[1][e]);
-            acc[2][e] = fmaf(x[e], t.z, acc[2][e]); acc[3][e] = fmaf(x[e], t.w, acc[3][e]);
-        }
-    }
-    const int J = J8 * 8;
-    float* q = p.part[z] + ((size_t)blockIdx.y * 4) * J + (size_t)j8 * 8;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        *(float4*)(q + (size_t)r * J) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-        *(float4*)(q + (size_t)r * J + 4) = make_float4(acc[r][4], acc[r][5], acc[r][6], acc[r][7]);
-    }
+    if ((int)blockIdx.x * 64 >= p.J8[z]) return;       // whole workgroup: no barrier is skipped by part of it
+    colreduce_body(p.a[z], p.v[z], p.part[z], M, p.J8[z], rows, blockIdx.y, blockIdx.x, sred);
 }
 
 __global__ __launch_bounds__(256) void lora_colreduce_pair_finish_kernel(ColPair p, int chunks)
@@ -310,9 +352,7 @@ __global__ __launch_bounds__(256) void lora_colreduce_pair_finish_kernel(ColPair
     const int z = i >= n0;
     if (z) i -= n0;
     const int J = 8 * p.J8[z];
-    const float* part = p.part[z];
-    float s = 0.f;
-    for (int c = 0; c < chunks; c++) s += part[(size_t)c * 4 * J + i];
+    const float s = chunk_sum(p.part[z], (size_t)4 * J, i, chunks);
     const int r = i / J, j = i - r * J;
     float* dst = p.g[z] + (z == 0 ? (size_t)j * 4 + r : (size_t)i);          // d up as [N][4], d down as [4][K]
     *dst = p.acc ? *dst + s : s;
@@ -387,7 +427,7 @@ int gd_nn_lora_colreduce(void* stream, const void* a, const float* v, float* scr
     const int rows = chunk_rows(M);
     const int chunks = (int)((M + rows - 1) / rows);
     const int J8 = J / 8;
-    hipLaunchKernelGGL(lora_colreduce_kernel, dim3((J8 + 63) / 64, chunks), dim3(64), 0, (hipStream_t)stream, (const u32x4*)a,
+    hipLaunchKernelGGL(lora_colreduce_kernel, dim3((J8 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a,
                        (const float4*)v, scratch, (int)M, J8, rows);
     hipLaunchKernelGGL(lora_colreduce_finish_kernel, dim3((4 * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, g, chunks, J,
                        scale, g_is_j_by_4);
@@ -420,7 +460,7 @@ int gd_nn_lora_colreduce_pair_into(void* stream, const void* dy, const float* hs
     p.a[1] = (const u32x4*)x; p.v[1] = (const float4*)dh; p.part[1] = scratch + (size_t)chunks * 4 * N; p.g[1] = d_down; p.J8[1] = K / 8;
     p.acc = accumulate ? 1 : 0;
     const int jmax = N > K ? N / 8 : K / 8;
-    hipLaunchKernelGGL(lora_colreduce_pair_kernel, dim3((jmax + 63) / 64, chunks, 2), dim3(64), 0, (hipStream_t)stream, p, (int)M, rows);
+    hipLaunchKernelGGL(lora_colreduce_pair_kernel, dim3((jmax + 63) / 64, chunks, 2), dim3(256), 0, (hipStream_t)stream, p, (int)M, rows);
     hipLaunchKernelGGL(lora_colreduce_pair_finish_kernel, dim3((4 * (N + K) + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, chunks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
