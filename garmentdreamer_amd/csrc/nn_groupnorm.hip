@@ -249,7 +249,7 @@ __global__ __launch_bounds__(THREADS) void gn_group_fused_kernel(const uint32_t*
                                                                  const uint16_t* __restrict__ gamma,
                                                                  const uint16_t* __restrict__ beta, int HW, int C2,
                                                                  int cg2, int G, uint32_t magic, float eps,
-                                                                 int apply_silu)
+                                                                 int apply_silu, float* __restrict__ mean_rstd)
 {
     constexpr int WAVES = THREADS / 64;
     __shared__ double s_red[2][WAVES];
@@ -302,6 +302,10 @@ __global__ __launch_bounds__(THREADS) void gn_group_fused_kernel(const uint32_t*
         double var = sb / M - mean * mean;
         var = var < 0 ? 0 : var;
         const float meanf = (float)mean, rstd = rsqrtf((float)var + eps);
+        if (tid == 0 && mean_rstd) {       // training: the backward pass (gn_group_fused_bwd_kernel) normalises with these
+            mean_rstd[((size_t)n * G + g) * 2] = meanf;
+            mean_rstd[((size_t)n * G + g) * 2 + 1] = rstd;
+        }
         const int c = (g * cg2 + tid) * 2;
         const float a0 = rstd * bf2f(gamma[c]), a1 = rstd * bf2f(gamma[c + 1]);
         s_a[tid] = f2{a0, a1};
@@ -320,6 +324,108 @@ __global__ __launch_bounds__(THREADS) void gn_group_fused_kernel(const uint32_t*
         if (apply_silu) z = z * sigmoid2(z);
         __builtin_amdgcn_raw_buffer_store_b32(pack2(z), rs_y, off, 0, 0);
         if ((i & (R >= 64 ? 3 : 7)) == (R >= 64 ? 3 : 7)) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+
+// The backward pass of the same layers in ONE launch (the LoRA UNet's training pass, NeTF stage): the workgroup of
+// (image, group) holds its slices of x AND dy in registers, forms the group's two sums
+//   m1 = mean(gamma dz),  m2 = mean(gamma dz xhat),   dz = dy silu'(z),  z = gamma xhat + beta,  xhat = (x - mean) rstd
+// (per-thread fp32, cross-thread fp64, like the forward pass) and writes dx = rstd (gamma dz - m1 - xhat m2) from the
+// registers: x and dy read once (the two-pass form reads them twice and takes two launches plus a memset-free workspace),
+// no atomics, bit-reproducible.  mean / rstd come from the forward launch.
+template <int THREADS, int R>
+__global__ __launch_bounds__(THREADS) void gn_group_fused_bwd_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ dy,
+                                                                     uint32_t* __restrict__ dx, const uint16_t* __restrict__ gamma,
+                                                                     const uint16_t* __restrict__ beta,
+                                                                     const float* __restrict__ mean_rstd, int HW, int C2, int cg2,
+                                                                     int G, uint32_t magic, int apply_silu)
+{
+    constexpr int WAVES = THREADS / 64;
+    __shared__ double s_red[2][WAVES];
+    __shared__ f2 s_g[64], s_b[64];
+    __shared__ float s_m[2];
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);      // an image's groups on one XCD (see the forward kernel)
+    const int n = bid / G, g = bid - n * G, tid = threadIdx.x;
+    const int total = HW * cg2;
+    const uint32_t img_bytes = (uint32_t)HW * (uint32_t)C2 * 4u;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)n * HW * C2), 0, (int)img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (size_t)n * HW * C2), 0, (int)img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(dx + (size_t)n * HW * C2), 0, (int)img_bytes, 0x00020000);
+    const uint32_t goff = (uint32_t)g * (uint32_t)cg2 * 4u;
+    const float mean = mean_rstd[((size_t)n * G + g) * 2], rstd = mean_rstd[((size_t)n * G + g) * 2 + 1];
+    if (tid < cg2) {
+        const int c = (g * cg2 + tid) * 2;
+        s_g[tid] = f2{bf2f(gamma[c]), bf2f(gamma[c + 1])};
+        s_b[tid] = f2{bf2f(beta[c]), bf2f(beta[c + 1])};
+    }
+    uint32_t vx[R], vd[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int d = tid + i * THREADS;
+        const uint32_t p = __umulhi((uint32_t)d, magic);          // d / cg2
+        const uint32_t off = d < total ? (p * (uint32_t)C2 + ((uint32_t)d - p * (uint32_t)cg2)) * 4u + goff : 0xfffffff0u;
+        vx[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0);
+        vd[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_d, off, 0, 0);       // past the end: dy = 0 -> the cell adds nothing
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    // gamma dz and xhat of register i
+    auto cell = [&](int t0, int i, f2& t, f2& xh) {
+        const int d = t0 + i * THREADS;
+        const uint32_t p = __umulhi((uint32_t)d, magic);
+        const uint32_t j = ((uint32_t)d - p * (uint32_t)cg2) & 63u;
+        const f2 gm = s_g[j];
+        xh = (unpack2(vx[i]) - mean) * rstd;
+        f2 dz = unpack2(vd[i]);
+        if (apply_silu) {
+            const f2 z = xh * gm + s_b[j];
+            const f2 sg = sigmoid2(z);
+            dz *= sg * (1.f + z * (1.f - sg));
+        }
+        t = dz * gm;
+    };
+    f2 q1 = f2{0.f, 0.f}, q2 = f2{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        f2 t, xh;
+        cell(tid, i, t, xh);
+        q1 += t;
+        q2 += t * xh;
+        if (R < 16 ? (i & 3) == 3 : (i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // few cells in flight: 2 R data registers are live
+    }
+    double a = (double)q1.x + (double)q1.y, b = (double)q2.x + (double)q2.y;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = a; s_red[1][tid >> 6] = b; }
+    __syncthreads();
+    if (tid == 0) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) { sa += s_red[0][w]; sb += s_red[1][w]; }
+        const double M = (double)total * 2.0;
+        s_m[0] = (float)(sa / M);
+        s_m[1] = (float)(sb / M);
+    }
+    __syncthreads();
+    const float m1 = s_m[0], m2 = s_m[1];
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));       // the offsets are recomputed here, not kept alive across the reduction
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int d = tid2 + i * THREADS;
+        const uint32_t p = __umulhi((uint32_t)d, magic);
+        const uint32_t off = d < total ? (p * (uint32_t)C2 + ((uint32_t)d - p * (uint32_t)cg2)) * 4u + goff : 0xfffffff0u;
+        f2 t, xh;
+        cell(tid2, i, t, xh);      // channel index and gamma / beta are looked up again, not carried over in registers
+        const f2 r = (t - m1 - xh * m2) * rstd;
+        __builtin_amdgcn_raw_buffer_store_b32(pack2(r), rs_o, off, 0, 0);
+        if (R < 16 ? (i & 3) == 3 : (i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -623,6 +729,41 @@ int gd_nn_groupnorm_silu_fused_supported(int N, int HW, int C, int G)
 int gd_nn_groupnorm_silu_fused_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
                                        int HW, int C, int G, float eps, int apply_silu)
 {
+    return gd_nn_groupnorm_silu_fused_forward_stats(stream, x, y, gamma, beta, N, HW, C, G, eps, apply_silu, nullptr);
+}
+
+int gd_nn_groupnorm_silu_fused_backward_supported(int N, int HW, int C, int G)
+{
+    // x AND dy live in registers: half the forward pass's slice (32 dwords of each per thread spill 144 registers)
+    return gd_nn_groupnorm_silu_fused_supported(N, HW, C, G) && (long)HW * (C / G / 2) <= 1024L * 16 ? 1 : 0;
+}
+
+int gd_nn_groupnorm_silu_fused_backward(void* stream, const void* x, const void* dy, const void* gamma, const void* beta,
+                                        const float* mean_rstd, void* dx, int N, int HW, int C, int G, int apply_silu)
+{
+    if (!x || !dy || !gamma || !beta || !mean_rstd || !dx) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!gd_nn_groupnorm_silu_fused_backward_supported(N, HW, C, G))
+        return fail(GD_NN_ERR_INVALID_ARG, "fused GroupNorm backward: need C % G == 0, C / G even, 4 <= C / G <= 128, HW * C / G <= 32768");
+    const int cg2 = C / G / 2, total = HW * cg2;
+    const uint32_t magic = (uint32_t)((0x100000000ull + (uint64_t)cg2 - 1) / (uint64_t)cg2);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)G * (unsigned)N);
+#define GD_GN_FUSED_BWD(T_, R_)                                                                                         \
+    hipLaunchKernelGGL((gn_group_fused_bwd_kernel<T_, R_>), grid, dim3(T_), 0, s, (const uint32_t*)x, (const uint32_t*)dy, \
+                       (uint32_t*)dx, (const uint16_t*)gamma, (const uint16_t*)beta, mean_rstd, HW, C / 2, cg2, G, magic, \
+                       apply_silu)
+    if (total <= 256 * 8) GD_GN_FUSED_BWD(256, 8);
+    else if (total <= 1024 * 8) GD_GN_FUSED_BWD(1024, 8);
+    else GD_GN_FUSED_BWD(1024, 16);
+#undef GD_GN_FUSED_BWD
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_groupnorm_silu_fused_forward_stats(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
+                                             int HW, int C, int G, float eps, int apply_silu, float* mean_rstd)
+{
     if (!x || !y || !gamma || !beta) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
     if (!gd_nn_groupnorm_silu_fused_supported(N, HW, C, G))
         return fail(GD_NN_ERR_INVALID_ARG, "fused GroupNorm: need C % G == 0, C / G even, 4 <= C / G <= 128, HW * C / G <= 65536");
@@ -632,7 +773,7 @@ int gd_nn_groupnorm_silu_fused_forward(void* stream, const void* x, void* y, con
     const dim3 grid((unsigned)G * (unsigned)N);
 #define GD_GN_FUSED(T_, R_)                                                                                             \
     hipLaunchKernelGGL((gn_group_fused_kernel<T_, R_>), grid, dim3(T_), 0, s, (const uint32_t*)x, (uint32_t*)y,          \
-                       (const uint16_t*)gamma, (const uint16_t*)beta, HW, C / 2, cg2, G, magic, eps, apply_silu)
+                       (const uint16_t*)gamma, (const uint16_t*)beta, HW, C / 2, cg2, G, magic, eps, apply_silu, mean_rstd)
     if (total <= 256 * 8) GD_GN_FUSED(256, 8);
     else if (total <= 1024 * 8) GD_GN_FUSED(1024, 8);
     else if (total <= 1024 * 16) GD_GN_FUSED(1024, 16);

@@ -31,6 +31,9 @@ SIGNATURES = {
     "gd_nn_groupnorm_silu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "gd_nn_groupnorm_silu_fused_supported": (_i, [_i, _i, _i, _i]),
     "gd_nn_groupnorm_silu_fused_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i]),
+    "gd_nn_groupnorm_silu_fused_forward_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "gd_nn_groupnorm_silu_fused_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gd_nn_groupnorm_silu_fused_backward_supported": (_i, [_i, _i, _i, _i]),
     "gd_nn_groupnorm_silu_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gd_nn_groupnorm_ws_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
@@ -227,6 +230,53 @@ def _gn_fused_small(x, weight, bias, groups, eps, silu):
     return y
 
 
+# GD_NN_GN_SMALL_TRAIN=0: the two-pass pair also in the training pass (A/B timing in tools/; never set in tests)
+_GN_FUSED_TRAIN = os.environ.get("GD_NN_GN_SMALL_TRAIN", "1") != "0"
+
+
+class _GroupNormSiLUSmall(torch.autograd.Function):
+    """GroupNorm(+SiLU) WITH an input gradient on maps whose (image, group) slice fits a workgroup's registers (the LoRA
+    UNet's training pass): one launch forward (statistics kept), one launch backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, silu):
+        N, Cc, H, W = x.shape
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        mr = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+        w, b = weight.contiguous(), bias.contiguous()
+        with torch.cuda.device(x.device):
+            _check(lib().gd_nn_groupnorm_silu_fused_forward_stats(
+                torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), y.data_ptr(), w.data_ptr(), b.data_ptr(), N,
+                H * W, Cc, groups, float(eps), int(silu), mr.data_ptr()), "gd_nn_groupnorm_silu_fused_forward_stats")
+        ctx.save_for_backward(x, w, b, mr)
+        ctx.groups, ctx.silu = groups, silu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, mr = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        L = lib()
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            if L.gd_nn_groupnorm_silu_fused_backward_supported(N, H * W, Cc, ctx.groups):
+                _check(L.gd_nn_groupnorm_silu_fused_backward(stream, x.data_ptr(), dy.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                             mr.data_ptr(), dx.data_ptr(), N, H * W, Cc, ctx.groups,
+                                                             int(ctx.silu)), "gd_nn_groupnorm_silu_fused_backward")
+            else:       # x and dy of the slice do not fit the registers together: the two-pass pair on the kept statistics
+                ws = _gn_workspace(x, N, ctx.groups)
+                sums = torch.empty(N * ctx.groups * 2, dtype=torch.float32, device=x.device)
+                _check(L.gd_nn_groupnorm_silu_backward(stream, x.data_ptr(), dy.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                       mr.data_ptr(), dx.data_ptr(), N, H * W, Cc, ctx.groups,
+                                                       int(ctx.silu), ws.data_ptr(), sums.data_ptr(), None),
+                       "gd_nn_groupnorm_silu_backward")
+        return dx, None, None, None, None, None
+
+
 def group_norm_silu(x, weight, bias, groups: int, eps: float, silu: bool = True):
     """``silu(group_norm(x))`` (or just group_norm).  HIP kernel for bf16 NHWC tensors on the GPU."""
     if x.is_cuda:
@@ -235,8 +285,11 @@ def group_norm_silu(x, weight, bias, groups: int, eps: float, silu: bool = True)
         if x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0:
             if not x.is_contiguous(memory_format=torch.channels_last):
                 x = x.contiguous(memory_format=torch.channels_last)
-            if _GN_FUSED_SMALL and not (torch.is_grad_enabled() and x.requires_grad) and \
-                    lib().gd_nn_groupnorm_silu_fused_supported(x.shape[0], x.shape[2] * x.shape[3], x.shape[1], groups):
+            small = lib().gd_nn_groupnorm_silu_fused_supported(x.shape[0], x.shape[2] * x.shape[3], x.shape[1], groups)
+            if torch.is_grad_enabled() and x.requires_grad:
+                if small and _GN_FUSED_TRAIN:
+                    return _GroupNormSiLUSmall.apply(x, weight, bias, groups, eps, silu)
+            elif small and _GN_FUSED_SMALL:
                 return _gn_fused_small(x, weight, bias, groups, eps, silu)
             return _GroupNormSiLU.apply(x, weight, bias, groups, eps, silu)
         # fp32 GPU runs (parity checks of the bf16 path) use torch's ops

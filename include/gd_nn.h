@@ -91,13 +91,23 @@ int gd_nn_conv_set_route_scale(int k);
 
 /* gd_nn_groupnorm_silu_forward as ONE launch for inference on small feature maps (the UNet's GroupNorms at <= 16
  * latents: diffusers ResnetBlock2D.norm1 / norm2, Transformer2DModel.norm, conv_norm_out): one workgroup per (image,
- * group) holds its HW x C/G slice in registers -- x is read once, no workspace, no statistics output (the backward pass
- * needs the two-pass form).  _supported: C % G == 0, C / G even, 4 <= C / G <= 128, HW * C / G <= 65536 elements
+ * group) holds its HW x C/G slice in registers -- x is read once, no workspace.  _supported: C % G == 0, C / G even, 4 <= C / G <= 128, HW * C / G <= 65536 elements
  * (<= 32768 when C / G < 16: short channel runs load poorly)
  * (the slice lives in the workgroup's registers). */
 int gd_nn_groupnorm_silu_fused_supported(int N, int HW, int C, int G);
 int gd_nn_groupnorm_silu_fused_forward(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
                                        int HW, int C, int G, float eps, int apply_silu);
+/* The same launch with the statistics kept (mean_rstd[N][G][2] = {mean, 1 / sqrt(var + eps)}, may be NULL), and the
+ * input gradient of such a layer as ONE launch as well -- the training pass of the NeTF stage's LoRA UNet
+ * (Garment_Deformer_NeTF/netf/vsd/lora_unet.py:119-160 skeleton, trained by netf/trainer.py:215-256), whose feature maps
+ * are one or two latents: the (image, group) workgroup holds its slices of x and dy in registers, forms the two group
+ * sums of gd_nn_groupnorm_silu_backward and writes dx (frozen gamma / beta; bit-reproducible); larger slices take
+ * gd_nn_groupnorm_silu_backward on the kept statistics. */
+int gd_nn_groupnorm_silu_fused_forward_stats(void* stream, const void* x, void* y, const void* gamma, const void* beta, int N,
+                                             int HW, int C, int G, float eps, int apply_silu, float* mean_rstd);
+int gd_nn_groupnorm_silu_fused_backward_supported(int N, int HW, int C, int G);   /* _supported and HW * C / G <= 32768 */
+int gd_nn_groupnorm_silu_fused_backward(void* stream, const void* x, const void* dy, const void* gamma, const void* beta,
+                                        const float* mean_rstd, void* dx, int N, int HW, int C, int G, int apply_silu);
 
 /* GroupNorm statistics only: mean_rstd[N][G][2] = {mean, 1/sqrt(var + eps)} of x (bf16 [N,HW,C]); stats_ws as in
  * gd_nn_groupnorm_silu_forward.  Feeds gd_nn_conv3x3_gn_forward (and gd_nn_groupnorm_silu_backward). */

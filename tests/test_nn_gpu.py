@@ -62,10 +62,10 @@ def test_one_launch_groupnorm_matches_fp32_reference_and_the_two_pass_kernels(N,
     ulp = torch.maximum(y2.float().abs(), torch.full_like(d, 2.0 ** -8)) * 2.0 ** -7      # one bf16 step at |y|
     assert bool((d <= ulp).all()), float((d / ulp).max())
     assert float((d > 0).float().mean()) < 2e-2
-    # a tensor that needs a gradient keeps the two-pass form (the backward pass reads mean / rstd)
+    # a tensor that needs a gradient takes the same launch with the statistics kept (its backward pass: the test below)
     xg = x.clone().requires_grad_(True)
     yg = nn_ops.group_norm_silu(xg, w, b, 32, 1e-5, silu)
-    assert yg.grad_fn is not None and torch.equal(yg.detach(), y2)
+    assert yg.grad_fn is not None and torch.equal(yg.detach(), y)
 
 
 def test_one_launch_groupnorm_refuses_slices_that_do_not_fit_the_registers():
@@ -85,6 +85,48 @@ def test_one_launch_groupnorm_refuses_slices_that_do_not_fit_the_registers():
     with torch.no_grad():          # the dispatch falls back to the two-pass kernels
         y = nn_ops.group_norm_silu(torch.randn_like(x), w, torch.zeros_like(w), 32, 1e-5, True)
     assert torch.isfinite(y.float()).all()
+
+@pytest.mark.parametrize("N,C,H,W,silu", [(1, 640, 32, 32, True), (2, 960, 32, 32, True), (2, 1280, 32, 32, True),
+                                          (1, 1920, 32, 32, False), (2, 1280, 16, 16, True), (1, 2560, 16, 16, True),
+                                          (2, 1280, 8, 8, False), (1, 1920, 5, 7, True), (2, 128, 2, 2, True)])
+def test_one_launch_groupnorm_training_pair_matches_fp32_reference_and_the_two_pass_kernels(N, C, H, W, silu):
+    """GroupNorm(+SiLU) WITH an input gradient on the LoRA UNet's training maps: one launch forward that keeps mean / rstd
+    (gd_nn_groupnorm_silu_fused_forward_stats) and one launch backward with x and dy of the (image, group) slice in registers
+    (gd_nn_groupnorm_silu_fused_backward; slices above 32768 elements take the two-pass backward on the kept statistics) --
+    against fp32 torch at the GroupNorm bars and against the two-pass pair; bit-reproducible."""
+    from garmentdreamer_amd import nn_ops
+    L = nn_ops.lib()
+    assert L.gd_nn_groupnorm_silu_fused_supported(N, H * W, C, 32) == 1
+    assert L.gd_nn_groupnorm_silu_fused_backward_supported(N, H * W, C, 32) == (1 if H * W * (C // 64) <= 16384 else 0)
+    g = torch.Generator(DEV).manual_seed(C + H + N)
+    x = (torch.randn(N, C, H, W, device=DEV, generator=g) * 1.7 + 0.4).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, device=DEV, generator=g) * 0.5 + 1.0).to(torch.bfloat16)
+    b = (torch.randn(C, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
+    gy = torch.randn(N, C, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fn in (lambda t: nn_ops.group_norm_silu(t, w, b, 32, 1e-5, silu), lambda t: nn_ops.group_norm_silu(t, w, b, 32, 1e-5, silu),
+               lambda t: nn_ops._GroupNormSiLU.apply(t, w, b, 32, 1e-5, silu)):
+        xi = x.detach().clone().requires_grad_(True)
+        y = fn(xi)
+        y.backward(gy)
+        outs.append((y.detach(), xi.grad, type(y.grad_fn).__name__))
+    (y, dx, name), (y_again, dx_again, _), (y2, dx2, name2) = outs
+    assert "GroupNormSiLUSmall" in name and "GroupNormSiLUSmall" not in name2
+    assert torch.equal(y, y_again) and torch.equal(dx, dx_again)
+    with torch.no_grad():
+        assert torch.equal(y, nn_ops.group_norm_silu(x, w, b, 32, 1e-5, silu))      # the inference launch, same bits
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.group_norm(xr, 32, w.float(), b.float(), 1e-5)
+    yr = F.silu(yr) if silu else yr
+    yr.backward(gy.float())
+    assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item() + 1e-2
+    gerr = (dx.float() - xr.grad).abs().max().item()
+    assert gerr <= 2e-2 * xr.grad.abs().max().item() + 1e-3, gerr
+    assert F.cosine_similarity(dx.float().flatten(), xr.grad.flatten(), dim=0).item() > 0.9995
+    # vs the two-pass pair: statistics equal up to the last bit, so outputs / gradients differ by bf16 rounding steps at most
+    assert (dx.float() - dx2.float()).abs().max().item() <= 2e-2 * xr.grad.abs().max().item() + 1e-3
+    assert (dx.float() - xr.grad).abs().mean().item() <= 1.2 * (dx2.float() - xr.grad).abs().mean().item() + 1e-6
+
 
 def test_groupnorm_workspace_is_shared_and_left_zero():
     """The statistics workspace is zero-initialised once per (device, stream) and every call must leave it zero
