@@ -332,8 +332,15 @@ def test_vae_encoder_with_epilogue_statistics_equals_the_statistics_pass_path(mo
         passes["n"] += a[11] is not None      # stats_ws given: the call runs its own statistics pass
         return real_fwd(*a)
 
+    real_small = L.gd_nn_groupnorm_silu_fused_forward_stats
+
+    def counted_small(*a):                    # the one-launch form of small maps forms its own statistics too
+        passes["n"] += 1
+        return real_small(*a)
+
     monkeypatch.setattr(L, "gd_nn_groupnorm_stats", counted_stats)
     monkeypatch.setattr(L, "gd_nn_groupnorm_silu_forward", counted_fwd)
+    monkeypatch.setattr(L, "gd_nn_groupnorm_silu_fused_forward_stats", counted_small)
 
     def run(flag):
         monkeypatch.setattr(nn_ops, "_EPILOGUE_STATS", flag)
