@@ -228,6 +228,101 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const bf16x8* _
 
 }  // namespace
 
+// Row softmax of the VAE mid block's single-head attention ([8 images x 4096 queries] rows of 4096 bf16 scores, 268 MB: the
+// score matrix is materialised on purpose) and its backward.  One wave per row, the row in registers (R 16-byte
+// vectors per lane): forward = read once, write once (in place if y == x); backward ds = p (dp - sum(p dp)) = read p and dp once,
+// write once -- torch's softmax backward runs a separate `grad * output` pass over the matrix first (aten::mul, 142 us) and then
+// its row kernel (137 us).  fp32 arithmetic, exp through v_exp_f32 on (x - max) log2(e).
+template <int R>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int64_t rows, int L8)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const u32x4* xr = x + row * L8;
+    u32x4 v[R];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int c = lane + 64 * i;
+        if (c < L8) {
+            v[i] = xr[c];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const f2 f = unpack2(v[i].w[e]); m = fmaxf(m, fmaxf(f.x, f.y)); }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const float k = 1.4426950408889634f;
+    const float mk = m == -INFINITY ? 0.f : m * k;
+    float sum = 0.f;
+    f2 ex[R][4];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        if (lane + 64 * i < L8) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const f2 f = unpack2(v[i].w[e]);
+                ex[i][e] = f2{__builtin_amdgcn_exp2f(f.x * k - mk), __builtin_amdgcn_exp2f(f.y * k - mk)};
+                sum += ex[i][e].x + ex[i][e].y;
+            }
+        }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    u32x4* yr = y + row * L8;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int c = lane + 64 * i;
+        if (c < L8) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o.w[e] = pack2(ex[i][e] * inv);
+            yr[c] = o;
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void softmax_rows_backward_kernel(const u32x4* __restrict__ p, const u32x4* __restrict__ dp,
+                                                                    u32x4* __restrict__ ds, int64_t rows, int L8)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const u32x4* pr = p + row * L8;
+    const u32x4* gr = dp + row * L8;
+    u32x4 vp[R], vg[R];
+    f2 acc = f2{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int c = lane + 64 * i;
+        if (c < L8) {
+            vp[i] = pr[c];
+            vg[i] = gr[c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        if (lane + 64 * i < L8) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc += unpack2(vp[i].w[e]) * unpack2(vg[i].w[e]);
+        }
+    }
+    const float s = wave_sum(acc.x + acc.y);
+    u32x4* or_ = ds + row * L8;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const int c = lane + 64 * i;
+        if (c < L8) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o.w[e] = pack2(unpack2(vp[i].w[e]) * (unpack2(vg[i].w[e]) - s));
+            or_[c] = o;
+        }
+    }
+}
+
 // AutoencoderKL.quant_conv: nn.Conv2d(8, 8, 1) on the encoder's [B, 8, 64, 64] moments (diffusers AutoencoderKL.encode, reached
 // through StableDiffusionGuidance.encode_images, stable_diffusion_guidance.py:160-167).  NHWC: a pixel is ONE 16-byte vector;
 // thread = pixel, the 8 x 8 weights + bias are wave-uniform (scalar loads), 64 FMAs per pixel in fp32.  TRANSPOSED = the input
@@ -346,6 +441,38 @@ int gd_nn_conv1x1_c8(void* stream, const void* x, const void* weight, const void
         hipLaunchKernelGGL(conv1x1_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x,
                            (const uint16_t*)weight, (const uint16_t*)bias, (u32x4*)y, npix);
     return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "conv1x1_c8: launch failed");
+}
+
+int gd_nn_softmax_rows_forward(void* stream, const void* x, void* y, int64_t rows, int L)
+{
+    if (!x || !y) return fail(GD_NN_ERR_INVALID_ARG, "softmax_rows: null pointer");
+    if (rows <= 0 || L <= 0 || L % 8 || L > 8192) return fail(GD_NN_ERR_INVALID_ARG, "softmax_rows: need rows > 0, L % 8 == 0, L <= 8192");
+    const int64_t blocks = (rows + 3) / 4;
+    if (blocks > 2147483647LL) return fail(GD_NN_ERR_INVALID_ARG, "softmax_rows: too many rows");
+    const int L8 = L / 8, R = (L8 + 63) / 64;
+#define GD_SM(R_) hipLaunchKernelGGL(softmax_rows_kernel<R_>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (u32x4*)y, rows, L8)
+    if (R <= 2) GD_SM(2);
+    else if (R <= 4) GD_SM(4);
+    else if (R <= 8) GD_SM(8);
+    else GD_SM(16);
+#undef GD_SM
+    return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "softmax_rows: launch failed");
+}
+
+int gd_nn_softmax_rows_backward(void* stream, const void* p, const void* dp, void* ds, int64_t rows, int L)
+{
+    if (!p || !dp || !ds) return fail(GD_NN_ERR_INVALID_ARG, "softmax_rows_backward: null pointer");
+    if (rows <= 0 || L <= 0 || L % 8 || L > 8192) return fail(GD_NN_ERR_INVALID_ARG, "softmax_rows_backward: need rows > 0, L % 8 == 0, L <= 8192");
+    const int64_t blocks = (rows + 3) / 4;
+    if (blocks > 2147483647LL) return fail(GD_NN_ERR_INVALID_ARG, "softmax_rows_backward: too many rows");
+    const int L8 = L / 8, R = (L8 + 63) / 64;
+#define GD_SMB(R_) hipLaunchKernelGGL(softmax_rows_backward_kernel<R_>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)p, (const u32x4*)dp, (u32x4*)ds, rows, L8)
+    if (R <= 2) GD_SMB(2);
+    else if (R <= 4) GD_SMB(4);
+    else if (R <= 8) GD_SMB(8);
+    else GD_SMB(16);
+#undef GD_SMB
+    return hipGetLastError() == hipSuccess ? 0 : fail(GD_NN_ERR_HIP, "softmax_rows_backward: launch failed");
 }
 
 }  // extern "C"

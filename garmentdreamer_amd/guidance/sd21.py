@@ -46,6 +46,7 @@ import os as _os
 _FUSED_QKV = _os.environ.get("GD_FUSED_QKV", "1") != "0"   # A/B toggle of the fused self-attention projection
 _VT_GEMM = _os.environ.get("GD_VT_GEMM", "1") != "0"         # A/B toggle: V^T from a GEMM instead of the transposing pre-pass
 _LORA_FUSED = _os.environ.get("GD_LORA_FUSED", "1") != "0"   # A/B toggle: own rank-4 LoRA kernels (fwd + bwd) instead of torch ops
+_VAE_ATTN_NODE = _os.environ.get("GD_VAE_ATTN_NODE", "1") != "0"  # A/B toggle: VAE mid attention as one autograd node with own softmax
 _LORA_LINEAR = _os.environ.get("GD_LORA_LINEAR", "1") != "0"  # A/B toggle: adapted projection as ONE autograd node (nn_ops.lora_linear)
 from .. import nn_ops  # noqa: E402
 _FP8_ACTIVE = [None]   # the nn_ops.Fp8State of the UNet whose no-grad forward is running (set by its forward)
@@ -706,12 +707,20 @@ class _VAEAttention(nn.Module):
             # head_dim 512 runs at ~180 TFLOP/s; the [B,N,N] bf16 score matrix (34 MB per image at N = 4096) is
             # cheap on a 288 GB part.  Frozen weights: one [C, 3C] projection with the softmax scale folded into its
             # q rows (no N x C scaling pass forward or backward); the bmm's read the strided q / k / v views.
+            o = None
             if _FUSED_QKV and not (self.to_q.weight.requires_grad or self.to_k.weight.requires_grad or self.to_v.weight.requires_grad):
-                q, k, v = _lib_linear(h, *self._qkv_scaled(h.dtype, C ** -0.5)).chunk(3, dim=-1)
+                qkv = _lib_linear(h, *self._qkv_scaled(h.dtype, C ** -0.5))
+                if _VAE_ATTN_NODE and nn_ops.single_head_attention_supported(qkv):
+                    # scores, own row softmax (forward and backward, in place) and the three GEMM gradients written into one
+                    # [B, N, 3C] tensor: one autograd node (nn_ops._SingleHeadAttention)
+                    o = nn_ops.single_head_attention(qkv)
+                else:
+                    q, k, v = qkv.chunk(3, dim=-1)
             else:
                 q, k, v = _lin(self.to_q, h) * (C ** -0.5), _lin(self.to_k, h), _lin(self.to_v, h)
-            p = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
-            o = torch.bmm(p, v)
+            if o is None:
+                p = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
+                o = torch.bmm(p, v)
         else:
             q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
             o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]

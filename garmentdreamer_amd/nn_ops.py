@@ -87,6 +87,8 @@ SIGNATURES = {
     "gd_nn_geglu_forward": (_i, [_vp, _vp, _vp, C.c_int64, _i]),
     "gd_nn_geglu_backward": (_i, [_vp, _vp, _vp, _vp, C.c_int64, _i]),
     "gd_nn_conv1x1_c8": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i]),
+    "gd_nn_softmax_rows_forward": (_i, [_vp, _vp, _vp, C.c_int64, _i]),
+    "gd_nn_softmax_rows_backward": (_i, [_vp, _vp, _vp, _vp, C.c_int64, _i]),
     "gd_nn_layernorm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, C.c_float]),
     "gd_nn_add_layernorm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, C.c_int64, _i]),
     "gd_nn_attention_ws_bytes": (C.c_size_t, [_i, _i, _i]),
@@ -1160,6 +1162,68 @@ class _GegluTrain(torch.autograd.Function):
         if ret < 0:
             raise RuntimeError(f"gd_nn_geglu_backward failed ({ret}): {L.gd_nn_elementwise_last_error().decode()}")
         return dx
+
+
+def softmax_rows_(s):
+    """In-place softmax over the last dimension of a contiguous bf16 GPU tensor (gd_nn_softmax_rows_forward)."""
+    L = s.shape[-1]
+    with torch.cuda.device(s.device):
+        ret = lib().gd_nn_softmax_rows_forward(torch.cuda.current_stream(s.device).cuda_stream, s.data_ptr(), s.data_ptr(),
+                                               s.numel() // L, L)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_softmax_rows_forward failed ({ret}): {lib().gd_nn_elementwise_last_error().decode()}")
+    return s
+
+
+def softmax_rows_backward_(p, dp):
+    """``dp <- p * (dp - sum(p * dp, -1))`` in place (gd_nn_softmax_rows_backward): the gradient of the scores."""
+    L = p.shape[-1]
+    with torch.cuda.device(p.device):
+        ret = lib().gd_nn_softmax_rows_backward(torch.cuda.current_stream(p.device).cuda_stream, p.data_ptr(), dp.data_ptr(),
+                                                dp.data_ptr(), p.numel() // L, L)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_softmax_rows_backward failed ({ret}): {lib().gd_nn_elementwise_last_error().decode()}")
+    return dp
+
+
+class _SingleHeadAttention(torch.autograd.Function):
+    """``softmax(q k^T) v`` for ONE head of many channels (the VAE mid block: 4096 tokens x 512 channels per image) on the
+    packed projection ``qkv`` [B, N, 3C] (the softmax scale already folded into the q rows): library GEMMs on the strided
+    q / k / v views, the score matrix materialised in bf16 (34 MB per image -- cheaper here than a fused kernel whose
+    backward for head_dim 512 runs far below the GEMMs), own row softmax forward and backward in place, and the three
+    input gradients written by the GEMMs straight into the slices of ONE [B, N, 3C] tensor (autograd's split backward
+    concatenated them: 148 us per step)."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        Cc = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:]
+        p = softmax_rows_(torch.bmm(q, k.transpose(1, 2)))
+        ctx.save_for_backward(qkv, p)
+        return torch.bmm(p, v)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, p = ctx.saved_tensors
+        Cc = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:]
+        do = do.contiguous()
+        ds = softmax_rows_backward_(p, torch.bmm(do, v.transpose(1, 2)))
+        dqkv = torch.empty_like(qkv)
+        torch.bmm(ds, k, out=dqkv[..., :Cc])
+        torch.bmm(ds.transpose(1, 2), q, out=dqkv[..., Cc:2 * Cc])
+        torch.bmm(p.transpose(1, 2), do, out=dqkv[..., 2 * Cc:])
+        return dqkv
+
+
+def single_head_attention_supported(qkv) -> bool:
+    return (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.is_contiguous() and qkv.shape[-1] % 24 == 0
+            and qkv.shape[1] % 8 == 0 and qkv.shape[1] <= 8192)
+
+
+def single_head_attention(qkv):
+    """[B, N, 3C] packed (scaled q | k | v) -> softmax(q k^T) v as [B, N, C]; see _SingleHeadAttention."""
+    return _SingleHeadAttention.apply(qkv)
 
 
 def _conv1x1_c8_launch(x, weight, bias, transposed):

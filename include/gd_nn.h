@@ -350,6 +350,12 @@ const char* gd_nn_conv_last_error(void);
  * [npix][8], weight bf16 [8][8] (Cout, Cin), bias bf16 [8] or NULL; fp32 accumulation.  transposed != 0: the input gradient
  * dx[p][ci] = sum_co weight[co][ci] dy[p][co] (bias ignored). */
 int gd_nn_conv1x1_c8(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t npix, int transposed);
+/* Row softmax of the VAE mid block's attention scores and its backward (diffusers Attention of AutoencoderKL's UNetMidBlock2D,
+ * one head of 512 channels over 64x64 tokens; reached through StableDiffusionGuidance.encode_images,
+ * threestudio/models/guidance/stable_diffusion_guidance.py:160-167): x / y / p / dp / ds bf16 [rows][L], L % 8 == 0, L <= 8192.
+ * forward: y = softmax(x) per row (y may be x).  backward: ds = p * (dp - sum_j p_j dp_j) per row (ds may be dp). */
+int gd_nn_softmax_rows_forward(void* stream, const void* x, void* y, int64_t rows, int L);
+int gd_nn_softmax_rows_backward(void* stream, const void* p, const void* dp, void* ds, int64_t rows, int L);
 const char* gd_nn_elementwise_last_error(void);
 /* ---- rank-4 LoRA branch of the NeTF stage's trainable UNet (csrc/nn_lora.hip), fp32 accumulation, forward + backward.
  * Replaces diffusers 0.19 LoRALinearLayer.forward inside LoRAAttnProcessor -- hidden + scale * up(down(x)) -- and its

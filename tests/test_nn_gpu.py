@@ -1283,6 +1283,71 @@ def test_quant_conv_1x1_forward_and_input_gradient_match_fp32_reference(B, H, W,
     assert not nn_ops.conv1x1_c8_supported(x, conv.weight, conv.bias)
 
 
+@pytest.mark.parametrize("rows,L", [(300, 4096), (77, 1024), (5, 8192), (130, 264), (9, 8)])
+def test_row_softmax_forward_and_backward_match_fp32_reference(rows, L):
+    """gd_nn_softmax_rows_forward / _backward (the VAE mid block's attention scores), in place, against fp32 torch on the same
+    bf16 values; rows of very different magnitude, a row of equal values and a masked-looking row included."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(rows + L)
+    x = (torch.randn(rows, L, device=DEV, generator=g) * torch.logspace(-1, 1.3, rows, device=DEV)[:, None]).to(torch.bfloat16)
+    x[0] = 3.0
+    if L > 8:
+        x[1, 1:] = -30000.0
+    ref = torch.softmax(x.float(), -1)
+    p = nn_ops.softmax_rows_(x.clone())
+    assert p.dtype == torch.bfloat16 and torch.isfinite(p.float()).all()
+    assert (p.float() - ref).abs().max().item() <= 4e-3 * ref.max().item() + 1e-6       # one bf16 rounding of a value <= 1
+    assert (p.float().sum(-1) - 1).abs().max().item() < 2e-2
+    dp = torch.randn(rows, L, device=DEV, generator=g).to(torch.bfloat16)
+    pf = p.float().requires_grad_(True)
+    want = torch._softmax_backward_data(dp.float(), pf.detach(), -1, torch.float32)
+    got = nn_ops.softmax_rows_backward_(p, dp.clone())
+    scale = want.abs().max().item()
+    assert (got.float() - want).abs().max().item() <= 8e-3 * scale + 1e-7
+    assert torch.equal(got, nn_ops.softmax_rows_backward_(p, dp.clone()))
+
+
+def test_vae_mid_attention_node_matches_the_library_path_and_fp32():
+    """sd21._VAEAttention with its core as one autograd node (library GEMMs on the packed projection, own in-place row softmax
+    forward / backward, the three input gradients written into one tensor) against the chunk + torch.softmax path of the
+    same module and against fp32: output and input gradient."""
+    from garmentdreamer_amd.guidance import sd21
+    g = torch.Generator(DEV).manual_seed(3)
+    att = sd21._VAEAttention(512).to(DEV)
+    sd21.init_random_(att, 4)
+    ref32 = sd21._VAEAttention(512).to(DEV)
+    ref32.load_state_dict(att.state_dict())
+    att = att.to(torch.bfloat16).requires_grad_(False)
+    x = torch.randn(2, 512, 32, 32, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, 512, 32, 32, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for node in (True, False):
+        sd21._VAE_ATTN_NODE = node
+        try:
+            xi = x.detach().clone().requires_grad_(True)
+            y = att(xi)
+            y.backward(gy)
+            res[node] = (y.detach().float(), xi.grad.float())
+        finally:
+            sd21._VAE_ATTN_NODE = True
+    ref32 = ref32.requires_grad_(False)
+    w = {k: v.to(torch.bfloat16).float() for k, v in ref32.state_dict().items()}
+    ref32.load_state_dict(w)
+    xr = x.detach().float().contiguous().requires_grad_(True)
+    hh = F.group_norm(xr, 32, ref32.group_norm.weight, ref32.group_norm.bias, 1e-6).permute(0, 2, 3, 1).reshape(2, 1024, 512)
+    q, k, v = ref32.to_q(hh), ref32.to_k(hh), ref32.to_v(hh)
+    o = torch.softmax(q @ k.transpose(1, 2) * 512 ** -0.5, -1) @ v
+    yr = xr + ref32.to_out[0](o).reshape(2, 32, 32, 512).permute(0, 3, 1, 2)
+    yr.backward(gy.float())
+    def rel(a, b):
+        return ((a - b).abs().max() / b.abs().max()).item()
+    (y1, g1), (y0, g0) = res[True], res[False]
+    assert rel(y1, yr.detach()) < 2e-2 and rel(g1, xr.grad) < 3e-2
+    assert rel(y1, y0) < 1e-2 and rel(g1, g0) < 1.5e-2
+    assert F.cosine_similarity(g1.flatten(), xr.grad.flatten(), dim=0).item() > 0.9995
+    assert rel(g1, xr.grad) <= 1.3 * rel(g0, xr.grad) + 2e-3
+
+
 def test_lora_gradients_land_in_the_flat_adam_sinks():
     """With flat_adam.FlatAdam the adapters' .grad are slices of one flat buffer and the LoRA backward kernels add into them
     (gd_nn_lora_colreduce_pair_into): the same bits as the gradients the node returns without sinks, twice that after a
