@@ -52,7 +52,103 @@ FLOPS_VISITED_PAIR = 14                   # backward.cu:522-532 per visited (pix
 FLOPS_CONTRIB_PAIR = 87                   # backward.cu:534-598 per contributing pair (incl. 10 adds)
 PEAK_FP32_TFLOPS = 157.3                  # MI355X fp32 vector = f32-input MFMA rate (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0                 # dense bf16 MFMA
+# What the VALU can ISSUE, measured on this chip (tools/probes/valu_rate_probe.hip): a wave64 v_pk_fma_f32 holds
+# its SIMD 5.3 cycles -> 2 FMA x 2 flop x 64 lanes / 5.3 cycles x 1024 SIMDs x 2.4 GHz; the 157.3 datasheet figure would need 4.0
+MEASURED_PACKED_FP32_TFLOPS = 2 * 2 * 64 / 5.3 * 1024 * 2.4e9 / 1e12
 METRIC = "SDS iters/sec (rasterize+UNet+bwd), 100k Gaussians ×8 views @512², 1/2/4/8 GPU"
+
+
+class Telemetry:
+    """Shader clock and socket power of THIS rank's GPU during the timed region, sampled from the amdgpu hwmon files by a side
+    thread (outside the step: two small sysfs reads every 20 ms).  The convolution family that dominates the step is
+    power-bound (profiles/r04_regw_ablation.txt), so two boxes of the pool differ by several % on the same tree: the line
+    carries what the box held while it was timed."""
+
+    def __init__(self, device_index: int):
+        self.samples = []          # (sclk MHz, power W)
+        self.source = None
+        self._stop = None
+        self._thread = None
+        try:
+            self._hwmon = self._find(device_index)
+        except Exception as e:     # telemetry is reporting only
+            self._hwmon, self.source = None, f"unavailable: {type(e).__name__}: {e}"
+
+    @staticmethod
+    def _cards():
+        import glob
+        out = []
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if os.path.exists(os.path.join(h, "freq1_input")) and os.path.exists(os.path.join(h, "power1_input")):
+                out.append(h)
+        return out
+
+    def _find(self, device_index: int):
+        cards = self._cards()
+        if not cards:
+            raise FileNotFoundError("no amdgpu hwmon with freq1_input + power1_input under /sys/class/drm")
+        bus = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bus = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        if bus is not None:
+            for h in cards:
+                real = os.path.realpath(os.path.join(h, "..", ".."))      # .../0000:05:00.0
+                if os.path.basename(real).lower().startswith(bus):
+                    self.source = f"{h} (PCI {bus})"
+                    return h
+        if len(cards) == 1:
+            self.source = cards[0]
+            return cards[0]
+        self.source = "busiest of %d amdgpu hwmon nodes (PCI id of the HIP device not matched)" % len(cards)
+        return cards           # sample all, keep the one that drew the most power
+
+    @staticmethod
+    def _read(h):
+        with open(os.path.join(h, "freq1_input")) as f:
+            mhz = int(f.read()) / 1e6
+        with open(os.path.join(h, "power1_input")) as f:
+            w = int(f.read()) / 1e6
+        return mhz, w
+
+    def start(self):
+        if self._hwmon is None:
+            return
+        import threading
+        self._stop = threading.Event()
+        many = isinstance(self._hwmon, list)
+        per = {h: [] for h in self._hwmon} if many else None
+
+        def run():
+            while not self._stop.is_set():
+                try:
+                    if many:
+                        for h in self._hwmon:
+                            per[h].append(self._read(h))
+                    else:
+                        self.samples.append(self._read(self._hwmon))
+                except Exception:
+                    pass
+                self._stop.wait(0.02)
+            if many:
+                best = max(per.values(), key=lambda v: sum(w for _, w in v) if v else 0.0)
+                self.samples = best
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self) -> dict:
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+        n = len(self.samples)
+        if n == 0:
+            return {"clock_mhz_mean": None, "power_w_mean": None, "samples": 0, "source": self.source}
+        return {"clock_mhz_mean": sum(m for m, _ in self.samples) / n, "clock_mhz_min": min(m for m, _ in self.samples),
+                "power_w_mean": sum(w for _, w in self.samples) / n, "power_w_max": max(w for _, w in self.samples),
+                "samples": n, "period_ms": 20, "source": self.source,
+                "what": "amdgpu hwmon freq1_input (sclk) / power1_input (socket) during the timed region"}
 
 
 def kernel_source_hash() -> str:
@@ -94,6 +190,10 @@ def parse():
                     help="six nn.Parameters + torch.optim.Adam(fused) instead of the flat-buffer GaussianModel")
     ap.add_argument("--nn-lib", default=None, help="A/B timing: another build of libgd_nn.so (recorded in the line's config)")
     ap.add_argument("--raster-lib", default=None, help="A/B timing: another build of libgd_raster.so (recorded likewise)")
+    ap.add_argument("--batch-invariant", action="store_true",
+                    help="SDSLoop(batch_invariant=True): kernels (and bf16 summation orders) selected for the WHOLE camera batch "
+                         "on every rank, so a sharded run reproduces the single-rank gradients per view bit for bit; off by "
+                         "default (each rank tunes its launches for its own share); recorded in the line's config")
     ap.add_argument("--stub-step", action="store_true",
                     help="TEST ONLY (tests/test_bench_launch.py): replace the SDS iteration by one small all-reduce so the "
                          "launch / rank-accounting logic of --gpus N can be exercised on CPU over gloo; the line it prints "
@@ -214,7 +314,7 @@ def vsd_main(args):
     # trainer.py:137 steps torch.optim.Adam over the adapters + embeddings: here one launch over the flat fp32 adapter buffer
     # (garmentdreamer_amd/flat_adam.py; constructed BEFORE the training graphs are captured -- it re-seats the adapters)
     from garmentdreamer_amd.flat_adam import FlatAdam
-    opt = FlatAdam(train, lr=1e-4) if os.environ.get("GD_FLAT_ADAM", "1") != "0" else torch.optim.Adam(train, lr=1e-4)
+    opt = FlatAdam.for_lora_unet(lora, train, lr=1e-4) if os.environ.get("GD_FLAT_ADAM", "1") != "0" else torch.optim.Adam(train, lr=1e-4)
     g = torch.Generator(device=device).manual_seed(7 + rk)
     gd.set_text_embeds(torch.randn(1, 77, 1024, device=device, generator=g),
                        torch.randn(1, 77, 1024, device=device, generator=g))
@@ -311,15 +411,13 @@ def launch_ranks_if_needed(args):
     set) this is a no-op; in every mode ``check_world`` then refuses a world that is not ``--gpus``."""
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous on a port IT binds (port 0) -- no bind-then-close window in which
+    # another process could take a pre-selected port; --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     sys.stderr.flush()
     os.execve(sys.executable, cmd, env)
@@ -431,7 +529,7 @@ def main():
                                             "use_hip_graphs": not args.no_graphs, "fp8_unet": bool(args.fp8)},
                                            device=device)
         prompt = PromptEmbeddings.random(device)
-    loop = SDSLoop(gaussians, guidance, prompt, bg)
+    loop = SDSLoop(gaussians, guidance, prompt, bg, batch_invariant=bool(args.batch_invariant))
     if args.per_view_raster:
         from garmentdreamer_amd.gaussian_renderer import render
 
@@ -465,16 +563,19 @@ def main():
         t = torch.randint(20, 981, (V,), device=device, generator=gen)
         loop.step(batch, noise=noise, timesteps=t, vae_noise=vae_noise)
 
+    from garmentdreamer_amd import nn_ops
+    nn_ops.library_fallbacks(reset=True)       # counted over warm-up (where the graphs are captured) AND the timed region
     for s in range(args.warmup):
         one_step(s)
     torch.cuda.synchronize()
     _native.profile_reset()
     _native.profile_enable(True)
-    from garmentdreamer_amd import nn_ops
     if not args.raster_only:
         nn_ops.conv_profile(enable=True, reset=True)
+    tele = Telemetry(device.index)
     gdist.barrier()
     torch.cuda.synchronize()
+    tele.start()
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step(args.warmup + s)
@@ -482,6 +583,8 @@ def main():
     gdist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    telemetry = tele.stop()
+    fallbacks = nn_ops.library_fallbacks()
     _native.profile_enable(False)
     prof = _native.profile_read()
     conv_ms, conv_n, conv_flops = nn_ops.conv_profile(enable=False) if not args.raster_only else (0.0, 0, 0.0)
@@ -552,6 +655,8 @@ def main():
         alg_bytes = (16.0 + 40.0 + 40.0) * counts["num_rendered"] + 20.0 * V_ * args.res * args.res
         roofline = {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                    "measured_issue_roof_tflops": MEASURED_PACKED_FP32_TFLOPS,
+                    "frac_vs_measured_issue_roof": ach / MEASURED_PACKED_FP32_TFLOPS,
                     "kernel": "render_backward_block_kernel", "avg_launch_us": avg_s * 1e6, "launches": bwd_n,
                     "flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": alg_bytes,
                     "note": ("fp32 VALU roof: 157.3 TF/s = the datasheet figure, which needs PACKED fp32 (v_pk_fma_f32) in "
@@ -586,11 +691,31 @@ def main():
                         roofline_conv["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in fam.values()) / n
                         roofline_conv["traffic_per_kernel"] = {k: v["hbm_bytes_per_launch"] for k, v in fam.items()}
                         roofline_conv["traffic_source"] = rel + " (launch-weighted mean over the family)"
+                        # matrix-pipe utilisation and HBM GB/s against chip peak (north_star), per kernel and time-weighted
+                        # over the family: mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) --
+                        # 0.976 on an MFMA-only stream (profiles/r05_mfma_util_check.txt) --, hbm_gbps = counter bytes /
+                        # duration, clock = GUI cycles per XCD / duration; all three under the profiler (tools/pmc_all.sh)
+                        w = {k: v["launches_sampled"] * v.get("avg_duration_us_profiled", 0.0) for k, v in fam.items()}
+                        tw = sum(w.values())
+                        if tw > 0 and all("mfma_util" in v and "hbm_gbps" in v for v in fam.values()):
+                            roofline_conv["mfma_util"] = sum(v["mfma_util"] * w[k] for k, v in fam.items()) / tw
+                            roofline_conv["hbm_gbps"] = sum(v["hbm_gbps"] * w[k] for k, v in fam.items()) / tw
+                            roofline_conv["hbm_frac_of_8TBps"] = roofline_conv["hbm_gbps"] / 8000.0
+                            roofline_conv["clock_ghz_profiled"] = sum(v.get("clock_ghz", 0.0) * w[k] for k, v in fam.items()) / tw
+                            roofline_conv["util_per_kernel"] = {k: {"mfma_util": round(v["mfma_util"], 4),
+                                                                    "hbm_gbps": round(v["hbm_gbps"], 1),
+                                                                    "clock_ghz": round(v.get("clock_ghz", 0.0), 3)}
+                                                                for k, v in fam.items()}
                 if roofline is not None:
                     for k, v in ks.items():
                         if k.startswith("render_backward") and "hbm_bytes_per_launch" in v:
                             roofline["traffic"] = v["hbm_bytes_per_launch"]
                             roofline["traffic_source"] = rel
+                            for key in ("hbm_gbps", "clock_ghz", "mfma_util"):
+                                if key in v:
+                                    roofline[key if key != "clock_ghz" else "clock_ghz_profiled"] = v[key]
+                            if "hbm_gbps" in v:
+                                roofline["hbm_frac_of_8TBps"] = v["hbm_gbps"] / 8000.0
                             if v.get("SQ_INSTS_VALU") and v.get("SQ_BUSY_CYCLES"):
                                 # SIMD-cycles of the launch: SQ_BUSY_CYCLES is summed over the 32 shader engines; 1024 SIMDs
                                 simd_cycles = v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
@@ -634,6 +759,9 @@ def main():
                        "fp8_unet_sites": (guidance.unet.fp8.sites_run if guidance is not None and
                                           getattr(guidance.unet, "fp8", None) is not None else 0),
                        "kernels_per_step": kernels_per_step,
+                       "batch_invariant": bool(loop.batch_invariant),
+                       "library_fallbacks": sum(fallbacks.values()),
+                       "library_fallback_sites": fallbacks or None,
                        "library_override": {"nn": args.nn_lib, "raster": args.raster_lib}
                        if (args.nn_lib or args.raster_lib) else None},
             "roofline": roofline_conv if roofline_conv is not None else roofline,
@@ -641,7 +769,11 @@ def main():
             "raster_kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
             "pair_counts_rank0": counts,
             "health": {"params_finite": params_finite, "visible_after_timed_steps": counts["visible"]},
+            "telemetry": telemetry,
         }
+        for r in (line["roofline"], line["roofline_raster_bwd"]):
+            if r is not None:
+                r["clock_mhz_mean"], r["power_w_mean"] = telemetry.get("clock_mhz_mean"), telemetry.get("power_w_mean")
         if not args.raster_only:
             dense_tflop = V * (2 * UNET_TFLOP_PER_SAMPLE + 2 * VAE_TFLOP_PER_IMAGE)
             raster_ms = sum(v[0] for v in prof.values()) / max(args.steps, 1)

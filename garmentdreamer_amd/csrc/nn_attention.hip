@@ -590,11 +590,13 @@ int gd_nn_attention_d64_backward(void* stream, const void* q, const void* k, con
     hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((rows8 + 255) / 256)), dim3(256), 0, s, (const uint16_t*)o,
                        (const uint16_t*)dout, dsum, B, S, H, o_bs, o_rs, do_bs, do_rs);
     const float c = scale * 1.4426950408889634f;
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
+    static bool attr_set[16] = {false};      // per device, as every other launcher of the library keys it
+    if (!attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_d64_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * kTile);
         (void)hipFuncSetAttribute((const void*)attn_bwd_d64_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * kTile);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     // (64 row-side elements per workgroup -- the two-wave instantiation -- measured SLOWER on the one-latent grids it was meant
     // for: 309 against 260 us at S = 4096, 5 heads, tools/attn_bwd_bench.py; four waves always)

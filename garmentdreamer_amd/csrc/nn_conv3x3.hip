@@ -987,7 +987,9 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
 
 #include "nn_conv_wino.h"
 #include "nn_conv_wide.h"
+#ifdef GD_NN_EXPERIMENTAL_REGW   // -Itools/experimental: the filter-bank-in-registers experiment, built by tools/ only
 #include "nn_conv_regw.h"
+#endif
 
 // out = bf16( sum_s partial[s] + bias + residual ): second half of the split-K path, 4 channels per thread, splits
 // added in index order (deterministic).  Partials are tile images in the convolution's MFMA fragment order (coalesced
@@ -1381,6 +1383,9 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
     if (variant == 2) GD_LAUNCH(256, 256, 2, 4);
     else if (variant == 4) GD_LAUNCH(32, 256, 1, 4);   // 32 channels x 256 pixels, 4 waves: 1/4 of the padded MFMA work
     else if (variant == 1) GD_LAUNCH(128, 256, 2, 4);
+    else if (variant == 5) GD_LAUNCH(64, 128, 2, 2);   // small-M layers: finer tiles instead of split-K + a reduce launch
+    else if (variant == 6) GD_LAUNCH(64, 64, 2, 2);
+    else if (variant == 7) GD_LAUNCH(128, 64, 2, 2);
     else GD_LAUNCH(128, 128, 2, 2);
 #undef GD_LAUNCH
     if (split > 1) {
@@ -1786,77 +1791,9 @@ int gd_nn_conv3x3_wide_gn_forward(void* stream, const void* x, const float* mean
                        Cin, Cout, stat_part);
 }
 
-// ---- 128 -> 128 channels with the filter bank resident in registers (nn_conv_regw.h)
-size_t gd_nn_conv3x3_regw_weights_bytes(void) { return (size_t)4 * 72 * 64 * 16; }
-
-int gd_nn_conv3x3_regw_weights(void* stream, const void* weight, void* u)
-{
-    if (!weight || !u) return fail(GD_NN_ERR_INVALID_ARG, "regw_weights: null pointer");
-    hipLaunchKernelGGL(conv3x3_regw_weights_kernel, dim3(72), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)weight,
-                       (uint16_t*)u);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
-    return GD_NN_OK;
-}
-
-int gd_nn_conv3x3_regw_supported(int N, int H, int W, int Cin, int Cout)
-{
-    if (N <= 0 || Cin != 128 || Cout != 128 || H < 16 || W < 32 || (H & 15) || (W & 31)) return 0;
-    if ((double)N * H * W * 256.0 >= 2147483648.0) return 0;
-    return 1;
-}
-
-int gd_nn_conv3x3_regw_forward(void* stream, const void* x, const void* u, const void* bias, int bias_img_stride,
-                               const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part)
-{
-    if (!x || !u || !y) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
-    if (residual) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_regw: no residual form");
-    if (!gd_nn_conv3x3_regw_supported(N, H, W, Cin, Cout))
-        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_regw: need Cin = Cout = 128, H % 16 == 0, W % 32 == 0, tensors < 2 GiB");
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
-    hipStream_t s = (hipStream_t)stream;
-    // column strips of 32 pixels, cut into vertical segments (multiples of 16 rows) until the grid fills the chip twice
-    const int strips = W / 32;
-    int segs = (512 + N * strips - 1) / (N * strips);
-    if (segs > H / 16) segs = H / 16;
-    if (segs < 1) segs = 1;
-    int seg_rows = ((H + segs - 1) / segs + 15) & ~15;
-    segs = (H + seg_rows - 1) / seg_rows;
-    const int nwg = N * strips * segs;
-    const int64_t M = (int64_t)N * H * W;
-    hipEvent_t ea = nullptr, eb = nullptr;
-    if (g_cprof.on) {
-        std::lock_guard<std::mutex> lk(g_cprof.mu);
-        ea = g_cprof.get(); eb = g_cprof.get();
-        if (ea && eb) (void)hipEventRecord(ea, s);
-    }
-#define GD_LAUNCH_RW(STAT_)                                                                                        \
-    do {                                                                                                           \
-        auto kern = conv3x3_regw_kernel<STAT_>;                                                                    \
-        static bool attr_set[16] = {false};                                                                        \
-        if (!attr_set[dev]) {                                                                                      \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kRegwLds);    \
-            attr_set[dev] = true;                                                                                  \
-        }                                                                                                          \
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), kRegwLds, s, (const uint16_t*)x, (const uint16_t*)u,        \
-                           (const uint16_t*)bias, bias_img_stride, (uint16_t*)y, N, H, W, strips, segs, seg_rows,  \
-                           nwg, stat_part);                                                                        \
-    } while (0)
-    if (stat_part) GD_LAUNCH_RW(true); else GD_LAUNCH_RW(false);
-#undef GD_LAUNCH_RW
-    if (ea && eb) {
-        (void)hipEventRecord(eb, s);
-        std::lock_guard<std::mutex> lk(g_cprof.mu);
-        g_cprof.pending.push_back({ea, eb});
-        g_cprof.total_flops += 2.0 * (double)M * Cout * 9.0 * Cin;
-        g_cprof.total_bytes += 2.0 * ((double)M * Cin + 9.0 * Cin * Cout + (double)M * Cout +
-                                      (residual ? (double)M * Cout : 0.0));
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
-    return GD_NN_OK;
-}
+#ifdef GD_NN_EXPERIMENTAL_REGW   // tools/regw_variants.sh only: a measured negative, not in libgd_nn.so
+#include "nn_conv_regw_api.h"
+#endif
 
 // persistent workgroups of the matrix-core first convolution: two per CU (8 waves of ~170 VGPRs), fewer for small inputs
 static int first_mfma_grid(int N, int H, int W)

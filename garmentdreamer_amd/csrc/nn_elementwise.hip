@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const bf16x8* _
 // write once -- torch's softmax backward runs a separate `grad * output` pass over the matrix first (aten::mul, 142 us) and then
 // its row kernel (137 us).  fp32 arithmetic, exp through v_exp_f32 on (x - max) log2(e).
 template <int R>
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int64_t rows, int L8)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const u32x4* x, u32x4* y, int64_t rows, int L8)   // no __restrict__: called in place (y == x)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const u32x4* __restri
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void softmax_rows_backward_kernel(const u32x4* __restrict__ p, const u32x4* __restrict__ dp,
-                                                                    u32x4* __restrict__ ds, int64_t rows, int L8)
+__global__ __launch_bounds__(256) void softmax_rows_backward_kernel(const u32x4* __restrict__ p, const u32x4* dp,
+                                                                    u32x4* ds, int64_t rows, int L8)   // ds may be dp (in place)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -15,10 +15,15 @@ update rule, same double-precision bias-correction scalars as torch's) and ``zer
 
 Semantics: ``.grad`` accumulates over backward passes until ``zero_grad()``, as in torch.  One difference, stated:
 ``torch.optim.Adam`` skips a parameter whose ``.grad`` is None (no moment decay, its own step count); a flat-set
-parameter always has a gradient here (zeros if nothing wrote one), so its moments decay on every step.  The flat set
-is the fp32 GPU parameters -- the adapters, which receive a gradient on every step; parameters that are not fp32
-(camera / shading embeddings in the base dtype) or that the caller lists in ``exclude`` are left to a plain
-``torch.optim.Adam`` over just those few tensors, with torch's skipping.
+parameter always has a gradient here (zeros if nothing wrote one), so its moments decay on every step.  That is only
+the reference's behaviour for tensors that DO receive a gradient on every step, so the flat set is opt-in: the caller
+names it (``flat=`` -- the rank-4 adapters, every one of which is on the path of every UNet call; ``for_lora_unet``
+picks exactly those).  Everything else -- the camera MLP, the three shading embeddings of which one is used per step
+(lora_unet.py:632-645), anything not fp32 or not on the GPU -- is stepped by a plain ``torch.optim.Adam`` over just
+those few tensors, with torch's skipping and per-parameter step counts.
+
+``param_groups`` is ONE list holding ONE dict, created once: ``for g in opt.param_groups: g["lr"] = x`` changes the
+learning rate of both halves, as with a torch optimizer; ``step()`` reads lr / betas / eps from that dict.
 """
 from __future__ import annotations
 
@@ -32,17 +37,25 @@ from . import _native
 
 class FlatAdam:
     def __init__(self, params: Iterable[torch.Tensor], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 exclude: Iterable[torch.Tensor] = (), check_views: bool = True):
-        """Re-seats every fp32 GPU parameter (not in ``exclude``) in the flat buffer NOW: construct it before any hipGraph
-        that reads those parameters is captured (a graph keeps the addresses it was captured with)."""
+                 flat: Optional[Iterable[torch.Tensor]] = None, exclude: Iterable[torch.Tensor] = (),
+                 check_views: bool = True):
+        """``flat``: the parameters (a subset of ``params``) that receive a gradient on EVERY step and may therefore live in
+        the flat buffer -- those among them that are fp32 GPU tensors and not in ``exclude`` are re-seated NOW: construct the
+        optimizer before any hipGraph that reads them is captured (a graph keeps the addresses it was captured with).
+        ``flat=None``: nothing is re-seated, every parameter is stepped by ``torch.optim.Adam``."""
         self.params: List[torch.Tensor] = [p for p in params]
         if not self.params:
             raise ValueError("FlatAdam: empty parameter list")
-        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self._group = {"params": self.params, "lr": float(lr), "betas": (float(betas[0]), float(betas[1])), "eps": float(eps)}
+        self._groups = [self._group]
         self.step_count = 0
         self._check_views = bool(check_views)    # a Python walk over the flat set per step (~50 us for 256 tensors)
         skip = {id(p) for p in exclude}
-        flat = [p for p in self.params if p.is_cuda and p.dtype == torch.float32 and id(p) not in skip]
+        listed = {id(p) for p in self.params}
+        want = [] if flat is None else [p for p in flat]
+        if any(id(p) not in listed for p in want):
+            raise ValueError("FlatAdam: `flat` must be a subset of `params`")
+        flat = [p for p in want if p.is_cuda and p.dtype == torch.float32 and id(p) not in skip]
         ids = {id(p) for p in flat}
         rest = [p for p in self.params if id(p) not in ids]
         self._flat_set = flat
@@ -80,9 +93,33 @@ class FlatAdam:
         if self._rest is not None:
             self._rest.zero_grad(set_to_none=set_to_none)
 
+    @classmethod
+    def for_lora_unet(cls, unet, params: Iterable[torch.Tensor], **kw):
+        """The optimizer of ``sd21.LoraUNet2DConditionModel``: its rank-4 adapters (``unet.lora_layers``, on the path of every
+        UNet call) in the flat set, the camera MLP and the shading embeddings under torch's Adam."""
+        return cls(params, flat=list(unet.lora_layers.parameters()), **kw)
+
     @property
     def param_groups(self):
-        return [{"params": self.params, "lr": self.lr, "betas": self.betas, "eps": self.eps}]
+        return self._groups
+
+    # lr / betas / eps live in the one group dict (what a scheduler or ``g["lr"] = x`` edits)
+    @property
+    def lr(self) -> float:
+        return float(self._group["lr"])
+
+    @lr.setter
+    def lr(self, v: float):
+        self._group["lr"] = float(v)
+
+    @property
+    def betas(self):
+        b = self._group["betas"]
+        return float(b[0]), float(b[1])
+
+    @property
+    def eps(self) -> float:
+        return float(self._group["eps"])
 
     @torch.no_grad()
     def step(self):
@@ -104,7 +141,7 @@ class FlatAdam:
                     self.betas[0], self.betas[1], self.eps, self.step_count), "gd_scene_adam_step")
         if self._rest is not None:
             for grp in self._rest.param_groups:
-                grp["lr"] = self.lr
+                grp["lr"], grp["betas"], grp["eps"] = self.lr, self.betas, self.eps
             self._rest.step()
 
     @property

@@ -68,6 +68,7 @@ def _conv3(conv: nn.Conv2d, x, image_bias=None, residual=None):
             y = conv3x3(x, conv.weight, None, None) + (bias[:, :, None, None] if bias.dim() == 2 else bias[None, :, None, None])
             return y if residual is None else y + residual
         return conv3x3(x, conv.weight, bias, residual)
+    nn_ops._note_fallback("sd21._conv3", x, "needs frozen bf16 channels_last weights, stride 1, pad 1, Cin % 64 == 0")
     y = F.conv2d(x, conv.weight, None if image_bias is not None else conv.bias, conv.stride, conv.padding)
     if image_bias is not None:
         y = y + image_bias[:, :, None, None]
@@ -401,6 +402,7 @@ class Downsample2D(nn.Module):
         if conv3x3_s2_supported(x, self.conv.weight):
             # stride-2 MFMA kernel; the VAE encoder's asymmetric pad (0,1,0,1) is part of its tap geometry
             return conv3x3_s2(x, self.conv.weight, self.conv.bias, self.padding)
+        nn_ops._note_fallback("sd21.Downsample2D", x, "needs frozen bf16 weights with Cin % 64 == 0 and Cout % 64 == 0")
         if self.padding == 0:  # VAE encoder: asymmetric pad (0,1,0,1)
             x = F.pad(x, (0, 1, 0, 1))
         return self.conv(x)
@@ -809,6 +811,7 @@ class _QuantConv(nn.Conv2d):
     def forward(self, x):
         if nn_ops.conv1x1_c8_supported(x, self.weight, self.bias):
             return nn_ops.conv1x1_c8(x, self.weight, self.bias)
+        nn_ops._note_fallback("sd21._QuantConv", x, "needs frozen contiguous bf16 8 -> 8 weights and a 16-byte aligned tensor")
         return super().forward(x)
 
 

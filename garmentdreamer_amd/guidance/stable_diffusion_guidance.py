@@ -161,6 +161,15 @@ class StableDiffusionGuidance(nn.Module):
                 self._graphs_failed(e)
         return self.unet(x, tt, encoder_hidden_states=ctx).to(input_dtype)
 
+    def may_capture(self, batch_size: int) -> bool:
+        """True while a call on `batch_size` images may still CAPTURE a hipGraph (the caller then keeps no collective of its
+        process in flight across it): graphs are on and the UNet / VAE graph of that batch shape does not exist yet."""
+        if not self.cfg.use_hip_graphs:
+            return False
+        have_u = any(k[0][0] in (2 * batch_size, 4 * batch_size) for k in self._unet_graphs)
+        have_v = any(k[0] == batch_size for k in self._vae_graphs)
+        return not (have_u and have_v)
+
     def _graphs_failed(self, err):
         """hipGraph capture is an optimisation: if it cannot be set up, say so once and continue with eager launches."""
         import warnings
@@ -394,9 +403,11 @@ class StableDiffusionGuidance(nn.Module):
         """Guided noise prediction of ONE timestep for the preview sampler (:452-501)."""
         batch_size = latents_noisy.shape[0]
         reps = 4 if use_perp_neg else 2
-        noise_pred = self.forward_unet(torch.cat([latents_noisy] * reps, dim=0),
-                                       torch.cat([t.reshape(1)] * reps).to(self.device),
-                                       encoder_hidden_states=text_embeddings)
+        from .. import nn_ops
+        with nn_ops.route_batch(reps, reps * batch_size):     # (read under batch-invariant kernel selection only)
+            noise_pred = self.forward_unet(torch.cat([latents_noisy] * reps, dim=0),
+                                           torch.cat([t.reshape(1)] * reps).to(self.device),
+                                           encoder_hidden_states=text_embeddings)
         if use_perp_neg:
             noise_pred_text = noise_pred[:batch_size]
             noise_pred_uncond = noise_pred[batch_size:batch_size * 2]

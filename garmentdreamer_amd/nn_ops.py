@@ -61,10 +61,6 @@ SIGNATURES = {
     "gd_nn_conv3x3_wino_weights_bytes": (C.c_size_t, [_i, _i]),
     "gd_nn_conv3x3_wino_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_conv3x3_wino_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "gd_nn_conv3x3_regw_supported": (_i, [_i, _i, _i, _i, _i]),
-    "gd_nn_conv3x3_regw_weights": (_i, [_vp, _vp, _vp]),
-    "gd_nn_conv3x3_regw_weights_bytes": (C.c_size_t, []),
-    "gd_nn_conv3x3_regw_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gd_nn_conv3x3_wide_supported": (_i, [_i, _i, _i, _i, _i]),
     "gd_nn_conv3x3_wide_weights": (_i, [_vp, _vp, _vp, _i, _i]),
     "gd_nn_conv3x3_wide_weights_bytes": (C.c_size_t, [_i, _i]),
@@ -172,6 +168,39 @@ def _gn_workspace(x, N, groups):
 def reset_workspaces():
     """Drop the cached workspaces (after an aborted hipGraph capture may have left one mid-update)."""
     _gn_ws_cache.clear()
+
+
+# ---------------------------------------------------------------------------------------------
+# library fallbacks: a bf16 GPU tensor that misses an own kernel's shape rules goes to PyTorch's op (MIOpen / aten).  That
+# is what the fp32 reference runs of the tests need and what an odd shape deserves, but on the step's tensors it would put
+# the library back into the iteration without anyone noticing -- so every such call is counted, and raises under strict mode.
+# ---------------------------------------------------------------------------------------------
+_FALLBACKS = {}
+_STRICT = False
+
+
+def set_strict_library(on: bool) -> None:
+    """``True``: a bf16 GPU tensor falling back to a PyTorch library op raises instead of being counted."""
+    global _STRICT
+    _STRICT = bool(on)
+
+
+def library_fallbacks(reset: bool = False) -> dict:
+    """{"op: reason": calls} of the bf16-GPU calls that ran on a PyTorch library op since the last reset (bench.py puts the
+    total in its line: 0 on the benchmark's shapes)."""
+    out = dict(_FALLBACKS)
+    if reset:
+        _FALLBACKS.clear()
+    return out
+
+
+def _note_fallback(op: str, x, why: str) -> None:
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.bfloat16):
+        return          # CPU / fp32 reference runs: the PyTorch op IS the intended path
+    key = f"{op}: {why}"
+    if _STRICT:
+        raise RuntimeError(f"nn_ops strict mode: {key} on a bf16 GPU tensor of shape {tuple(x.shape)} would run on the PyTorch library op")
+    _FALLBACKS[key] = _FALLBACKS.get(key, 0) + 1
 
 
 def _is_nhwc_bf16(x):
@@ -295,6 +324,7 @@ def group_norm_silu(x, weight, bias, groups: int, eps: float, silu: bool = True)
                 return _gn_fused_small(x, weight, bias, groups, eps, silu)
             return _GroupNormSiLU.apply(x, weight, bias, groups, eps, silu)
         # fp32 GPU runs (parity checks of the bf16 path) use torch's ops
+        _note_fallback("group_norm_silu", x, "needs a 4-D tensor with C % 8 == 0")
     y = F.group_norm(x, groups, weight, bias, eps)
     return F.silu(y) if silu else y
 
@@ -372,7 +402,7 @@ def route_rows(rows):
     M, K = rows.shape
     G, B = _ROUTE_BATCH if _ROUTE_BATCH is not None else (1, 0)
     if B <= 0 or B % G or M % B:
-        G, B = 1, 1                      # unknown structure: this rank's rows first, zero rows after them
+        G, B = 1, 1                      # unknown structure: this rank's M rows as block `rank` of k blocks, zeros elsewhere
     c, T = B // G, M // B
     padded = rows.new_zeros((G, c, k, T, K))
     padded[:, :, r] = rows.view(G, c, T, K)
@@ -476,37 +506,6 @@ def _wino_launch(x, w_khwc, bias, residual, out_channels, stat_part=None):
                                            None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
                                            out_channels, None if stat_part is None else stat_part.data_ptr())
     _check(ret, "gd_nn_conv3x3_wino_forward", "gd_nn_conv_last_error")
-    return y
-
-
-def _regw(weight):
-    """Cached re-packing of a frozen 128 -> 128 conv weight as the register fragments of csrc/nn_conv_regw.h."""
-    u = getattr(weight, "_gd_regw", None)
-    key = (weight.data_ptr(), weight._version)
-    if u is None or u.device != weight.device or getattr(weight, "_gd_regw_key", None) != key:
-        u = torch.empty(lib().gd_nn_conv3x3_regw_weights_bytes() // 2, dtype=torch.bfloat16, device=weight.device)
-        with torch.cuda.device(weight.device):
-            ret = lib().gd_nn_conv3x3_regw_weights(torch.cuda.current_stream(weight.device).cuda_stream,
-                                                   weight.data_ptr(), u.data_ptr())
-        _check(ret, "gd_nn_conv3x3_regw_weights", "gd_nn_conv_last_error")
-        weight._gd_regw, weight._gd_regw_key = u, key
-    return u
-
-
-def _regw_launch(x, w_khwc, bias, residual, out_channels, stat_part=None):
-    """3x3/s1/p1 convolution, 128 -> 128 channels, filter bank resident in registers (csrc/nn_conv_regw.h).  Not on the
-    default route (parity with the wide tile); tools/regw_conv_bench.py and the GPU tests call it."""
-    N, Cin, H, W = x.shape
-    L = lib()
-    y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    bias, stride = _bias_and_stride(bias)
-    u = _regw(w_khwc)
-    with torch.cuda.device(x.device):
-        ret = L.gd_nn_conv3x3_regw_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), u.data_ptr(),
-                                           None if bias is None else bias.data_ptr(), stride,
-                                           None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
-                                           out_channels, None if stat_part is None else stat_part.data_ptr())
-    _check(ret, "gd_nn_conv3x3_regw_forward", "gd_nn_conv_last_error")
     return y
 
 
@@ -661,6 +660,7 @@ class _ConvSmallCin(torch.autograd.Function):
             if mr_next is not None:
                 ctx.mark_non_differentiable(mr_next)
             return y, mr_next
+        _note_fallback("conv3x3_small_cin", x, "needs Cout % 8 == 0, 36 * Cin * Cout <= 65536 and a bf16 bias")
         with torch.no_grad():
             return F.conv2d(x, weight, bias, padding=1), None
 
@@ -697,6 +697,7 @@ def conv3x3_small_cin(x, weight, bias, next_norm=None):
         if mr_next is not None:
             y._gd_gn_stats = (mr_next, nn_[0], nn_[1], y._version)
         return y
+    _note_fallback("conv3x3_small_cin", x, "needs frozen bf16 weights with Cin <= 4 and Cout % 64 == 0")
     return F.conv2d(x, weight, bias, padding=1)
 
 
@@ -706,6 +707,7 @@ def conv1x1(x, weight, bias):
     if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
         y = F.linear(x.permute(0, 2, 3, 1), weight.flatten(1), bias)
         return y.permute(0, 3, 1, 2)
+    _note_fallback("conv1x1", x, "needs a channels_last (NHWC) tensor")
     return F.conv2d(x, weight, bias)
 
 
@@ -726,6 +728,7 @@ def conv3x3(x, weight, bias=None, residual=None):
         if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
             residual = residual.contiguous(memory_format=torch.channels_last)
         return _Conv3x3.apply(x, weight, bias, residual)
+    _note_fallback("conv3x3", x, "needs bf16 channels_last weights with Cin % 64 == 0 and Cout % 4 == 0")
     if bias is not None and bias.dim() == 2:
         y = F.conv2d(x, weight, None, padding=1) + bias[:, :, None, None]
     else:

@@ -43,9 +43,22 @@ class _RenderOut(dict):
             return v
         raise KeyError(key)
 
-    # the lazy key behaves like a stored one for every read path of a dict
+    # the lazy keys behave like stored ones for every read path of a dict
     def __contains__(self, key):
+        if key in ("depth_max", "radii_all") and dict.__contains__(self, "_pending_max"):
+            return True
         return key == "opacity" or dict.__contains__(self, key)
+
+    def finish(self):
+        """Wait for the pending [radii | depth maximum] collective of a sharded run, if any (a no-op otherwise): after
+        this the dict holds plain tensors only and can be copied, iterated or dropped without leaving work in flight."""
+        if dict.__contains__(self, "_pending_max"):
+            self["depth_max"]
+        return self
+
+    def copy(self):
+        self.finish()
+        return _RenderOut(dict.copy(self))
 
     def get(self, key, default=None):
         try:
@@ -54,19 +67,19 @@ class _RenderOut(dict):
             return default
 
     def keys(self):
-        self["opacity"]
+        self.finish()["opacity"]
         return dict.keys(self)
 
     def items(self):
-        self["opacity"]
+        self.finish()["opacity"]
         return dict.items(self)
 
     def values(self):
-        self["opacity"]
+        self.finish()["opacity"]
         return dict.values(self)
 
     def __iter__(self):
-        self["opacity"]
+        self.finish()["opacity"]
         return dict.__iter__(self)
 
 
@@ -76,10 +89,12 @@ class SDSLoop:
                  lr_scale: float = 1.0, fused_adam: Optional[bool] = None, densify: bool = True,
                  cameras_extent: float = 4.0, densify_seed: int = 0, batch_invariant: bool = False):
         self.gaussians = gaussians
-        if batch_invariant and gaussians.get_xyz.is_cuda:
+        self.batch_invariant = bool(batch_invariant and gaussians.get_xyz.is_cuda)
+        if self.batch_invariant:
             # sharded run that must reproduce the single-rank gradients as closely as bf16 allows: the guidance
             # kernels are selected for the whole camera batch (views per rank x world size), not for this rank's
-            # share (include/gd_nn.h gd_nn_conv_set_route_scale); costs a few % of step time on small shares
+            # share (include/gd_nn.h gd_nn_conv_set_route_scale); costs a few % of step time on small shares.
+            # Process-global routing state: close() (or dropping the loop) puts it back to 1
             from . import dist as gdist, nn_ops
             nn_ops.set_route_scale(gdist.world_size(), gdist.rank())
         self.guidance = guidance
@@ -120,8 +135,24 @@ class SDSLoop:
                                              lr_delay_mult=a.position_lr_delay_mult,
                                              max_steps=a.position_lr_max_steps)
 
+    def close(self):
+        """Undo the process-global kernel routing of ``batch_invariant=True`` (a later loop or guidance in the same process
+        would otherwise inherit the k-fold routing)."""
+        if getattr(self, "batch_invariant", False):
+            from . import nn_ops
+            nn_ops.set_route_scale(1, 0)
+            self.batch_invariant = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # -- forward (GaussianDreamer.forward, :180-219) --------------------------------------------
-    def render_views(self, batch: Dict):
+    def render_views(self, batch: Dict, finish: bool = True):
+        """``finish=False`` (step() only): in a sharded run the [radii | depth maximum] collective is left in flight and ends
+        when "depth_max" / "radii_all" / "opacity" is first read; every other caller gets a finished dict."""
         dev = self.gaussians.get_xyz.device
         c2w = batch["c2w_3dgs"]
         cams = [Camera(c2w[i], batch["fovy"][i], batch["height"], batch["width"], data_device="cpu")
@@ -135,16 +166,17 @@ class SDSLoop:
             # ONE asynchronous max over the ranks for [radii | depth maximum]; finished in step() after the guidance
             # forward, which it overlaps (dist.PendingMax)
             out["_pending_max"] = gdist.PendingMax(pkg["radii"].max(dim=0).values, local_max)
+            if finish:
+                out.finish()
         else:
             out["depth_max"] = local_max
         return out
 
-    def _guidance_graphs_ready(self) -> bool:
-        g = self.guidance
-        cfg = getattr(g, "cfg", None)
-        if cfg is None or not getattr(cfg, "use_hip_graphs", False):
-            return True                                   # eager launches: nothing is ever captured
-        return bool(getattr(g, "_unet_graphs", None)) and bool(getattr(g, "_vae_graphs", None))
+    def _guidance_may_capture(self, views: int) -> bool:
+        """Whether the next guidance call on `views` images may still capture a hipGraph (``guidance.may_capture``; a
+        guidance object without that method never captures)."""
+        fn = getattr(self.guidance, "may_capture", None)
+        return bool(fn(views)) if fn is not None else False
 
     # -- one iteration ----------------------------------------------------------------------------
     def step(self, batch: Dict, noise=None, timesteps=None, vae_noise=None) -> Dict:
@@ -160,12 +192,12 @@ class SDSLoop:
                     g["lr"] = self._xyz_lr(self.global_step)
         if self.global_step > 500:  # GaussianDreamer.py:233-234
             self.guidance.set_min_max_steps(min_step_percent=0.02, max_step_percent=0.55)
-        out = self.render_views(batch)
-        if not self._guidance_graphs_ready():
+        out = self.render_views(batch, finish=False)
+        if self._guidance_may_capture(out["comp_rgb"].shape[0]):
             # a call of the guidance that may still CAPTURE a hipGraph: no collective of this process is left in flight across a
             # capture (the process group's watchdog thread polls pending work with event queries); once the graphs exist the
             # [radii | depth maximum] collective overlaps their replays
-            out.get("depth_max")
+            out.finish()
         g_out = self.guidance(out["comp_rgb"], self.prompt_utils, batch["elevation"], batch["azimuth"],
                               batch["camera_distances"], rgb_as_latents=False, guidance_eval=False, noise=noise,
                               timesteps=timesteps, vae_noise=vae_noise)

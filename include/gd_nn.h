@@ -175,18 +175,6 @@ int gd_nn_conv3x3_wide_forward(void* stream, const void* x, const void* u, const
 int gd_nn_conv3x3_wide_gn_forward(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
                                   int groups, int apply_silu, const void* u, const void* bias, int bias_img_stride,
                                   const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
-/* The 128 -> 128-channel case with the WHOLE filter bank resident in registers (csrc/nn_conv_regw.h): eight waves hold
- * 32 output channels x 576 K each (144 registers), a workgroup walks down a 32-pixel column strip and fetches ONE new
- * input row per output row into an LDS ring; no filter traffic after the prologue.  u = gd_nn_conv3x3_regw_weights_bytes()
- * bytes ([8 waves][36 K steps][64 lanes][8], gd_nn_conv3x3_regw_weights; cached per frozen weight by the caller, dgrad =
- * the same kernel on the packing of the flipped weights).  Needs Cin = Cout = 128, H % 16 == 0, W % 32 == 0.  stat_part
- * as for the entry points above (same partial-sum rows); no GroupNorm-in-the-loader form and no residual (residual must be NULL).  Measured at parity with the
- * wide tile on the step's one shape and therefore NOT on the default route.  Replaces the same reference call. */
-int gd_nn_conv3x3_regw_supported(int N, int H, int W, int Cin, int Cout);
-size_t gd_nn_conv3x3_regw_weights_bytes(void);
-int gd_nn_conv3x3_regw_weights(void* stream, const void* weight, void* u);
-int gd_nn_conv3x3_regw_forward(void* stream, const void* x, const void* u, const void* bias, int bias_img_stride,
-                               const void* residual, void* y, int N, int H, int W, int Cin, int Cout, float* stat_part);
 /* ... and of the first convolution (gd_nn_conv3x3_first_forward below; Cout == 128 only, the VAE encoder's conv_in):
  * rows = gd_nn_conv3x3_first_stat_rows(N, H, W, Cin, Cout), 0 when that shape has no statistics path. */
 size_t gd_nn_conv3x3_first_stat_rows(int N, int H, int W, int Cin, int Cout);

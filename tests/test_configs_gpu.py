@@ -376,7 +376,7 @@ def test_config4_vsd_graphed_iteration_with_flat_adam_gradient_sinks():
     gd_e, _, train_e, q_e = _vsd_objects(kw_u, kw_v, torch.bfloat16, graphs=False)
     eager = [_vsd_step(gd_e, q_e, train_e, seed=sd) for sd in seeds]
     gd_g, _, train_g, q_g = _vsd_objects(kw_u, kw_v, torch.bfloat16, graphs=True)
-    opt = FlatAdam(train_g, lr=0.0)              # before any capture: it re-seats the adapters
+    opt = FlatAdam.for_lora_unet(q_g.unet, train_g, lr=0.0)              # before any capture: it re-seats the adapters
     flat = [p for p in train_g if hasattr(p, "_gd_grad_sink")]
     assert len(flat) >= 32 and all(p.grad is p._gd_grad_sink for p in flat)
     got = []

@@ -27,7 +27,7 @@ def test_flat_adam_leaves_cpu_and_non_fp32_parameters_to_torch_adam():
     g = torch.Generator().manual_seed(0)
     mine = [torch.nn.Parameter(torch.randn(4, 8, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g).to(torch.bfloat16))]
     ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
-    opt, ropt = FlatAdam(mine, lr=2e-3, betas=(0.8, 0.95), eps=1e-6), torch.optim.Adam(ref, lr=2e-3, betas=(0.8, 0.95), eps=1e-6)
+    opt, ropt = FlatAdam(mine, lr=2e-3, betas=(0.8, 0.95), eps=1e-6, flat=mine), torch.optim.Adam(ref, lr=2e-3, betas=(0.8, 0.95), eps=1e-6)
     assert opt.flat_grad is None and not any(hasattr(p, "_gd_grad_sink") for p in mine)
     assert opt.param_groups[0]["lr"] == 2e-3 and len(opt.param_groups[0]["params"]) == 2
     for it in range(4):
@@ -38,7 +38,8 @@ def test_flat_adam_leaves_cpu_and_non_fp32_parameters_to_torch_adam():
             gr = torch.randn(p.shape, generator=g).to(p.dtype)
             p.grad, q.grad = gr.clone(), gr.clone()
         if it == 2:
-            opt.lr = 5e-4
+            for grp in opt.param_groups:         # the torch idiom reaches the inner optimizer
+                grp["lr"] = 5e-4
             for grp in ropt.param_groups:
                 grp["lr"] = 5e-4
         opt.step()
@@ -47,3 +48,6 @@ def test_flat_adam_leaves_cpu_and_non_fp32_parameters_to_torch_adam():
     import pytest
     with pytest.raises(ValueError):
         FlatAdam([])
+    with pytest.raises(ValueError):              # `flat` names the always-written subset of `params`
+        FlatAdam(mine, flat=[torch.nn.Parameter(torch.zeros(3))])
+    assert FlatAdam(mine).flat_grad is None     # flat=None: nothing re-seated

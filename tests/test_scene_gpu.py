@@ -94,10 +94,13 @@ def test_flat_adam_over_many_small_tensors_matches_torch_adam():
     mine.append(torch.nn.Parameter(torch.randn(16, 8, device=DEV, generator=g).to(torch.bfloat16)))      # -> torch.optim.Adam
     sparse = torch.nn.Parameter(torch.randn(9, device=DEV, generator=g))                                    # excluded, never a gradient
     ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
-    opt = FlatAdam(mine + [sparse], lr=3e-3, exclude=[sparse])
+    unused = torch.nn.Parameter(torch.randn(12, device=DEV, generator=g))      # fp32, NOT named in `flat`: torch's Adam, skipped while .grad is None
+    opt = FlatAdam(mine + [sparse, unused], lr=3e-3, flat=mine + [sparse], exclude=[sparse])
     ropt = torch.optim.Adam(ref, lr=3e-3)
     assert all(p.data_ptr() % 256 == 0 and p.grad is p._gd_grad_sink for p in mine[:-1])    # re-seated, aligned views of one buffer
-    assert mine[-1].grad is None and not hasattr(sparse, "_gd_grad_sink")
+    assert mine[-1].grad is None and not hasattr(sparse, "_gd_grad_sink") and not hasattr(unused, "_gd_grad_sink")
+    unused0 = unused.detach().clone()
+    assert opt.param_groups is opt.param_groups        # ONE list of ONE dict: editing it is how the learning rate changes
     assert torch.equal(torch.cat([p.detach().flatten().float() for p in mine]), torch.cat([p.detach().flatten().float() for p in ref]))
     sparse0 = sparse.detach().clone()
     for it in range(6):
@@ -115,7 +118,9 @@ def test_flat_adam_over_many_small_tensors_matches_torch_adam():
                 p._gd_grad_sink.add_(gr / 2)     # what the LoRA backward kernels do, twice (accumulation)
                 p._gd_grad_sink.add_(gr / 2)
         if it == 4:
-            opt.lr = 1e-3
+            for grp in opt.param_groups:         # the torch idiom (it used to edit a throw-away dict)
+                grp["lr"] = 1e-3
+            assert opt.lr == 1e-3
             for grp in ropt.param_groups:
                 grp["lr"] = 1e-3
         opt.step()
@@ -124,7 +129,7 @@ def test_flat_adam_over_many_small_tensors_matches_torch_adam():
             tol = dict(rtol=2e-6, atol=2e-7) if p.dtype == torch.float32 else dict(rtol=0, atol=0)
             assert torch.allclose(p.detach().float(), q.detach().float(), **tol), (it, p.shape)
         assert all(p.grad is p._gd_grad_sink for p in mine[:-1])
-    assert torch.equal(sparse.detach(), sparse0)
+    assert torch.equal(sparse.detach(), sparse0) and torch.equal(unused.detach(), unused0)
     assert opt.flat_grad.numel() == sum((p.numel() + 63) // 64 * 64 for p in mine[:-1])
 
 

@@ -1,12 +1,59 @@
 #!/usr/bin/env python
-"""128 -> 128 3x3 convolution with the filter bank in registers (csrc/nn_conv_regw.h): parity against fp32 PyTorch and
-time against what the routing table picks today (wide tile).  usage: python tools/regw_conv_bench.py [N H W]"""
+"""128 -> 128 3x3 convolution with the filter bank in registers (tools/experimental/nn_conv_regw.h -- a measured negative,
+DESIGN.md 3.11; since round 5 NOT in libgd_nn.so: build it with `tools/regw_variants.sh regw:` and point GD_NN_LIB at
+ablate/libgd_nn_regw.so): parity against fp32 PyTorch and time against what the routing table picks today (wide tile).
+usage: GD_NN_LIB=ablate/libgd_nn_regw.so python tools/regw_conv_bench.py [N H W]"""
+import ctypes as C_
 import sys
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, ".")
 import tools.ablib  # noqa: F401,E402
 from garmentdreamer_amd import nn_ops  # noqa: E402
+
+_vp, _i = C_.c_void_p, C_.c_int
+for _name, (_res, _args) in {
+        "gd_nn_conv3x3_regw_supported": (_i, [_i, _i, _i, _i, _i]),
+        "gd_nn_conv3x3_regw_weights": (_i, [_vp, _vp, _vp]),
+        "gd_nn_conv3x3_regw_weights_bytes": (C_.c_size_t, []),
+        "gd_nn_conv3x3_regw_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp])}.items():
+    _fn = getattr(nn_ops.lib(), _name)          # AttributeError = the library was not built with -DGD_NN_EXPERIMENTAL_REGW
+    _fn.restype, _fn.argtypes = _res, _args
+
+
+def _regw(weight):
+    """Cached re-packing of a frozen 128 -> 128 conv weight as the register fragments of csrc/nn_conv_regw.h."""
+    u = getattr(weight, "_gd_regw", None)
+    key = (weight.data_ptr(), weight._version)
+    if u is None or u.device != weight.device or getattr(weight, "_gd_regw_key", None) != key:
+        u = torch.empty(nn_ops.lib().gd_nn_conv3x3_regw_weights_bytes() // 2, dtype=torch.bfloat16, device=weight.device)
+        with torch.cuda.device(weight.device):
+            ret = nn_ops.lib().gd_nn_conv3x3_regw_weights(torch.cuda.current_stream(weight.device).cuda_stream,
+                                                   weight.data_ptr(), u.data_ptr())
+        nn_ops._check(ret, "gd_nn_conv3x3_regw_weights", "gd_nn_conv_last_error")
+        weight._gd_regw, weight._gd_regw_key = u, key
+    return u
+
+
+def _regw_launch(x, w_khwc, bias, residual, out_channels, stat_part=None):
+    """3x3/s1/p1 convolution, 128 -> 128 channels, filter bank resident in registers (csrc/nn_conv_regw.h).  Not on the
+    default route (parity with the wide tile); tools/regw_conv_bench.py and the GPU tests call it."""
+    N, Cin, H, W = x.shape
+    L = nn_ops.lib()
+    y = torch.empty((N, out_channels, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    bias, stride = nn_ops._bias_and_stride(bias)
+    u = _regw(w_khwc)
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_conv3x3_regw_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), u.data_ptr(),
+                                           None if bias is None else bias.data_ptr(), stride,
+                                           None if residual is None else residual.data_ptr(), y.data_ptr(), N, H, W, Cin,
+                                           out_channels, None if stat_part is None else stat_part.data_ptr())
+    nn_ops._check(ret, "gd_nn_conv3x3_regw_forward", "gd_nn_conv_last_error")
+    return y
+
+
+
+nn_ops._regw_launch = _regw_launch
 
 N, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (8, 512, 512)
 dev = "cuda"

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Timing-only builds of libgd_nn.so that differ in nn_conv3x3.hip only (csrc/nn_conv_regw.h switches):
+# Timing-only builds of libgd_nn.so WITH the filter-bank-in-registers experiment (tools/experimental/nn_conv_regw.h, not in
+# the product library since round 5) that differ in nn_conv3x3.hip only:
 #   tools/regw_variants.sh "name:-DGD_REGW_ABLATE=1" ...  -> ablate/libgd_nn_<name>.so  (run with GD_NN_LIB=..., tools/ablib.py)
 cd $(dirname $0)/..
 mkdir -p ablate
@@ -14,7 +15,7 @@ objs = []
 for src, extra in _build_nn.NN_SOURCES:
     if src == "nn_conv3x3.hip":
         o = f"ablate/{name}_nn_conv3x3.o"
-        subprocess.check_call([_build._hipcc()] + _build.COMMON + extra + flags + ["-Wno-unused-variable", "-c", os.path.join(_build.CSRC, src), "-o", o])
+        subprocess.check_call([_build._hipcc()] + _build.COMMON + extra + flags + ["-DGD_NN_EXPERIMENTAL_REGW", "-Itools/experimental", "-Wno-unused-variable", "-c", os.path.join(_build.CSRC, src), "-o", o])
     else:
         o = os.path.join(_build.CSRC, os.path.splitext(src)[0] + ".o")
     objs.append(o)
