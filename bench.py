@@ -190,6 +190,10 @@ def parse():
                     help="six nn.Parameters + torch.optim.Adam(fused) instead of the flat-buffer GaussianModel")
     ap.add_argument("--nn-lib", default=None, help="A/B timing: another build of libgd_nn.so (recorded in the line's config)")
     ap.add_argument("--raster-lib", default=None, help="A/B timing: another build of libgd_raster.so (recorded likewise)")
+    ap.add_argument("--host-sync-raster", action="store_true",
+                    help="A/B: the rasterizer forward pass reads its instance count back to the host every iteration (the "
+                         "reference's one stream synchronisation, rasterizer_impl.cu:282) instead of the capacity-bounded "
+                         "sync-free form that is the default since round 5")
     ap.add_argument("--batch-invariant", action="store_true",
                     help="SDSLoop(batch_invariant=True): kernels (and bf16 summation orders) selected for the WHOLE camera batch "
                          "on every rank, so a sharded run reproduces the single-rank gradients per view bit for bit; off by "
@@ -529,7 +533,8 @@ def main():
                                             "use_hip_graphs": not args.no_graphs, "fp8_unet": bool(args.fp8)},
                                            device=device)
         prompt = PromptEmbeddings.random(device)
-    loop = SDSLoop(gaussians, guidance, prompt, bg, batch_invariant=bool(args.batch_invariant))
+    loop = SDSLoop(gaussians, guidance, prompt, bg, batch_invariant=bool(args.batch_invariant),
+                   sync_free=not args.host_sync_raster)
     if args.per_view_raster:
         from garmentdreamer_amd.gaussian_renderer import render
 
@@ -760,6 +765,10 @@ def main():
                                           getattr(guidance.unet, "fp8", None) is not None else 0),
                        "kernels_per_step": kernels_per_step,
                        "batch_invariant": bool(loop.batch_invariant),
+                       "raster_forward_host_syncs_in_timed_region": (
+                           0 if loop.capacity is not None and loop.capacity.calls_sync_free >= args.warmup + args.steps - 1
+                           else args.steps),
+                       "raster_instance_capacity": None if loop.capacity is None else loop.capacity.value,
                        "library_fallbacks": sum(fallbacks.values()),
                        "library_fallback_sites": fallbacks or None,
                        "library_override": {"nn": args.nn_lib, "raster": args.raster_lib}

@@ -58,6 +58,10 @@ SIGNATURES = {
                                   + [_i] * 3 + [_vp] + [_i] * 2
                                   + [_vp] * 5 + [_f] + [_vp] * 5
                                   + [_PF] * 2 + [_i] + [_vp] * 4 + [_i]),
+    "gd_raster_forward_batched_capacity": (_i, [_vp, _i] + [ALLOC_FN, _vp] * 3
+                                           + [_i] * 3 + [_vp] + [_i] * 2
+                                           + [_vp] * 5 + [_f] + [_vp] * 5
+                                           + [_PF] * 2 + [_i] + [_vp] * 4 + [_i] + [C.c_int64, _vp]),   # + capacity, count_dev
     "gd_raster_backward_batched": (_i, [_vp, _i] + [_i] * 4 + [_vp] + [_i] * 2
                                    + [_vp] * 5 + [_f] + [_vp] * 5
                                    + [_PF] * 2 + [_vp] * 5

@@ -74,6 +74,28 @@ __global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict
     }
 }
 
+// The backward pass's three transposes (K^T, Q^T, dO^T) in ONE launch: blockIdx.z = 3 b + which.
+struct VtJob { const uint16_t* src; uint16_t* dst; int S; int64_t bs; int rs; int len; };
+__global__ __launch_bounds__(256) void attn_vt3_kernel(VtJob j0, VtJob j1, VtJob j2, int H)
+{
+    __shared__ uint16_t tile[64][66];
+    const int which = blockIdx.z % 3, b = blockIdx.z / 3;
+    const VtJob j = which == 0 ? j0 : (which == 1 ? j1 : j2);
+    const int h = blockIdx.y, k0 = blockIdx.x * 64;
+    if (k0 >= j.S) return;                                  // (workgroup-uniform: the grid is sized for the longest tensor)
+    const uint16_t* src = j.src + b * j.bs + (int64_t)k0 * j.rs + h * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int key = i >> 6, d = i & 63;
+        tile[key][d] = k0 + key < j.len ? src[(int64_t)key * j.rs + d] : (uint16_t)0;
+    }
+    __syncthreads();
+    uint16_t* dst = j.dst + (((int64_t)b * H + h) * 64) * j.S + k0;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int d = i >> 6, pos = i & 63;
+        dst[(int64_t)d * j.S + pos] = tile[pos][d];
+    }
+}
+
 // WAVES = 4 or 8 wave64s per workgroup (32 query rows each).  Eight waves share every K / V^T tile: half the LDS-DMA
 // issue and LDS fill per query; four waves give twice the workgroups when the grid is small (one view per GPU).
 template <int WAVES>
@@ -81,7 +103,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
                                                            const uint16_t* __restrict__ vt, uint16_t* __restrict__ o, int S,
                                                            int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs,
                                                            int64_t o_bs, int o_rs, float c /* scale * log2(e) */, int kv_len,
-                                                           float* __restrict__ lse /* [B][H][S] natural-log sum-exp of the scaled scores, or NULL */)
+                                                           float* __restrict__ lse /* [B][H][S] natural-log sum-exp of the scaled scores, or NULL */,
+                                                           int64_t vt_bs /* elements between the V^T images of two batch entries */)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                 // 3 stages
@@ -106,7 +129,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(k + b * k_bs + h * kD), 0, (int)((uint32_t)kv_len * k_row_bytes), 0x00020000);   // rows >= kv_len read as 0
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(vt + (((int64_t)b * H + h) * kD) * Skv), 0, (int)((uint32_t)kD * v_row_bytes), 0x00020000);
+        (void*)(vt + b * vt_bs + ((int64_t)h * kD) * Skv), 0, (int)((uint32_t)kD * v_row_bytes), 0x00020000);
     uint32_t k_off[NP], v_off[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -317,8 +340,12 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_d64_kernel(
     const uint16_t* __restrict__ x1, int64_t x1_bs, int x1_rs, const uint16_t* __restrict__ x2, int64_t x2_bs, int x2_rs,
     const uint16_t* __restrict__ t1, const uint16_t* __restrict__ t2, const float* __restrict__ lse,
     const float* __restrict__ dsum, uint16_t* __restrict__ out1, int64_t o1_bs, int o1_rs, uint16_t* __restrict__ out2,
-    int64_t o2_bs, int o2_rs, int Sr, int Sc, int H, float c, float scale, int r_len, int c_len, int Sq)
+    int64_t o2_bs, int o2_rs, int Sr, int Sc, int H, float c, float scale, int r_len, int c_len, int Sq,
+    int tiles_per_chunk /* 0: one workgroup walks every streamed tile */, float* __restrict__ part /* fp32 partials of the chunks */)
 {
+    // Chunked form (MODE 1 with a handful of keys -- the cross-attention over 77 text tokens has ONE key block per head): the
+    // streamed (query) tiles are dealt to gridDim.z workgroups per key block, each leaves fp32 partial sums of dV^T / dK^T in
+    // `part` [z][b h][gridDim.x * 32 WAVES rows][2][64], attn_bwd_reduce_kernel adds the chunks up in index order.
     constexpr int NT = MODE == 0 ? 3 : 4;            // tiles per stage: x1, x2, t1 (, t2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -377,9 +404,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_d64_kernel(
 #pragma unroll
     for (int r = 0; r < 16; r++) g0[r] = g1[r] = e0[r] = e1[r] = 0.f;
 
-    const int ntiles = Sc / kTk;
-    issue(0, 0);
-    for (int t = 0; t < ntiles; t++) {
+    const int t_begin = tiles_per_chunk ? (int)blockIdx.z * tiles_per_chunk : 0;
+    const int ntiles = tiles_per_chunk ? min(Sc / kTk, t_begin + tiles_per_chunk) : Sc / kTk;
+    issue(t_begin & 1, t_begin);
+    for (int t = t_begin; t < ntiles; t++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < ntiles) issue((t + 1) & 1, t + 1);
@@ -460,6 +488,20 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_d64_kernel(
             }
         }
     }
+    if (MODE == 1 && part != nullptr) {
+        if (rrow < r_len) {
+            const size_t rows_pad = (size_t)gridDim.x * (32 * WAVES);
+            float* pp = part + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * rows_pad + rrow) * 2) * kD;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {     // rows d = (r & 3) + 8 (r >> 2) + 4 fh of each 32-d block, as below
+                *(float4*)(pp + 8 * g4 + 4 * fh) = make_float4(g0[4 * g4], g0[4 * g4 + 1], g0[4 * g4 + 2], g0[4 * g4 + 3]);
+                *(float4*)(pp + 32 + 8 * g4 + 4 * fh) = make_float4(g1[4 * g4], g1[4 * g4 + 1], g1[4 * g4 + 2], g1[4 * g4 + 3]);
+                *(float4*)(pp + kD + 8 * g4 + 4 * fh) = make_float4(e0[4 * g4], e0[4 * g4 + 1], e0[4 * g4 + 2], e0[4 * g4 + 3]);
+                *(float4*)(pp + kD + 32 + 8 * g4 + 4 * fh) = make_float4(e1[4 * g4], e1[4 * g4 + 1], e1[4 * g4 + 2], e1[4 * g4 + 3]);
+            }
+        }
+        return;
+    }
     if (rrow < r_len) {
         const float s1f = MODE == 0 ? scale : 1.0f;
         uint16_t* op = out1 + b * o1_bs + (int64_t)rrow * o1_rs + h * kD;
@@ -489,6 +531,43 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_d64_kernel(
     }
 }
 
+// dV = bf16(sum_z part[z][..][0][:]), dK = bf16(scale * sum_z part[z][..][1][:]): chunks added in index order (deterministic).
+// One thread = 4 channels of one (b, h, key) row of one of the two outputs.
+__global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* __restrict__ part, int chunks, int BH, int H,
+                                                              int rows_pad, int r_len, uint16_t* __restrict__ out1, int64_t o1_bs,
+                                                              int o1_rs, uint16_t* __restrict__ out2, int64_t o2_bs, int o2_rs,
+                                                              float scale)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int d4 = (int)(i & 15), which = (int)((i >> 4) & 1);
+    const int64_t row = i >> 5;                       // bh * r_len + key
+    if (row >= (int64_t)BH * r_len) return;
+    const int bh = (int)(row / r_len), key = (int)(row - (int64_t)bh * r_len);
+    const int b = bh / H, h = bh - b * H;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < chunks; z++) {
+        const float4 t = *(const float4*)(part + ((((size_t)z * BH + bh) * rows_pad + key) * 2 + which) * kD + 4 * d4);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    const float f = which ? scale : 1.0f;
+    uint16_t* op = which ? out2 + b * o2_bs + (int64_t)key * o2_rs + h * kD : out1 + b * o1_bs + (int64_t)key * o1_rs + h * kD;
+    uint2 o;
+    o.x = pack_bf16(acc.x * f, acc.y * f);
+    o.y = pack_bf16(acc.z * f, acc.w * f);
+    *(uint2*)(op + 4 * d4) = o;
+}
+
+// How many chunks of streamed (query) tiles the key-owning backward kernel is cut into: enough workgroups for the chip when
+// a head has only one or two key blocks, at least two 64-query tiles per chunk.
+static int bwd_key_chunks(int B, int S, int kv_len, int H)
+{
+    const int blocks = ((kv_len + 127) / 128) * B * H, tiles = S / kTk;
+    if (blocks >= 128 || tiles < 4) return 1;
+    int chunks = (256 + blocks - 1) / blocks;
+    if (chunks > tiles / 2) chunks = tiles / 2;
+    return chunks < 2 ? 1 : chunks;
+}
+
 }  // namespace
 
 extern "C" {
@@ -499,8 +578,9 @@ size_t gd_nn_attention_ws_bytes(int B, int Skv, int H) { return (size_t)B * H * 
 
 static int launch_attention(hipStream_t s, const void* q, const void* k, const void* vt, void* o, int B, int S, int Skv, int H,
                             int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t o_bs, int o_rs, float scale, int kv_len,
-                            float* lse = nullptr)
+                            float* lse = nullptr, int64_t vt_bs = -1)
 {
+    if (vt_bs < 0) vt_bs = (int64_t)H * kD * Skv;      // contiguous [B][H][64][Skv]
     if (const char* e = getenv("GD_NN_ATTN_WAVES")) g_attn_waves = atoi(e);
     const float c = scale * 1.4426950408889634f;
     int waves = 4;     // 8 waves per workgroup measured the same at batch 16 and worse on small grids (tools/attn_bench.py)
@@ -508,11 +588,11 @@ static int launch_attention(hipStream_t s, const void* q, const void* k, const v
     if (waves == 8)
         hipLaunchKernelGGL(attn_fwd_d64_kernel<8>, dim3((S + 255) / 256, B * H), dim3(512), 6 * kTile, s, (const uint16_t*)q,
                            (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
-                           o_rs, c, kv_len, lse);
+                           o_rs, c, kv_len, lse, vt_bs);
     else
         hipLaunchKernelGGL(attn_fwd_d64_kernel<4>, dim3((S + 127) / 128, B * H), dim3(256), 6 * kTile, s, (const uint16_t*)q,
                            (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
-                           o_rs, c, kv_len, lse);
+                           o_rs, c, kv_len, lse, vt_bs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
@@ -560,10 +640,24 @@ int gd_nn_attention_d64_forward_vt(void* stream, const void* q, const void* k, c
     return launch_attention((hipStream_t)stream, q, k, vt, o, B, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs, o_rs, scale, Skv);
 }
 
+int gd_nn_attention_d64_forward_vt_strided(void* stream, const void* q, const void* k, const void* vt, void* o, int B, int S,
+                                           int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t vt_bs,
+                                           int64_t o_bs, int o_rs, float scale, int kv_len)
+{
+    if (int e = check_attention(q, k, vt, o, B, S, Skv, H, q_rs, k_rs, o_rs, kv_len)) return e;
+    if (vt_bs < (int64_t)H * kD * Skv || vt_bs % 8)
+        return fail(GD_NN_ERR_INVALID_ARG, "attention: vt batch stride must be >= H * 64 * Skv elements and a multiple of 8");
+    return launch_attention((hipStream_t)stream, q, k, vt, o, B, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs, o_rs, scale, kv_len,
+                            nullptr, vt_bs);
+}
+
 // Workspace of the backward pass: K^T [B][H][64][Skv], Q^T and dO^T [B][H][64][S] (bf16), D [B][H][S] (fp32).
 size_t gd_nn_attention_bwd_ws_bytes(int B, int S, int Skv, int H)
 {
-    return (size_t)B * H * 64 * ((size_t)Skv + 2 * (size_t)S) * 2 + (size_t)B * H * S * 4;
+    // ... + the fp32 partials of the chunked key-owning kernel (sized for the largest chunk count any kv_len <= Skv gives)
+    const size_t base = (size_t)B * H * 64 * ((size_t)Skv + 2 * (size_t)S) * 2 + (size_t)B * H * S * 4;
+    const int chunks = bwd_key_chunks(B, S, Skv, H);
+    return base + (chunks > 1 ? (size_t)chunks * B * H * (size_t)((Skv + 127) / 128 * 128) * 2 * 64 * sizeof(float) : 0);
 }
 
 int gd_nn_attention_d64_backward(void* stream, const void* q, const void* k, const void* v, const void* o, const void* dout,
@@ -583,9 +677,11 @@ int gd_nn_attention_d64_backward(void* stream, const void* q, const void* k, con
     uint16_t* qt = kt + (size_t)B * H * 64 * Skv;
     uint16_t* dot = qt + (size_t)B * H * 64 * S;
     float* dsum = (float*)(dot + (size_t)B * H * 64 * S);
-    hipLaunchKernelGGL(attn_vt_kernel, dim3(Skv / 64, H, B), dim3(256), 0, s, (const uint16_t*)k, kt, Skv, H, k_bs, k_rs, kv_len);
-    hipLaunchKernelGGL(attn_vt_kernel, dim3(S / 64, H, B), dim3(256), 0, s, (const uint16_t*)q, qt, S, H, q_bs, q_rs, S);
-    hipLaunchKernelGGL(attn_vt_kernel, dim3(S / 64, H, B), dim3(256), 0, s, (const uint16_t*)dout, dot, S, H, do_bs, do_rs, S);
+    {   // K^T, Q^T, dO^T: one launch (three 7 us launches per attention backward before round 5)
+        const VtJob jk = {(const uint16_t*)k, kt, Skv, k_bs, k_rs, kv_len}, jq = {(const uint16_t*)q, qt, S, q_bs, q_rs, S},
+                    jd = {(const uint16_t*)dout, dot, S, do_bs, do_rs, S};
+        hipLaunchKernelGGL(attn_vt3_kernel, dim3((S > Skv ? S : Skv) / 64, H, 3 * B), dim3(256), 0, s, jk, jq, jd, H);
+    }
     const int64_t rows8 = (int64_t)B * S * H * 8;
     hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((rows8 + 255) / 256)), dim3(256), 0, s, (const uint16_t*)o,
                        (const uint16_t*)dout, dsum, B, S, H, o_bs, o_rs, do_bs, do_rs);
@@ -604,12 +700,26 @@ int gd_nn_attention_d64_backward(void* stream, const void* q, const void* k, con
     hipLaunchKernelGGL((attn_bwd_d64_kernel<0, 4>), dim3((S + 127) / 128, B * H), dim3(256), 2 * 3 * kTile, s, (const uint16_t*)q,
                        q_bs, q_rs, (const uint16_t*)dout, do_bs, do_rs, (const uint16_t*)k, k_bs, k_rs, (const uint16_t*)v, v_bs,
                        v_rs, kt, (const uint16_t*)nullptr, lse, dsum, (uint16_t*)dq, dq_bs, dq_rs, (uint16_t*)nullptr, (int64_t)0,
-                       0, S, Skv, H, c, scale, S, kv_len, S);
-    // dK, dV: lanes = keys, queries stream
-    hipLaunchKernelGGL((attn_bwd_d64_kernel<1, 4>), dim3((kv_len + 127) / 128, B * H), dim3(256), 2 * 4 * kTile, s,
-                       (const uint16_t*)k, k_bs, k_rs, (const uint16_t*)v, v_bs, v_rs, (const uint16_t*)q, q_bs, q_rs,
-                       (const uint16_t*)dout, do_bs, do_rs, dot, qt, lse, dsum, (uint16_t*)dv, dv_bs, dv_rs, (uint16_t*)dk, dk_bs,
-                       dk_rs, kv_len, S, H, c, scale, kv_len, S, S);
+                       0, S, Skv, H, c, scale, S, kv_len, S, 0, (float*)nullptr);
+    // dK, dV: lanes = keys, queries stream -- in `chunks` workgroups per key block when a head has only a few keys
+    const int chunks = bwd_key_chunks(B, S, kv_len, H) <= bwd_key_chunks(B, S, Skv, H) ? bwd_key_chunks(B, S, kv_len, H) : 1;
+    const int gx = (kv_len + 127) / 128;
+    if (chunks > 1) {
+        float* part = (float*)((char*)(dsum + (size_t)B * H * S));
+        const int tpc = (S / kTk + chunks - 1) / chunks, nz = (S / kTk + tpc - 1) / tpc;     // no empty chunk
+        hipLaunchKernelGGL((attn_bwd_d64_kernel<1, 4>), dim3(gx, B * H, nz), dim3(256), 2 * 4 * kTile, s,
+                           (const uint16_t*)k, k_bs, k_rs, (const uint16_t*)v, v_bs, v_rs, (const uint16_t*)q, q_bs, q_rs,
+                           (const uint16_t*)dout, do_bs, do_rs, dot, qt, lse, dsum, (uint16_t*)dv, dv_bs, dv_rs, (uint16_t*)dk,
+                           dk_bs, dk_rs, kv_len, S, H, c, scale, kv_len, S, S, tpc, part);
+        const int64_t threads = (int64_t)B * H * kv_len * 32;
+        hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, part, nz, B * H, H,
+                           gx * 128, kv_len, (uint16_t*)dv, dv_bs, dv_rs, (uint16_t*)dk, dk_bs, dk_rs, scale);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_d64_kernel<1, 4>), dim3(gx, B * H), dim3(256), 2 * 4 * kTile, s,
+                           (const uint16_t*)k, k_bs, k_rs, (const uint16_t*)v, v_bs, v_rs, (const uint16_t*)q, q_bs, q_rs,
+                           (const uint16_t*)dout, do_bs, do_rs, dot, qt, lse, dsum, (uint16_t*)dv, dv_bs, dv_rs, (uint16_t*)dk,
+                           dk_bs, dk_rs, kv_len, S, H, c, scale, kv_len, S, S, 0, (float*)nullptr);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;

@@ -1308,10 +1308,22 @@ static size_t split_ws_bytes(int split, int64_t M, int Cout)
     return (size_t)split * (size_t)((M + 127) / 128) * (size_t)((Cout + 127) / 128) * 16384u * sizeof(float);
 }
 
+// Shallow, narrow layers on a half-empty tile grid (the UNet's 320 -> 320 convolutions on the 64^2 maps of one or two latents):
+// 64 x 64 tiles, one launch, instead of two or three K ranges + the reduce launch -- 1.23-1.28x on MI355X
+// (profiles/r05_small_tile_sweep.txt; every deeper or wider small-M layer is faster split, same file)
+static bool small_tile_nosplit(int64_t M, int Cout, int ntaps, int Cin)
+{
+    if (g_force_split >= 0 || g_force_variant >= 0) return false;
+    M *= g_route_scale;
+    const int64_t t128 = ((M + 127) / 128) * ((Cout + 127) / 128), t64 = ((M + 63) / 64) * ((Cout + 63) / 64);
+    return ntaps == 9 && Cin <= 320 && Cout <= 320 && Cout % 8 == 0 && t128 < 256 && t64 >= 256;
+}
+
 static int choose_split(int64_t M, int Cout, int ntaps, int Cin)
 {
     const int steps = ntaps * (Cin / BK);
     if (g_force_split >= 0) return g_force_split > 1 && g_force_split <= steps ? g_force_split : 1;
+    if (small_tile_nosplit(M, Cout, ntaps, Cin)) return 1;
     M *= g_route_scale;
     const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
     if (tiles >= 256 || Cout % 8 || steps < 8) return 1;
@@ -1347,6 +1359,7 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
     const int tps = split > 1 ? (total_steps + split - 1) / split : total_steps;
     if (split > 1) split = (total_steps + tps - 1) / tps;   // no empty ranges
     int variant = split > 1 ? 0 : g_force_variant;
+    if (variant < 0 && small_tile_nosplit(M, Cout, g.ntaps, Cin)) variant = 6;
     if (variant < 0) {
         // rules distilled from tools/conv_kernel_bench.py on MI355X: the 256x256 tile wins whenever Cout fills it
         // and there is most of a wave of tiles; 128 ch x 256 px wins for long pixel dimensions with deep K or huge M;

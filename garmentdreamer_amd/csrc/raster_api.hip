@@ -178,9 +178,14 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
                  const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                  const float* projmatrix, const float* cam_pos, const float* tanx, const float* tany,
-                 int prefiltered, float* out_color, float* out_depth, float* out_alpha, int* radii, int debug)
+                 int prefiltered, float* out_color, float* out_depth, float* out_alpha, int* radii, int debug,
+                 uint32_t capacity = 0, uint32_t* count_dev = nullptr)
 {
+    // capacity > 0: the sync-free form (gd_raster_forward_batched_capacity) -- the instance count never leaves the device
     g_err[0] = 0;
+    const bool sync_free = capacity > 0;
+    if (sync_free && !count_dev) return fail(GD_ERR_INVALID_ARG, "%s", "the sync-free form needs the 4-word device count buffer");
+    if (sync_free && capacity >= (1u << 30)) return fail(GD_ERR_INVALID_ARG, "%s", "capacity exceeds 2^30 (32-bit strip-list offsets)");
     if (V < 1 || V > GD_MAX_VIEWS) return fail(GD_ERR_INVALID_ARG, "V must be in [1, %s]", "GD_MAX_VIEWS");
     if (P < 0 || W <= 0 || H <= 0) return fail(GD_ERR_INVALID_ARG, "%s", "P, width, height must be positive");
     if (!geom_alloc || !binning_alloc || !image_alloc) return fail(GD_ERR_INVALID_ARG, "%s", "allocator callbacks are required");
@@ -191,6 +196,7 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
         GD_HIP(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * HW * V, stream));
         GD_HIP(hipMemsetAsync(out_depth, 0, sizeof(float) * HW * V, stream));
         GD_HIP(hipMemsetAsync(out_alpha, 0, sizeof(float) * HW * V, stream));
+        if (sync_free) GD_HIP(hipMemsetAsync(count_dev, 0, 4 * sizeof(uint32_t), stream));
         return 0;
     }
     if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !cam_pos)
@@ -217,15 +223,18 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
                       prefiltered != 0); }
     if (int e = check_debug(stream, debug, "preprocess")) return e;
     const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
-    { ProfScope ps(stream, GD_K_SCAN); launch_scan_block_sums(stream, geom.block_sums, nblk); }
+    { ProfScope ps(stream, GD_K_SCAN); launch_scan_block_sums(stream, geom.block_sums, nblk, sync_free ? count_dev : nullptr, capacity); }
     if (int e = check_debug(stream, debug, "scan")) return e;
 
-    // the one host sync of the forward pass (rasterizer_impl.cu:282)
-    uint32_t num_rendered = 0;
-    GD_HIP(hipMemcpyAsync(&num_rendered, geom.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GD_HIP(hipStreamSynchronize(stream));
-    // the compact per-strip lists index 4 * num_rendered cells with 32-bit arithmetic (raster_render.hip: my_base, rowpos)
-    if (num_rendered >= (1u << 30)) return fail(GD_ERR_INVALID_ARG, "%s", "num_rendered exceeds 2^30 (32-bit strip-list offsets)");
+    uint32_t num_rendered = capacity;       // sync-free: every buffer, grid and layout below is sized for the capacity
+    const uint32_t* n_dev = sync_free ? count_dev + 1 : nullptr;     // ... and the kernels read the live count here
+    if (!sync_free) {
+        // the one host sync of the forward pass (rasterizer_impl.cu:282)
+        GD_HIP(hipMemcpyAsync(&num_rendered, geom.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        GD_HIP(hipStreamSynchronize(stream));
+        // the compact per-strip lists index 4 * num_rendered cells with 32-bit arithmetic (raster_render.hip: my_base, rowpos)
+        if (num_rendered >= (1u << 30)) return fail(GD_ERR_INVALID_ARG, "%s", "num_rendered exceeds 2^30 (32-bit strip-list offsets)");
+    }
 
     char* bin_chunk = binning_alloc(binning_user, gd_raster_binning_bytes(num_rendered));
     if (!bin_chunk) return fail(GD_ERR_ALLOC, "%s", "binning allocator returned NULL");
@@ -235,13 +244,14 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     const bool start_in_alt = (plan.passes & 1) != 0;
     { ProfScope ps(stream, GD_K_DUPLICATE);
     launch_duplicate(stream, (int)VP, P, radii, geom, start_in_alt ? bin.keys_alt : bin.keys,
-                     start_in_alt ? bin.point_list_alt : bin.point_list, bin.slot_vp, nullptr, dm.tiles_x, dm.tiles_y); }
+                     start_in_alt ? bin.point_list_alt : bin.point_list, bin.slot_vp, nullptr, dm.tiles_x, dm.tiles_y,
+                     sync_free ? count_dev : nullptr); }
     GD_HIP(hipMemsetAsync(bin.rowpos, 0, sizeof(uint4) * (size_t)num_rendered, stream));
     if (int e = check_debug(stream, debug, "duplicate")) return e;
-    { ProfScope ps(stream, GD_K_SORT); launch_radix_sort(stream, bin, num_rendered, plan, start_in_alt); }
+    { ProfScope ps(stream, GD_K_SORT); launch_radix_sort(stream, bin, num_rendered, plan, start_in_alt, n_dev); }
     if (int e = check_debug(stream, debug, "sort")) return e;
     { ProfScope ps(stream, GD_K_RANGES); launch_tile_ranges(stream, bin.keys, num_rendered, img.ranges, dm.tiles_total, bin.point_list,
-                                                          bin.slot_vp, bin.point_list_alt); }
+                                                          bin.slot_vp, bin.point_list_alt, n_dev); }
     if (int e = check_debug(stream, debug, "ranges")) return e;
     { ProfScope ps(stream, GD_K_RENDER_FWD);
     launch_render_forward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, bin.point_list, geom, background,
@@ -370,6 +380,24 @@ int gd_raster_forward_batched(void* stream, int V, gd_alloc_fn geom_alloc, void*
                         image_user, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
                         scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
                         tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug);
+}
+
+int gd_raster_forward_batched_capacity(void* stream, int V, gd_alloc_fn geom_alloc, void* geom_user,
+                                       gd_alloc_fn binning_alloc, void* binning_user, gd_alloc_fn image_alloc,
+                                       void* image_user, int P, int D, int M, const float* background, int width,
+                                       int height, const float* means3D, const float* shs, const float* colors_precomp,
+                                       const float* opacities, const float* scales, float scale_modifier,
+                                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                       const float* projmatrix, const float* cam_pos, const float* tan_fovx,
+                                       const float* tan_fovy, int prefiltered, float* out_color, float* out_depth,
+                                       float* out_alpha, int* radii, int debug, int64_t capacity, uint32_t* count_dev)
+{
+    if (!tan_fovx || !tan_fovy) return fail(GD_ERR_INVALID_ARG, "%s", "tan_fovx / tan_fovy host arrays are required");
+    if (capacity <= 0 || capacity >= (1ll << 30)) return fail(GD_ERR_INVALID_ARG, "%s", "capacity must be in [1, 2^30)");
+    return forward_impl((hipStream_t)stream, V, geom_alloc, geom_user, binning_alloc, binning_user, image_alloc,
+                        image_user, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
+                        scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                        tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug, (uint32_t)capacity, count_dev);
 }
 
 int gd_raster_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,

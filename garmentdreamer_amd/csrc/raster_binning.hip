@@ -51,7 +51,10 @@ SortPlan plan_sort(uint32_t tiles_total)
 namespace {
 
 // Exclusive scan of block_sums[0..n) in place; block_sums[n] receives the grand total (= R).
-__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ sums, uint32_t n)
+// Sync-free form (info != NULL, round 5): the total stays on the device -- info[0] = R, info[1] = the instance count the
+// binning kernels work on (R if it fits the caller's capacity, else 0: nothing is rendered), info[2] = 1 on overflow.
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ sums, uint32_t n,
+                                                               uint32_t* __restrict__ info, uint32_t capacity)
 {
     __shared__ uint32_t wave_incl[16];
     __shared__ uint32_t carry_s;
@@ -77,14 +80,24 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
         if (tid == 1023) carry_s = carry + wave_off + incl;
         __syncthreads();
     }
-    if (tid == 0) sums[n] = carry_s;
+    if (tid == 0) {
+        sums[n] = carry_s;
+        if (info) {
+            const bool over = carry_s > capacity;
+            info[0] = carry_s;
+            info[1] = over ? 0u : carry_s;
+            info[2] = over ? 1u : 0u;
+            info[3] = capacity;
+        }
+    }
 }
 
 __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, const int* __restrict__ radii,
                                                                 GeomState gs, uint64_t* __restrict__ keys_out,
                                                                 uint32_t* __restrict__ vals_out,
                                                                 uint32_t* __restrict__ slot_vp,
-                                                                uint4* __restrict__ rowpos, uint32_t gx, uint32_t gy)
+                                                                uint4* __restrict__ rowpos, uint32_t gx, uint32_t gy,
+                                                                const uint32_t* __restrict__ info)
 {
     __shared__ uint32_t wave_incl[kGaussBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -103,6 +116,10 @@ __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, c
     const uint32_t incl_global = gs.block_sums[blockIdx.x] + wave_off + incl;
     if (vp >= VP) return;
     gs.point_offsets[vp] = incl_global;  // inclusive, as the reference stores it
+    if (info && info[2]) {               // sync-free form: more instances than the binning buffer holds -- write none,
+        gs.tiles_touched[vp] = 0;        // and leave the backward pass (instance_sum_kernel) nothing to gather either
+        return;
+    }
     const int r = radii[vp];
     if (r > 0) {
         uint32_t off = incl_global - touched;
@@ -141,9 +158,11 @@ __device__ __forceinline__ uint32_t live_digit(uint64_t key, int shift, uint32_t
 
 template <int BITS>
 __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift,
-                                                         uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk)
+                                                         uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
+                                                         const uint32_t* __restrict__ n_dev)
 {
     constexpr int BINS = 1 << BITS;
+    if (n_dev) n = *n_dev;      // sync-free form: the key count lives on the device, the grid covers the capacity
     __shared__ uint32_t h[BINS];
     for (int i = threadIdx.x; i < BINS; i += 256) h[i] = 0;
     __syncthreads();
@@ -195,10 +214,15 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
                                                             uint64_t* __restrict__ keys_out,
                                                             uint32_t* __restrict__ vals_out, uint32_t n, int shift,
                                                             uint32_t mask, const uint32_t* __restrict__ hist,
-                                                            const uint32_t* __restrict__ totals, uint32_t nblk)
+                                                            const uint32_t* __restrict__ totals, uint32_t nblk,
+                                                            const uint32_t* __restrict__ n_dev)
 {
     constexpr int BINS = 1 << BITS;
     constexpr int PER_THREAD = BINS / 256;
+    if (n_dev) {
+        n = *n_dev;
+        if (blockIdx.x * kSortTile >= n) return;     // (workgroup-uniform) nothing of this tile is live
+    }
     __shared__ uint32_t cnt[4][BINS];    // per-wave running digit counts, later wave bases
     __shared__ uint32_t dbase[BINS];     // global base of digit d for this workgroup
     __shared__ uint32_t wave_tot[4];
@@ -286,8 +310,9 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
 
 __global__ void tile_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t L, uint2* __restrict__ ranges,
                                    uint32_t* __restrict__ point_list, const uint32_t* __restrict__ slot_vp,
-                                   uint32_t* __restrict__ slot_of)
+                                   uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ n_dev)
 {
+    if (n_dev) L = *n_dev;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L) return;
     if (slot_vp) {   // the sort's epilogue: the payload (slot) moves aside, point_list becomes the Gaussian ids
@@ -309,36 +334,38 @@ __global__ void tile_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t L
 
 template <int BITS>
 void sort_pass(hipStream_t s, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, uint32_t n,
-               int shift, int width, uint32_t* hist, uint32_t nblk)
+               int shift, int width, uint32_t* hist, uint32_t nblk, const uint32_t* n_dev)
 {
     constexpr int BINS = 1 << BITS;
     uint32_t* totals = hist + (size_t)BINS * nblk;
     const uint32_t mask = (1u << width) - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel<BITS>, dim3(nblk), dim3(256), 0, s, kin, n, shift, mask, hist, nblk);
+    hipLaunchKernelGGL(radix_hist_kernel<BITS>, dim3(nblk), dim3(256), 0, s, kin, n, shift, mask, hist, nblk, n_dev);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(BINS), dim3(256), 0, s, hist, nblk, totals);
     hipLaunchKernelGGL(radix_scatter_kernel<BITS>, dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout, n, shift, mask,
-                       hist, totals, nblk);
+                       hist, totals, nblk, n_dev);
 }
 
 }  // namespace
 
-void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks)
+void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks, uint32_t* info, uint32_t capacity)
 {
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nblocks);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nblocks, info, capacity);
 }
 
 void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* keys_out,
-                      uint32_t* vals_out, uint32_t* slot_vp, uint4* rowpos, int tiles_x, int tiles_y)
+                      uint32_t* vals_out, uint32_t* slot_vp, uint4* rowpos, int tiles_x, int tiles_y, const uint32_t* info)
 {
     const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
     hipLaunchKernelGGL(duplicate_kernel, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, keys_out, vals_out,
-                       slot_vp, rowpos, (uint32_t)tiles_x, (uint32_t)tiles_y);
+                       slot_vp, rowpos, (uint32_t)tiles_x, (uint32_t)tiles_y, info);
 }
 
 // Sorts (keys, vals) of length R on the low plan.total_bits bits.  The unsorted input sits in
 // the *_alt buffers when start_in_alt, else in the primary buffers; the caller picks that so
 // the final pass lands in b.keys / b.point_list.
-void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan, bool start_in_alt)
+// n_dev != NULL (sync-free form): R is the CAPACITY the grids and the histogram layout are sized for, the live key count is
+// read from *n_dev by every kernel.
+void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan, bool start_in_alt, const uint32_t* n_dev)
 {
     if (R == 0) return;
     const uint32_t nblk = (R + kSortTile - 1) / kSortTile;
@@ -350,21 +377,21 @@ void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan,
         int width = plan.live_bits - shift;
         if (width > plan.digit_bits) width = plan.digit_bits;
         switch (plan.digit_bits) {
-            case 8: sort_pass<8>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk); break;
-            case 9: sort_pass<9>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk); break;
-            default: sort_pass<10>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk); break;   // Morton codes (raster_scene.hip)
+            case 8: sort_pass<8>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk, n_dev); break;
+            case 9: sort_pass<9>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk, n_dev); break;
+            default: sort_pass<10>(s, k[cur], v[cur], k[cur ^ 1], v[cur ^ 1], R, shift, width, b.sort_hist, nblk, n_dev); break;   // Morton codes (raster_scene.hip)
         }
         cur ^= 1;
     }
 }
 
 void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total,
-                        uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of)
+                        uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of, const uint32_t* n_dev)
 {
     (void)hipMemsetAsync(ranges, 0, (size_t)tiles_total * sizeof(uint2), s);
     if (R > 0)
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges, point_list,
-                           slot_vp, slot_of);
+                           slot_vp, slot_of, n_dev);
 }
 
 }  // namespace gd

@@ -102,13 +102,13 @@ void launch_preprocess_backward(hipStream_t s, int P, int D, int M, int V, const
                                 float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
                                 float* dL_dsh, float* dL_dscale, float* dL_drot, float* view_partials);
 
-void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks);
+void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks, uint32_t* info = nullptr, uint32_t capacity = 0);
 void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* keys_out,
-                      uint32_t* vals_out, uint32_t* slot_vp, uint4* rowpos, int tiles_x, int tiles_y);
-void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan, bool start_in_alt);
+                      uint32_t* vals_out, uint32_t* slot_vp, uint4* rowpos, int tiles_x, int tiles_y, const uint32_t* info = nullptr);
+void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan, bool start_in_alt, const uint32_t* n_dev = nullptr);
 // identifyTileRanges + the sort's epilogue: slot_of[s] = point_list[s] (the slot), point_list[s] = its Gaussian id
 void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total,
-                        uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of);
+                        uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of, const uint32_t* n_dev = nullptr);
 
 void launch_blend_exp(hipStream_t s, const float* x, float* y, int n);   // y = gd_expf(x): parity test hook
 void launch_poison_lds(hipStream_t s);                                   // NaN patterns into every CU's LDS: test hook

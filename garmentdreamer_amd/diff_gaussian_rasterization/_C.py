@@ -173,12 +173,76 @@ def _farr(vals):
     return arr
 
 
+class InstanceCapacity:
+    """Caller-side state of the SYNC-FREE batched forward pass (``gd_raster_forward_batched_capacity``, include/gd_raster.h).
+
+    The reference reads ``num_rendered`` back to the host in the middle of every forward pass to size the binning buffer
+    (rasterizer_impl.cu:282) -- the only stream synchronisation of the iteration.  With an ``InstanceCapacity`` handed to
+    ``rasterize_gaussians_batched`` the binning buffer is sized for ``capacity`` instances instead, the kernels read the live
+    count on the device, and the count comes back through a DEFERRED asynchronous copy into pinned memory that the NEXT call
+    looks at (by then it landed long ago): it re-sizes the capacity (``margin`` x the last count, rounded up to ``quantum``)
+    and RAISES if the previous call overflowed -- that call binned nothing (every view shows the background), so its results,
+    and whatever an optimizer did with them, are void; a loop that cannot tolerate that uses a larger margin or
+    ``reset()`` (the next call then takes the synchronising path once and re-seeds the capacity) whenever the scene changes
+    abruptly (densification).  The first call, or any call after ``reset()``, synchronises like the reference."""
+
+    def __init__(self, margin: float = 1.5, quantum: int = 1 << 16):
+        self.margin, self.quantum = float(margin), int(quantum)
+        self.value = None            # capacity of the next call; None -> synchronising path
+        self.last_count = None       # num_rendered of the most recent call whose count has been read
+        self.calls_sync_free = 0
+        self._dev = self._host = self._event = None
+        self._pending = False
+
+    def reset(self):
+        self.collect()
+        self.value = None
+
+    def _round(self, n: int) -> int:
+        q = self.quantum
+        return max(q, (int(n * self.margin) + q - 1) // q * q)
+
+    def seed(self, num_rendered: int):
+        self.last_count = int(num_rendered)
+        self.value = self._round(num_rendered)
+
+    def buffers(self, device):
+        if self._dev is None or self._dev.device != device:
+            self._dev = torch.zeros(4, dtype=torch.int32, device=device)
+            self._host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            self._event = torch.cuda.Event()
+        return self._dev
+
+    def observe(self, device):
+        """Right after a sync-free call: start the count's trip to the host (no wait)."""
+        self._host.copy_(self._dev, non_blocking=True)
+        self._event.record(torch.cuda.current_stream(device))
+        self._pending = True
+        self.calls_sync_free += 1
+
+    def collect(self):
+        """Look at the previous sync-free call's count (a wait only if the GPU has not reached that copy yet)."""
+        if not self._pending:
+            return
+        self._event.synchronize()
+        self._pending = False
+        total, _live, over, cap = (int(v) & 0xffffffff for v in self._host.tolist())
+        self.last_count = total
+        if over:
+            self.value = None
+            raise RuntimeError(f"rasterizer: the previous sync-free forward pass overflowed its instance capacity "
+                               f"({total} instances > capacity {cap}): it rendered nothing and its results are void")
+        self.value = self._round(total)
+
+
 def rasterize_gaussians_batched(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                                campos, prefiltered, debug):
+                                campos, prefiltered, debug, capacity: "InstanceCapacity | None" = None):
     """V views in one launch set.  viewmatrix/projmatrix [V,4,4], campos [V,3], tan_fov*: sequences
     of V floats.  Returns ``(num_rendered, color[V,3,H,W], depth[V,1,H,W], alpha[V,1,H,W],
-    radii[V,P], geom, binning, img)``."""
+    radii[V,P], geom, binning, img)``.  ``capacity``: an ``InstanceCapacity`` -- the call then runs WITHOUT the host read-back
+    of the instance count whenever the object holds a capacity, and the first returned value is that capacity (what the
+    backward call wants as R), not the instance count."""
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D)
@@ -198,14 +262,23 @@ def rasterize_gaussians_batched(background, means3D, colors, opacity, scales, ro
                                     viewmatrix, projmatrix, campos)]
     bg, m3, shc, col, opa, scl, rot, cov, vm, pm, cp = keep
     tx, ty = _farr(tan_fovx), _farr(tan_fovy)
+    if capacity is not None:
+        capacity.collect()           # the previous call's count: re-sizes the capacity, raises after an overflow
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        rendered = L.gd_raster_forward_batched(
-            stream, V, geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H, _ptr(m3),
-            _ptr(shc), _ptr(col), _ptr(opa), _ptr(scl), float(scale_modifier), _ptr(rot), _ptr(cov), _ptr(vm),
-            _ptr(pm), _ptr(cp), tx, ty, int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(),
-            out_alpha.data_ptr(), radii.data_ptr() if P else None, int(bool(debug)))
-    _native.check(rendered, "gd_raster_forward_batched")
+        head = (stream, V, geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H, _ptr(m3),
+                _ptr(shc), _ptr(col), _ptr(opa), _ptr(scl), float(scale_modifier), _ptr(rot), _ptr(cov), _ptr(vm),
+                _ptr(pm), _ptr(cp), tx, ty, int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(),
+                out_alpha.data_ptr(), radii.data_ptr() if P else None, int(bool(debug)))
+        if capacity is not None and capacity.value is not None and P > 0:
+            rendered = L.gd_raster_forward_batched_capacity(*head, int(capacity.value), capacity.buffers(dev).data_ptr())
+            _native.check(rendered, "gd_raster_forward_batched_capacity")
+            capacity.observe(dev)
+        else:
+            rendered = L.gd_raster_forward_batched(*head)
+            _native.check(rendered, "gd_raster_forward_batched")
+            if capacity is not None:
+                capacity.seed(rendered)
     return rendered, out_color, out_depth, out_alpha, radii, geom.tensor, binning.tensor, img.tensor
 
 

@@ -127,6 +127,7 @@ class BatchedRasterizationSettings(NamedTuple):
     campos: torch.Tensor
     prefiltered: bool
     debug: bool
+    capacity: object = None      # _C.InstanceCapacity: forward pass without the host read-back of the instance count
 
 
 class _RasterizeGaussiansBatched(torch.autograd.Function):
@@ -139,7 +140,7 @@ class _RasterizeGaussiansBatched(torch.autograd.Function):
                 rs.viewmatrix, rs.projmatrix, list(rs.tanfovx), list(rs.tanfovy), rs.image_height, rs.image_width,
                 sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
         num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer = \
-            _C.rasterize_gaussians_batched(*args)
+            _C.rasterize_gaussians_batched(*args, capacity=getattr(rs, "capacity", None))
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,

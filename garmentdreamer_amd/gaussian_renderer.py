@@ -64,10 +64,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             "alpha": alpha}
 
 
-def render_batch(cameras, pc, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+def render_batch(cameras, pc, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, capacity=None):
     """Render ``len(cameras)`` views in one launch set.  Returns the per-view dict keys stacked on
     a leading V axis: render [V,3,H,W], viewspace_points [V,P,3] (gradient holder), radii [V,P],
-    depth_3dgs [V,1,H,W], alpha [V,1,H,W]."""
+    depth_3dgs [V,1,H,W], alpha [V,1,H,W].  ``capacity``: a ``diff_gaussian_rasterization._C.InstanceCapacity`` kept by the
+    caller across iterations -- the forward pass then runs without its host synchronisation (see that class)."""
     xyz = pc.get_xyz
     cb = cameras if isinstance(cameras, CameraBatch) else CameraBatch(cameras, xyz.device)
     V = cb.viewmatrix.shape[0]
@@ -80,7 +81,7 @@ def render_batch(cameras, pc, bg_color: torch.Tensor, scaling_modifier=1.0, over
     rs = BatchedRasterizationSettings(
         image_height=cb.image_height, image_width=cb.image_width, tanfovx=cb.tanfovx, tanfovy=cb.tanfovy,
         bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=cb.viewmatrix, projmatrix=cb.projmatrix,
-        sh_degree=pc.active_sh_degree, campos=cb.campos, prefiltered=False, debug=False)
+        sh_degree=pc.active_sh_degree, campos=cb.campos, prefiltered=False, debug=False, capacity=capacity)
     rasterizer = GaussianRasterizer(raster_settings=rs)
     if hasattr(pc, "activated"):     # flat-buffer GaussianModel: all activations in one launch
         feats, opacities, scales, rotations = pc.activated()

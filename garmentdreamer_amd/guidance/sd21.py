@@ -47,6 +47,7 @@ _FUSED_QKV = _os.environ.get("GD_FUSED_QKV", "1") != "0"   # A/B toggle of the f
 _VT_GEMM = _os.environ.get("GD_VT_GEMM", "1") != "0"         # A/B toggle: V^T from a GEMM instead of the transposing pre-pass
 _LORA_FUSED = _os.environ.get("GD_LORA_FUSED", "1") != "0"   # A/B toggle: own rank-4 LoRA kernels (fwd + bwd) instead of torch ops
 _VAE_ATTN_NODE = _os.environ.get("GD_VAE_ATTN_NODE", "1") != "0"  # A/B toggle: VAE mid attention as one autograd node with own softmax
+_CTX_VT = _os.environ.get("GD_CTX_VT", "1") != "0"           # A/B toggle: cross-attention V^T of all layers from one GEMM (round 5)
 _LORA_LINEAR = _os.environ.get("GD_LORA_LINEAR", "1") != "0"  # A/B toggle: adapted projection as ONE autograd node (nn_ops.lora_linear)
 from .. import nn_ops  # noqa: E402
 _FP8_ACTIVE = [None]   # the nn_ops.Fp8State of the UNet whose no-grad forward is running (set by its forward)
@@ -161,10 +162,13 @@ class ContextProjections:
     embeddings do not depend on the sample, so the 16 layers' 32 projections of the [B, 77, 1024] context are one
     [B*77, 1024] x [1024, 24960] product whose column slices feed the attentions as strided views."""
 
-    __slots__ = ("context", "kv")
+    __slots__ = ("context", "kv", "vt")
 
-    def __init__(self, context, kv):
-        self.context, self.kv = context, kv
+    def __init__(self, context, kv, vt=None):
+        # vt[id(attn)]: V^T of the zero-padded context, a [B, C, 128] channel slice of ONE W_v_cat . context^T product
+        # (round 5): the attention kernel consumes V transposed, and the per-layer transposing pre-pass (15 launches per
+        # UNet forward) is gone
+        self.context, self.kv, self.vt = context, kv, (vt or {})
 
     @property
     def shape(self):
@@ -238,13 +242,19 @@ class Attention(nn.Module):
 
     def forward(self, x, context=None):
         B, N, _ = x.shape
-        kv = None
+        kv = context_vt = None
         if isinstance(context, ContextProjections):
             kv = context.kv.get(id(self)) if self.lora is None else None
+            context_vt = context.vt
             context = context.context
         ctx = x if context is None else context
         if kv is not None:
             q, (k, v) = _lin(self.to_q, x), kv
+            vt = context_vt.get(id(self)) if context_vt is not None else None
+            if vt is not None and N >= 256 and _CTX_VT and q.shape[-1] == 64 * self.heads and not torch.is_grad_enabled():
+                q4, k4 = q.view(B, N, self.heads, 64), k.view(B, k.shape[1], self.heads, 64)
+                if nn_ops._attention_d64_layout_ok(q4, k4, k4):
+                    return _lin(self.to_out[0], nn_ops.attention_d64_vt_strided(q4, k4, vt, k.shape[1]))
         elif _FUSED_QKV and context is None and self.lora is None and x.is_cuda and self.to_q.bias is None and \
                 not self.to_q.weight.requires_grad and not torch.is_grad_enabled():
             # frozen self-attention: ONE [C, 2C] projection for q | k (the attention kernel reads the two strided views)
@@ -546,15 +556,27 @@ class UNet2DConditionModel(nn.Module):
         if cache is None or cache[0] != key:
             with torch.no_grad():
                 w = torch.cat([t for a in atts for t in (a.to_k.weight, a.to_v.weight)], dim=0).to(ctx.dtype).contiguous()
-            cache = self._ctx_cat = (key, w)
+                wv = torch.cat([a.to_v.weight for a in atts], dim=0).to(ctx.dtype).contiguous()
+            cache = self._ctx_cat = (key, w, wv)
         with torch.no_grad():
             allp = _lib_linear(ctx, cache[1])
-        kv, off = {}, 0
+            vt_all = None
+            if _CTX_VT and ctx.dtype == torch.bfloat16 and all(a.to_v.out_features == 64 * a.heads for a in atts):
+                # V^T of every layer: W_v_cat [sum C, 1024] x context^T, the context zero-padded to a whole number of 64-key
+                # tiles (padded keys: V^T columns = 0, what the attention kernel expects); one batched GEMM per UNet call
+                T = ctx.shape[1]
+                Tp = (T + 63) // 64 * 64
+                ctx_p = F.pad(ctx, (0, 0, 0, Tp - T)) if Tp != T else ctx
+                vt_all = torch.matmul(cache[2], ctx_p.transpose(1, 2))          # [B, sum C, Tp]
+        kv, vt, off, voff = {}, {}, 0, 0
         for a in atts:
             c = a.to_k.out_features
             kv[id(a)] = (allp[..., off:off + c], allp[..., off + c:off + 2 * c])
+            if vt_all is not None:
+                vt[id(a)] = vt_all[:, voff:voff + c]
             off += 2 * c
-        return ContextProjections(ctx, kv)
+            voff += c
+        return ContextProjections(ctx, kv, vt)
 
     def _project_temb(self, temb):
         """All blocks' per-image conv1 biases in one GEMM (``TembProjections``) when nothing on the way needs a

@@ -96,6 +96,8 @@ SIGNATURES = {
     "gd_nn_attention_d64_backward": (_i, [_vp] * 11 + [_i, _i, _i, _i] + [C.c_int64, _i] * 8 + [_f, _i]),
     "gd_nn_attention_d64_forward_vt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i, C.c_int64, _i,
                                             _f]),
+    "gd_nn_attention_d64_forward_vt_strided": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, _i, C.c_int64, _i, C.c_int64,
+                                                    C.c_int64, _i, _f, _i]),
     "gd_nn_attention_last_error": (C.c_char_p, []),
     "gd_nn_vae_prologue_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_vae_prologue_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
@@ -1272,7 +1274,10 @@ def conv1x1_c8(x, weight, bias=None):
 
 _ATTN_TRAIN = os.environ.get("GD_ATTN_TRAIN", "1") != "0"    # A/B toggle: own attention forward kernel in the training pass
 _ATTN_BWD = os.environ.get("GD_ATTN_BWD", "1") != "0"        # A/B toggle: own attention backward kernels (else the library's flash backward)
-_ATTN_BWD_MIN_KEYS = 256                                     # fewer keys (cross-attention): library backward (tests lower it)
+# Fewer keys than this: the library's flash backward.  Round 5: 1 -- the key-owning kernel cuts the query range into chunks
+# when a head has one or two key blocks (the 77 text tokens), so the cross-attention backward is own code too
+# (GD_ATTN_BWD_MIN_KEYS=256 restores the round-4 routing for same-box A/B)
+_ATTN_BWD_MIN_KEYS = int(os.environ.get("GD_ATTN_BWD_MIN_KEYS", "1"))
 _ROW_TRAIN = os.environ.get("GD_ROW_TRAIN", "1") != "0"    # A/B toggle: own GEGLU / LayerNorm backward in the training pass
 
 
@@ -1479,6 +1484,25 @@ def attention_d64_vt(q, k, vt):
                                                k.stride(0), k.stride(1), o.stride(0), o.stride(1), 64 ** -0.5)
     if ret < 0:
         raise RuntimeError(f"gd_nn_attention_d64_forward_vt failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
+    return o
+
+
+def attention_d64_vt_strided(q, k, vt, kv_len: int):
+    """Cross-attention with V^T handed in as a [B, H*64, Skv] VIEW (rows contiguous, any batch stride: a channel slice of
+    the all-layers context projection), ``kv_len`` <= Skv live keys (the rest of every V^T row is zero).  q: [B, S, H, 64],
+    k: [B, kv_len, H, 64] views."""
+    B, S, H, _ = q.shape
+    Skv = vt.shape[2]
+    assert vt.shape[:2] == (B, H * 64) and vt.stride(2) == 1 and vt.stride(1) == Skv and vt.dtype == torch.bfloat16 and Skv % 64 == 0
+    L = lib()
+    o = torch.empty((B, S, H * 64), dtype=torch.bfloat16, device=q.device)
+    with torch.cuda.device(q.device):
+        ret = L.gd_nn_attention_d64_forward_vt_strided(torch.cuda.current_stream(q.device).cuda_stream, q.data_ptr(), k.data_ptr(),
+                                                       vt.data_ptr(), o.data_ptr(), B, S, Skv, H, q.stride(0), q.stride(1),
+                                                       k.stride(0), k.stride(1), vt.stride(0), o.stride(0), o.stride(1),
+                                                       64 ** -0.5, int(kv_len))
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_attention_d64_forward_vt_strided failed ({ret}): {L.gd_nn_attention_last_error().decode()}")
     return o
 
 

@@ -87,8 +87,15 @@ class SDSLoop:
     def __init__(self, gaussians, guidance, prompt_utils, bg_color: torch.Tensor,
                  render_batch_fn: Optional[Callable] = None, lambda_sds: float = 1.0, lambda_sparsity: float = 1.0,
                  lr_scale: float = 1.0, fused_adam: Optional[bool] = None, densify: bool = True,
-                 cameras_extent: float = 4.0, densify_seed: int = 0, batch_invariant: bool = False):
+                 cameras_extent: float = 4.0, densify_seed: int = 0, batch_invariant: bool = False,
+                 sync_free: bool = True, capacity_margin: float = 1.5):
         self.gaussians = gaussians
+        # forward pass without the host read-back of the instance count (rasterizer_impl.cu:282; include/gd_raster.h,
+        # gd_raster_forward_batched_capacity): the binning buffer is sized from the previous iterations' counts with a margin
+        self.capacity = None
+        if sync_free and render_batch_fn is None and gaussians.get_xyz.is_cuda:
+            from .diff_gaussian_rasterization._C import InstanceCapacity
+            self.capacity = InstanceCapacity(margin=capacity_margin)
         self.batch_invariant = bool(batch_invariant and gaussians.get_xyz.is_cuda)
         if self.batch_invariant:
             # sharded run that must reproduce the single-rank gradients as closely as bf16 allows: the guidance
@@ -157,7 +164,10 @@ class SDSLoop:
         c2w = batch["c2w_3dgs"]
         cams = [Camera(c2w[i], batch["fovy"][i], batch["height"], batch["width"], data_device="cpu")
                 for i in range(c2w.shape[0])]
-        pkg = self.render_batch_fn(CameraBatch(cams, dev), self.gaussians, self.bg)
+        if self.capacity is not None:
+            pkg = self.render_batch_fn(CameraBatch(cams, dev), self.gaussians, self.bg, capacity=self.capacity)
+        else:
+            pkg = self.render_batch_fn(CameraBatch(cams, dev), self.gaussians, self.bg)
         images = pkg["render"].permute(0, 2, 3, 1)      # [V,H,W,3]
         depths = pkg["depth_3dgs"].permute(0, 2, 3, 1)  # [V,H,W,1]
         out = _RenderOut({**pkg, "comp_rgb": images, "depth": depths, "alphas": pkg["alpha"].permute(0, 2, 3, 1)})
@@ -229,6 +239,8 @@ class SDSLoop:
                         self.gaussians.densify_and_prune(0.0002, 0.05, self.cameras_extent, size_threshold,
                                                          generator=self._densify_gen)
                         densified = True
+                        if self.capacity is not None:
+                            self.capacity.reset()     # the point count jumped: the next forward pass synchronises once
             else:
                 vs_grad = out["viewspace_points"].grad.sum(0)  # sum over this rank's views
                 grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]

@@ -290,6 +290,13 @@ int gd_nn_attention_d64_backward(void* stream, const void* q, const void* k, con
                                  int dv_rs, float scale, int kv_len);
 int gd_nn_attention_d64_forward_vt(void* stream, const void* q, const void* k, const void* vt, void* o, int B, int S, int Skv,
                                    int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t o_bs, int o_rs, float scale);
+/* ... with the V^T images of the batch entries `vt_bs` elements apart (each image [H*64][Skv] contiguous) and kv_len <= Skv
+ * live keys (columns >= kv_len of V^T must be zero): the cross-attention of a frozen UNet, whose V^T of the 77 text tokens
+ * for ALL its layers comes out of ONE GEMM (W_v_cat . context^T; sd21.UNet2DConditionModel._project_context) -- the
+ * per-layer slice is read in place, no transposing pre-pass runs. */
+int gd_nn_attention_d64_forward_vt_strided(void* stream, const void* q, const void* k, const void* vt, void* o, int B, int S,
+                                           int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs, int64_t vt_bs,
+                                           int64_t o_bs, int o_rs, float scale, int kv_len);
 const char* gd_nn_attention_last_error(void);
 
 /* The guidance's image prologue as ONE kernel each way (threestudio stable_diffusion_guidance.py:394-396 + :164):

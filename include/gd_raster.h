@@ -106,6 +106,26 @@ int gd_raster_forward_batched(void* stream, int V, gd_alloc_fn geom_alloc, void*
                               const float* tan_fovy, int prefiltered, float* out_color, float* out_depth,
                               float* out_alpha, int* radii, int debug);
 
+/* The same forward pass WITHOUT the host read-back of the instance count (rasterizer_impl.cu:282 reads num_rendered back to
+ * size the binning buffer: one stream synchronisation per forward pass, the only one of the iteration).  The caller names a
+ * CAPACITY instead: the binning buffer is allocated for `capacity` instances (gd_raster_binning_bytes(capacity)), every grid
+ * is sized for it, and the kernels read the live count from count_dev[1]:
+ *   count_dev[0] = num_rendered of this call, [1] = the count the kernels worked on (= [0], or 0 after an overflow),
+ *   count_dev[2] = 1 if num_rendered > capacity (NOTHING was binned: every view shows the background; the caller reads the
+ *   flag whenever it likes -- a deferred, asynchronous copy -- and must treat the call's results as void), [3] = capacity.
+ * Returns `capacity` (>= 0) -- the value to pass as R to gd_raster_backward_batched, gd_raster_backward_scratch_bytes and
+ * gd_raster_get_layout, which then use the same layout -- or a negative error.  Results for the live instances are bit-identical
+ * to gd_raster_forward_batched.  No reference counterpart (the reference synchronises). */
+int gd_raster_forward_batched_capacity(void* stream, int V, gd_alloc_fn geom_alloc, void* geom_user,
+                                       gd_alloc_fn binning_alloc, void* binning_user, gd_alloc_fn image_alloc,
+                                       void* image_user, int P, int D, int M, const float* background, int width,
+                                       int height, const float* means3D, const float* shs, const float* colors_precomp,
+                                       const float* opacities, const float* scales, float scale_modifier,
+                                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                       const float* projmatrix, const float* cam_pos, const float* tan_fovx,
+                                       const float* tan_fovy, int prefiltered, float* out_color, float* out_depth,
+                                       float* out_alpha, int* radii, int debug, int64_t capacity, uint32_t* count_dev);
+
 /* Batched backward.  dL_dpix [V,3,H,W], dL_dpix_depth/dL_dalphas/alphas [V,1,H,W].
  * dL_dmean2D is PER VIEW [V,P,3] (densification statistics need it per view,
  * GaussianDreamer.py:270-276); all other outputs are summed over the V views. */

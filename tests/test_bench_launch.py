@@ -44,3 +44,25 @@ def test_single_rank_stub_line():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip())
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_the_real_step_under_the_launcher_two_ranks_share_one_gpu_over_gloo():
+    """The REAL ``bench.py --gpus 2 --steps 2`` (round-4 review: the stub covers the launcher, not the step under it): the
+    process re-executes itself under torch.distributed.run with two ranks; GD_DIST_BACKEND=gloo lets both share the one GPU
+    of the test box (each renders its 4 of the 8 views with the full-size nets, gradients all-reduced through gloo).  One
+    JSON line, two ranks accounted for, four views per rank, a finite positive rate, a healthy scene."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "2", "--no-cpu-baseline"], {"GD_DIST_BACKEND": "gloo"}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo"
+    assert line["config"]["views_per_gpu"] == 4 and line["config"]["views"] == 8
+    assert line["steps"] == 2 and line["value"] > 0 and line["ms_per_step"] > 0
+    assert line["health"]["params_finite"] and line["health"]["visible_after_timed_steps"] > 0
+    assert line["config"]["batch_invariant"] is False and line["config"]["library_fallbacks"] == 0
+    assert "cpu_baseline" not in line and line["metric"].startswith("SDS iters/sec")

@@ -364,6 +364,57 @@ def test_batched_matches_per_view():
         assert float((vps[i].grad - pkg["viewspace_points"].grad[i]).abs().max()) <= 2e-4 * s
 
 
+@pytest.mark.parametrize("P,HW,V", [(3000, 96, 3), (20000, 256, 2)])
+def test_sync_free_forward_is_the_synchronising_forward_bit_for_bit(P, HW, V):
+    """gd_raster_forward_batched_capacity (round 5: no host read-back of the instance count, rasterizer_impl.cu:282 -- the
+    binning buffer is sized for a caller-chosen capacity, the kernels read the live count on the device): images, radii and
+    every gradient of the backward pass run on the capacity's layout are the bits of the synchronising path; the count comes
+    back through the deferred copy; a capacity below the instance count renders NOTHING, raises its flag, and the next call
+    raises."""
+    from garmentdreamer_amd import cameras as gcam
+    from garmentdreamer_amd.diff_gaussian_rasterization._C import InstanceCapacity
+    from garmentdreamer_amd.gaussian_renderer import render_batch
+    from garmentdreamer_amd.scene import GaussianParams, synthetic_gaussians
+    sc = synthetic_gaussians(P, seed=21)
+    batch = gcam.orbit_batch(V, height=HW, width=HW)
+    cams = [gcam.Camera(batch["c2w_3dgs"][i], batch["fovy"][i], HW, HW, data_device=DEV) for i in range(V)]
+    bg = torch.ones(3, device=DEV)
+    gi = torch.randn(V, 3, HW, HW, device=DEV, generator=torch.Generator(DEV).manual_seed(5))
+    gd_ = torch.randn(V, 1, HW, HW, device=DEV, generator=torch.Generator(DEV).manual_seed(6))
+
+    def run(capacity):
+        pc = GaussianParams(sc, device=DEV)
+        pkg = render_batch(cams, pc, bg, capacity=capacity)
+        ((pkg["render"] * gi).sum() + (pkg["depth_3dgs"] * gd_).sum() + pkg["alpha"].sum()).backward()
+        grads = [p.grad.clone() for _, p in pc.named_parameters() if p.grad is not None and p.grad.numel()]
+        return pkg, grads + [pkg["viewspace_points"].grad.clone()]
+
+    ref, g_ref = run(None)
+    cap = InstanceCapacity(margin=1.3, quantum=1 << 10)
+    first, _ = run(cap)                                 # no capacity yet: synchronises and seeds it
+    assert cap.value is not None and cap.calls_sync_free == 0 and cap.last_count > 0
+    R = cap.last_count
+    assert cap.value >= R and cap.value % (1 << 10) == 0
+    got, g_got = run(cap)                               # sync-free
+    assert cap.calls_sync_free == 1
+    for k in ("render", "depth_3dgs", "alpha", "radii"):
+        assert torch.equal(ref[k], first[k]) and torch.equal(ref[k], got[k]), k
+    for a, b in zip(g_ref, g_got):
+        assert torch.equal(a, b)
+    cap.collect()
+    assert cap.last_count == R
+    # overflow: a capacity one below the count
+    small = InstanceCapacity()
+    small.value = R - 1
+    over, _ = run(small)
+    assert torch.equal(over["render"], bg.view(1, 3, 1, 1).expand(V, 3, HW, HW)) and float(over["alpha"].abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="overflowed"):
+        small.collect()
+    assert small.value is None                          # the next call synchronises and re-seeds
+    again, _ = run(small)
+    assert torch.equal(again["render"], ref["render"]) and small.value is not None
+
+
 def _check_backward_dense(st, args, out, seed):
     """Backward parity for dense scenes.  This fork derives T_final = 1 - out_alpha (backward.cu:463); where most
     pixels saturate (T_final ~ 1e-4) one ulp of out_alpha is a 6e-4 relative change of every gradient term of that

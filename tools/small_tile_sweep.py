@@ -66,17 +66,21 @@ if what == "conv":
         print(f"N{n} {ci:4d}->{co:4d} @{hw:3d}: " + " | ".join(row) + f"  BEST {best[1]} {t_auto / best[0]:.2f}x", flush=True)
 else:
     levels = [(320, 4096), (640, 1024), (1280, 256), (1280, 64)]
-    for C, tok in levels:
-        M = N * tok
-        for K, Nn in ((C, C), (C, 2 * C), (C, 8 * C), (4 * C, C), (1024, 2 * C)):
-            Mx = M if K != 1024 else N * 77
+    if N >= 8:      # the 8-view step: the 256 x 256 and 128 x 256 tiles belong in the comparison, TF/s in the table
+        VARIANTS = {0: "128x128", 1: "128chx256px", 2: "256x256", 5: "64x128", 7: "128x64"}
+    shapes = [(N * tok, K, Nn) for C, tok in levels for K, Nn in ((C, C), (C, 2 * C), (C, 8 * C), (4 * C, C))]
+    shapes += [(N * 77, 1024, 24960)]                         # every cross-attention's K | V of the text tokens, one product
+    if N >= 8:
+        shapes += [(N // 2 * 4096, 512, 1536), (N // 2 * 4096, 512, 512), (N // 2 * 16384, 256, 512)]   # VAE: qkv, to_out, 1x1 shortcut
+    for Mx, K, Nn in shapes:
+        if True:
             x = torch.randn(Mx, K, device="cuda").to(torch.bfloat16)
             w = (torch.randn(Nn, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
             b = torch.randn(Nn, device="cuda").to(torch.bfloat16)
             with torch.no_grad():
                 ref = F.linear(x, w, b).float()
                 t0 = graph_time(lambda: F.linear(x, w, b))
-                row = [f"hipBLASLt {t0:6.1f}us"]
+                row = [f"hipBLASLt {t0:6.1f}us {2.0 * Mx * K * Nn / t0 / 1e6:5.0f}TF"]
                 best = (t0, "lib")
                 for v, name in VARIANTS.items():
                     force(v, 1)

@@ -22,7 +22,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "render_backward_block_kernel" in r["Kernel_Name"]]
 rows = rows[marks[3]:marks[-1]]; steps = len(marks) - 4
-for pat in ("conv3x3_nhwc_bf16_kernel<128, 128", "gn_stats_kernel", "Cijk"):
+for pat in ("conv3x3_nhwc_bf16_kernel<128, 128", "conv3x3_nhwc_bf16_kernel<256, 256", "conv_splitk", "Cijk"):
     agg = collections.OrderedDict()
     for r in rows:
         if pat in r["Kernel_Name"]:
