@@ -115,11 +115,18 @@ struct ConvGeom {
 
 // Tile = BN output channels x BM pixels, WN x WM waves, each wave (BN/WN) x (BM/WM) built from
 // 32x32x16 MFMAs.  bias_img_stride: 0 -> bias[co]; Cout -> bias[n][co].
-template <int BN, int BM, int WN, int WM>
-__global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
+// TR: the epilogue goes through LDS -- a wave parks its 64-channel x 64-pixel fp32 block in the (now free) stage memory and
+// reads it back pixel-major, so a lane adds bias / residual to EIGHT consecutive channels of one pixel and stores 16 bytes,
+// eight lanes covering the pixel's 128 contiguous bytes (the direct form: 64 scattered 8-byte stores per instruction).  Same
+// operations in the same order as the direct epilogue: bit-identical results.  Used where the K loop is short and the
+// epilogue IS the kernel: the parity classes of a stride-2 input gradient (1, 2, 2, 4 taps).  Needs FA = FB = 2, Cout % 8 = 0.
+constexpr int kTrPitch = 64 * 4 + 16;                  // bytes per pixel row of a wave's transposition block
+
+template <int BN, int BM, int WN, int WM, bool TR = false>
+__device__ __forceinline__ void conv3x3_nhwc_bf16_body(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
-    int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, const ConvGeom g,
-    int Cin, int Cout, int tiles_n, int nwg, float* __restrict__ partial, int steps_per_split)
+    int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, const ConvGeom& g,
+    int Cin, int Cout, int tiles_n, int nwg, float* __restrict__ partial, int steps_per_split, int bid_raw, int split_idx)
 {
     constexpr int THREADS = 64 * WN * WM;
     constexpr int NA = BM * 8 / THREADS;      // 16-B chunks of the pixel tile per thread per K-step
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware tile order: consecutive logical tiles (same pixel tile, different Cout tile, then
     // the next pixel tile) stay on one XCD's L2.
-    int bid = blockIdx.x;
+    int bid = bid_raw;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int tn = bid % tiles_n, tm = bid / tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
     const int kc = Cin / BK;         // K-steps per tap
     // split-K (small-M layers): blockIdx.y walks contiguous ranges of the (tap, channel step) sequence, fp32 partial
     // sums go to partial[split]
-    const int step0 = partial ? (int)blockIdx.y * steps_per_split : 0;
+    const int step0 = partial ? split_idx * steps_per_split : 0;
     const int step1 = partial ? min(g.ntaps * kc, step0 + steps_per_split) : g.ntaps * kc;
     const int nsteps = step1 - step0;
     const int tap0 = step0 / kc;
@@ -293,6 +300,56 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
         }
     }
 
+    if constexpr (TR) {
+        static_assert(FA == 2 && FB == 2, "transposed epilogue: 64 x 64 wave tiles");
+        __syncthreads();                               // every wave is past its last fragment read: the stages are free
+        char* tr = smem + wave * (64 * kTrPitch);
+#pragma unroll
+        for (int b = 0; b < FB; b++)
+#pragma unroll
+            for (int a = 0; a < FA; a++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    *(float4*)(tr + (b * 32 + frow) * kTrPitch + (a * 32 + 8 * q + 4 * fk) * 4) =
+                        make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+        __builtin_amdgcn_wave_barrier();               // (a wave's LDS operations execute in order: no counter wait needed)
+        const int cgrp = lane & 7, prow = lane >> 3;
+        const int co = n0 + wc * (BN / WN) + cgrp * 8;
+        // GEMM row of the lane's first pixel -> (image, grid point); the seven later ones are 8 rows further each
+        int64_t m = (int64_t)m0 + wp * (BM / WM) + prow;
+        int nimg = (int)(m / HW);
+        int rem = (int)(m - (int64_t)nimg * HW);
+        int ga = rem / g.Wg, gb = rem - ga * g.Wg;
+#pragma unroll 1
+        for (int it = 0; it < 8; it++) {
+            if (m < M && co < Cout) {
+                const char* src = tr + (it * 8 + prow) * kTrPitch + cgrp * 32;
+                const float4 lo = *(const float4*)src, hi = *(const float4*)(src + 16);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const size_t opix = ((size_t)nimg * g.Hout + (size_t)(ga * g.osy + g.ooy)) * g.Wout + (size_t)(gb * g.osx + g.oox);
+                if (bias) {
+                    const uint4 bb = *(const uint4*)(bias + (size_t)nimg * bias_img_stride + co);
+                    const uint32_t w[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((uint16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((uint16_t)(w[e] >> 16)); }
+                }
+                if (residual) {
+                    const uint4 rr = *(const uint4*)(residual + opix * Cout + co);
+                    const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((uint16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((uint16_t)(w[e] >> 16)); }
+                }
+                uint4 o;
+                o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
+                *(uint4*)(out + opix * Cout + co) = o;
+            }
+            m += 8;
+            gb += 8;
+            while (gb >= g.Wg) { gb -= g.Wg; ga++; }
+            while (ga >= g.Hg) { ga -= g.Hg; nimg++; }
+        }
+        return;
+    }
     // ---- epilogue: D[i = channel][j = pixel]; lane: pixel column lane&31, rows (reg&3)+8*(reg>>2)+4*(lane>>5)
 #pragma unroll
     for (int b = 0; b < FB; b++) {
@@ -319,7 +376,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
                     // the scattered partial stores were HALF the time of the one-view-per-GPU convolutions
                     // (tools/conv_small_ablate.py: 640 -> 640 @ 32^2, 2 latents, 32 -> 17 us without them)
                     // (split launches always use the 128 x 128 / 4-wave tile: launch_conv)
-                    *(float4*)(partial + (((size_t)blockIdx.y * nwg + bid) * (BN * BM / 4) +
+                    *(float4*)(partial + (((size_t)split_idx * nwg + bid) * (BN * BM / 4) +
                                           (((wave * FB + b) * FA + a) * 4 + q) * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
                     continue;
                 }
@@ -340,6 +397,40 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
             }
         }
     }
+}
+
+template <int BN, int BM, int WN, int WM>
+__global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_kernel(
+    const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
+    int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, const ConvGeom g,
+    int Cin, int Cout, int tiles_n, int nwg, float* __restrict__ partial, int steps_per_split)
+{
+    conv3x3_nhwc_bf16_body<BN, BM, WN, WM>(in, wt, bias, bias_img_stride, residual, out, Nimg, g, Cin, Cout, tiles_n, nwg,
+                                           partial, steps_per_split, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Up to four launches of the kernel above that differ only in their geometry (and weight tensor) as ONE launch:
+// blockIdx.z picks the class.  The parity classes of a stride-2 input gradient (4 + 2 + 2 + 1 taps) and of the
+// upsample-fused convolution (4 x 4 taps) were four back-to-back launches with K loops of 2-16 steps each -- four ramps,
+// four tails, and the one-tap class alone cannot cover its own epilogue; together the classes fill each other's gaps.
+struct ConvGeomSet {
+    ConvGeom g[4];
+    const uint16_t* wt[4];
+    int nwg[4];
+    int n;
+};
+
+template <int BN, int BM, int WN, int WM, bool TR>
+__global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_multi_kernel(
+    const uint16_t* __restrict__ in, const uint16_t* __restrict__ bias, int bias_img_stride,
+    const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, const ConvGeomSet gs, int Cin, int Cout,
+    int tiles_n)
+{
+    const int cls = (int)blockIdx.z;
+    const int nwg = gs.nwg[cls];
+    if ((int)blockIdx.x >= nwg) return;          // (workgroup-uniform) classes of ragged images differ by a tile row
+    conv3x3_nhwc_bf16_body<BN, BM, WN, WM, TR>(in, gs.wt[cls], bias, bias_img_stride, residual, out, Nimg, gs.g[cls], Cin,
+                                               Cout, tiles_n, nwg, nullptr, 0, (int)blockIdx.x, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -995,6 +1086,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
 // added in index order (deterministic).  Partials are tile images in the convolution's MFMA fragment order (coalesced
 // 16-byte accesses on both sides); GEMM row -> output pixel is the convolution's map (identity for stride-1 layers,
 // every second pixel for the parity classes of a stride-2 input gradient).
+template <int BM_T>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ partial, int S, int nwg,
                                                                  int tiles_n, int64_t M, int Cout, int HWg, int Wg, int Hout,
                                                                  int Wout, int osy, int osx, int ooy, int oox,
@@ -1002,19 +1094,21 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
                                                                  const uint16_t* __restrict__ residual,
                                                                  uint16_t* __restrict__ out)
 {
-    // one thread = one float4 of a 128 x 128 tile image in the convolution's fragment order:
-    //   r = (((wave * 2 + b) * 2 + a) * 4 + q) * 64 + lane   (wave = pixel half * 2 + channel half of the tile)
-    const int tile = blockIdx.x >> 4;
-    const int r = ((blockIdx.x & 15) << 8) | threadIdx.x;
+    // one thread = one float4 of a 128-channel x BM_T-pixel tile image in the convolution's fragment order:
+    //   r = (((wave * 2 + b) * 2 + a) * 4 + q) * 64 + lane   (wave = pixel block of 64 * 2 + channel half of the tile;
+    //   4 waves for the 128 x 128 tile, 8 for 128 channels x 256 pixels)
+    constexpr int kQuads = 128 * BM_T / 4, kBlocks = kQuads / 256;
+    const int tile = blockIdx.x / kBlocks;
+    const int r = ((blockIdx.x % kBlocks) << 8) | threadIdx.x;
     const int lane = r & 63, q = (r >> 6) & 3, a = (r >> 8) & 1, b = (r >> 9) & 1, wave = r >> 10;
     const int tn = tile % tiles_n, tm = tile / tiles_n;
-    const int64_t m = (int64_t)tm * 128 + (wave >> 1) * 64 + b * 32 + (lane & 31);
+    const int64_t m = (int64_t)tm * BM_T + (wave >> 1) * 64 + b * 32 + (lane & 31);
     const int co = tn * 128 + (wave & 1) * 64 + a * 32 + 8 * q + 4 * (lane >> 5);
     if (m >= M || co >= Cout) return;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* p = (const float4*)partial + (size_t)tile * 4096 + r;
+    const float4* p = (const float4*)partial + (size_t)tile * kQuads + r;
     for (int sidx = 0; sidx < S; sidx++) {
-        const float4 t = p[(size_t)sidx * nwg * 4096];
+        const float4 t = p[(size_t)sidx * nwg * kQuads];
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     const size_t nimg = (size_t)(m / HWg);
@@ -1292,10 +1386,10 @@ const char* gd_nn_conv_last_error(void) { return g_err; }
 // are dealt to 3 or 9 workgroups per tile, fp32 partials are combined by conv_splitk_reduce_kernel.
 // tools/splitk_sweep.py on MI355X (UNet maps at batch 1 and 2): the best split gives ~420 workgroups in flight while
 // every workgroup keeps >= 7-8 K-steps; beyond 24 ranges the fp32 partial traffic costs more than the idle CUs.
-static int pick_split(int64_t M, int64_t tiles, int steps)
+static int pick_split(int64_t M, int64_t tiles, int steps, int target = 420)
 {
     (void)M;
-    int s = (int)((420 + tiles / 2) / tiles);
+    int s = (int)((target + tiles / 2) / tiles);
     const int cap = steps * 2 / 15 < 24 ? steps * 2 / 15 : 24;
     if (s > cap) s = cap;
     return s < 2 ? 1 : s;
@@ -1305,7 +1399,24 @@ static int pick_split(int64_t M, int64_t tiles, int steps)
 // accumulators in MFMA fragment order, one contiguous 64 KB block per tile and K range)
 static size_t split_ws_bytes(int split, int64_t M, int Cout)
 {
-    return (size_t)split * (size_t)((M + 127) / 128) * (size_t)((Cout + 127) / 128) * 16384u * sizeof(float);
+    // (tiles of 128 channels x 128 pixels, or x 256 pixels -- split_tile_px; the pixel dimension padded to 256 covers both)
+    return (size_t)split * (size_t)((M + 255) / 256 * 2) * (size_t)((Cout + 127) / 128) * 16384u * sizeof(float);
+}
+
+// Pixel extent of the split-K tile: 256 (the 128-channel x 256-pixel / 8-wave tile) on the larger of the small maps -- a
+// layer whose whole filter bank is re-read once per pixel tile is bound by that traffic (1280 -> 1280 @ 8^2 x 16 latents:
+// 236 MB of weight reads in 51 us), and the longer tile halves it -- else 128.  GD_NN_SPLIT_PX=128/256 forces (A/B).
+int g_split_px = 0;
+static int split_tile_px(int64_t M, int Cout)
+{
+    static int env_read = 0;
+    if (!env_read) { if (const char* e = getenv("GD_NN_SPLIT_PX")) g_split_px = atoi(e); env_read = 1; }
+    if (g_split_px == 128 || g_split_px == 256) return g_split_px;
+    // profiles/r05_split_px_sweep.txt (UNet layers at 1 / 2 / 4 / 16 latents): the long tile wins from 1024 GEMM rows on when the
+    // layer has >= 8 channel tiles (1280-wide: 1.03-1.15x), from 2048 rows on otherwise (640-wide: 1.0-1.06x); below, the
+    // 128-pixel tile's finer split fills the chip better (up to 1.35x)
+    M *= g_route_scale;
+    return (M >= 1024 && Cout >= 1024) || M >= 2048 ? 256 : 128;
 }
 
 // Shallow, narrow layers on a half-empty tile grid (the UNet's 320 -> 320 convolutions on the 64^2 maps of one or two latents):
@@ -1324,10 +1435,13 @@ static int choose_split(int64_t M, int Cout, int ntaps, int Cin)
     const int steps = ntaps * (Cin / BK);
     if (g_force_split >= 0) return g_force_split > 1 && g_force_split <= steps ? g_force_split : 1;
     if (small_tile_nosplit(M, Cout, ntaps, Cin)) return 1;
+    const int px = split_tile_px(M, Cout);
     M *= g_route_scale;
-    const int64_t tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
+    if (((M + 127) / 128) * ((Cout + 127) / 128) >= 256) return 1;       // the unsplit 128 x 128 grid fills the chip
+    const int64_t tiles = ((M + px - 1) / px) * ((Cout + 127) / 128);
     if (tiles >= 256 || Cout % 8 || steps < 8) return 1;
-    return pick_split(M, tiles, steps);
+    // (the 8-wave 128 x 256 tile holds 96 KB of LDS: one workgroup per CU, so one wave of 256 workgroups is the target)
+    return pick_split(M, tiles, steps, px == 256 ? 256 : 420);
 }
 
 static int launch_conv(hipStream_t s, const void* x, const void* weight, const void* bias, int bias_img_stride,
@@ -1358,7 +1472,8 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
     const int total_steps = g.ntaps * (Cin / BK);
     const int tps = split > 1 ? (total_steps + split - 1) / split : total_steps;
     if (split > 1) split = (total_steps + tps - 1) / tps;   // no empty ranges
-    int variant = split > 1 ? 0 : g_force_variant;
+    const int spx = split > 1 ? split_tile_px(M, Cout) : 128;
+    int variant = split > 1 ? (spx == 256 ? 1 : 0) : g_force_variant;
     if (variant < 0 && small_tile_nosplit(M, Cout, g.ntaps, Cin)) variant = 6;
     if (variant < 0) {
         // rules distilled from tools/conv_kernel_bench.py on MI355X: the 256x256 tile wins whenever Cout fills it
@@ -1402,10 +1517,15 @@ static int launch_conv(hipStream_t s, const void* x, const void* weight, const v
     else GD_LAUNCH(128, 128, 2, 2);
 #undef GD_LAUNCH
     if (split > 1) {
-        const int tiles_n = (Cout + 127) / 128, nwg = (int)((M + 127) / 128) * tiles_n;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)nwg * 16u), dim3(256), 0, s, partial, split, nwg,
-                           tiles_n, M, Cout, g.Hg * g.Wg, g.Wg, g.Hout, g.Wout, g.osy, g.osx, g.ooy, g.oox,
-                           (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y);
+        const int tiles_n = (Cout + 127) / 128, nwg = (int)((M + spx - 1) / spx) * tiles_n;
+        if (spx == 256)
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<256>, dim3((unsigned)nwg * 32u), dim3(256), 0, s, partial, split, nwg,
+                               tiles_n, M, Cout, g.Hg * g.Wg, g.Wg, g.Hout, g.Wout, g.osy, g.osx, g.ooy, g.oox,
+                               (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y);
+        else
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<128>, dim3((unsigned)nwg * 16u), dim3(256), 0, s, partial, split, nwg,
+                               tiles_n, M, Cout, g.Hg * g.Wg, g.Wg, g.Hout, g.Wout, g.osy, g.osx, g.ooy, g.oox,
+                               (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y);
     }
     if (ea && eb) {
         (void)hipEventRecord(eb, s);
@@ -1428,6 +1548,109 @@ static void add_tap(ConvGeom& g, int dy, int dx, int widx)
     g.w4 |= (uint64_t)widx << (4 * g.ntaps);
     g.ntaps++;
 }
+
+// One launch for up to four geometries of the same layer (conv3x3_nhwc_bf16_multi_kernel).  Returns 1 if the classes were
+// launched, 0 if the shape wants split-K or differing tiles (the caller then launches the classes one by one), < 0 on error.
+int g_multi_class = 1;      // GD_NN_CONV_MULTI=0: the classes back to back as before round 5 (same-box A/B)
+static int launch_conv_multi(hipStream_t s, const void* x, const void* const* weights, const void* bias, int bias_img_stride,
+                             const void* residual, void* y, int N, ConvGeom* geoms, int ncls, int Cin, int Cout, bool may_split)
+{
+    static int env_read = 0;
+    if (!env_read) { if (const char* e = getenv("GD_NN_CONV_MULTI")) g_multi_class = atoi(e); env_read = 1; }
+    if (!g_multi_class || ncls < 2 || ncls > 4 || g_force_variant >= 0 || g_force_split >= 0) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(GD_NN_ERR_HIP, "hipGetDevice failed");
+    int64_t Mmax = 0, Msum = 0;
+    double flops = 0, bytes = 0;
+    for (int c = 0; c < ncls; c++) {
+        ConvGeom& g = geoms[c];
+        int minlin = 0;
+        for (int t = 0; t < g.ntaps; t++) {
+            const int dy = (int)((g.ty4 >> (4 * t)) & 15u) - 8, dx = (int)((g.tx4 >> (4 * t)) & 15u) - 8;
+            minlin = dy * g.Win + dx < minlin ? dy * g.Win + dx : minlin;
+        }
+        g.back = -minlin;
+        if (g.wtaps == 0) g.wtaps = 9;
+        if (((double)N * g.Hin * g.Win + g.back) * Cin * 2.0 >= 2147483648.0 || (double)Cout * 9.0 * Cin * 2.0 >= 2147483648.0)
+            return fail(GD_NN_ERR_INVALID_ARG, "conv3x3: activation / weight tensor must be < 2 GiB (32-bit buffer offsets)");
+        const int64_t M = (int64_t)N * g.Hg * g.Wg;
+        if (M <= 0) return 0;
+        if (may_split && choose_split(M, Cout, g.ntaps, Cin) > 1) return 0;     // small maps: the split-K path, class by class
+        Mmax = M > Mmax ? M : Mmax;
+        Msum += M;
+        flops += 2.0 * (double)M * Cout * (double)g.ntaps * Cin;
+        bytes += 2.0 * ((double)g.ntaps * Cin * Cout + (double)M * Cout + (residual ? (double)M * Cout : 0.0));
+    }
+    bytes += 2.0 * (double)N * geoms[0].Hin * geoms[0].Win * Cin;
+    // tile choice on the SUM of the classes' rows (they run concurrently), same rules as launch_conv
+    int variant = 0;
+    {
+        const int64_t Ms = Msum * g_route_scale;
+        const int64_t t256 = ((Ms + 255) / 256) * ((Cout + 255) / 256);
+        const int64_t t128x256 = ((Ms + 255) / 256) * ((Cout + 127) / 128);
+        if (Cout % 256 == 0 && t256 >= 192) variant = 2;
+        else if (t128x256 >= 512 && (Cin >= 512 || Ms >= (1 << 20))) variant = 1;
+    }
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (g_cprof.on) {
+        std::lock_guard<std::mutex> lk(g_cprof.mu);
+        ea = g_cprof.get(); eb = g_cprof.get();
+        if (ea && eb) (void)hipEventRecord(ea, s);
+    }
+#define GD_LAUNCH_M(BN_, BM_, WN_, WM_, TR_)                                                                       \
+    do {                                                                                                           \
+        auto kern = conv3x3_nhwc_bf16_multi_kernel<BN_, BM_, WN_, WM_, TR_>;                                       \
+        constexpr int lds_st = 2 * (BN_ + BM_) * BK * 2, lds_tr = TR_ ? WN_ * WM_ * 64 * kTrPitch : 0;             \
+        constexpr int lds = lds_st > lds_tr ? lds_st : lds_tr;                                                     \
+        static bool attr_set[16] = {false};                                                                        \
+        if (!attr_set[dev]) {                                                                                      \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);         \
+            attr_set[dev] = true;                                                                                  \
+        }                                                                                                          \
+        ConvGeomSet gs = {};                                                                                       \
+        gs.n = ncls;                                                                                               \
+        const int tiles_n = (Cout + BN_ - 1) / BN_;                                                                \
+        int nmax = 0;                                                                                              \
+        for (int c = 0; c < ncls; c++) {                                                                           \
+            gs.g[c] = geoms[c];                                                                                    \
+            gs.wt[c] = (const uint16_t*)weights[c];                                                                \
+            const int64_t M = (int64_t)N * geoms[c].Hg * geoms[c].Wg;                                              \
+            gs.nwg[c] = (int)((M + BM_ - 1) / BM_) * tiles_n;                                                      \
+            nmax = gs.nwg[c] > nmax ? gs.nwg[c] : nmax;                                                            \
+        }                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(nmax, 1, ncls), dim3(64 * WN_ * WM_), lds, s, (const uint16_t*)x,            \
+                           (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y, N, gs, \
+                           Cin, Cout, tiles_n);                                                                    \
+    } while (0)
+    // short K loops (the parity classes of a stride-2 input gradient: at most 4 taps): the LDS-transposed epilogue, which
+    // needs the 64 x 64 wave tile -- the 128-channel x 256-pixel tile then stands in for the 256 x 256 one
+    int max_steps = 0;
+    for (int c = 0; c < ncls; c++) max_steps = geoms[c].ntaps * (Cin / BK) > max_steps ? geoms[c].ntaps * (Cin / BK) : max_steps;
+    static int tr_mode = -1;      // GD_NN_CONV_TR=0: direct stores everywhere (A/B); 2: the transposed epilogue for every multi launch
+    if (tr_mode < 0) { const char* e = getenv("GD_NN_CONV_TR"); tr_mode = e ? atoi(e) : 1; }
+    const bool tr = Cout % 8 == 0 && (tr_mode == 2 || (tr_mode == 1 && max_steps <= 32));
+    if (tr) {
+        if (variant >= 1) GD_LAUNCH_M(128, 256, 2, 4, true);
+        else GD_LAUNCH_M(128, 128, 2, 2, true);
+    } else {
+        if (variant == 2) GD_LAUNCH_M(256, 256, 2, 4, false);
+        else if (variant == 1) GD_LAUNCH_M(128, 256, 2, 4, false);
+        else GD_LAUNCH_M(128, 128, 2, 2, false);
+    }
+#undef GD_LAUNCH_M
+    if (ea && eb) {
+        (void)hipEventRecord(eb, s);
+        std::lock_guard<std::mutex> lk(g_cprof.mu);
+        g_cprof.pending.push_back({ea, eb});
+        g_cprof.total_flops += flops;
+        g_cprof.total_bytes += bytes;
+    }
+    (void)Mmax;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return 1;
+}
+
 
 static int launch_patch(void* stream, const void* x, const float* mean_rstd, const void* gamma, const void* beta,
                         int groups, int apply_silu, const void* weight, const void* bias, int bias_img_stride,
@@ -1966,7 +2189,17 @@ int gd_nn_conv3x3_s2_dgrad_ws(void* stream, const void* dy, const void* weight_f
     // dx[2a+py, 2b+px] = sum over (ky, kx) with (py + pad - ky), (px + pad - kx) even of
     //                    dy[a + (py + pad - ky)/2, b + (px + pad - kx)/2] . w[:, ky, kx, :]
     // weight_flipped[ci][8 - (3 ky + kx)][co] = w[co][ky][kx][ci]  (gd_nn_conv3x3_flip_weights)
-    // The four classes run back to back on one stream and may share the scratch.
+    // One launch for the four classes where the maps are large (round 5); else back to back on one stream, sharing the scratch.
+    {
+        ConvGeom gs4[4];
+        const void* ws4[4];
+        int n = 0;
+        for (int py = 0; py < 2; py++)
+            for (int px = 0; px < 2; px++)
+                if (s2_dgrad_geom(gs4[n], Hin, Win, pad_lo, py, px)) ws4[n++] = weight_flipped;
+        const int r = launch_conv_multi((hipStream_t)stream, dy, ws4, nullptr, 0, nullptr, dx, N, gs4, n, Cout, Cin, ws != nullptr);
+        if (r != 0) return r < 0 ? r : GD_NN_OK;
+    }
     for (int py = 0; py < 2; py++)
         for (int px = 0; px < 2; px++) {
             ConvGeom g;
@@ -1994,6 +2227,8 @@ int gd_nn_conv3x3_up2_forward(void* stream, const void* x, const void* w_even_ro
     // where Wc sums the 3x3 taps that land on the same source pixel of the nearest-neighbour upsampled image
     // (rows: py = 0 -> {ky=0}, {ky=1,2};  py = 1 -> {ky=0,1}, {ky=2}; columns alike).  Tap (px, ty, tx) of row
     // parity py is filter slot px*4 + ty*2 + tx of w_even_rows / w_odd_rows ([Cout][9][Cin], slot 8 unused).
+    ConvGeom gs4[4];
+    const void* ws4[4];
     for (int py = 0; py < 2; py++)
         for (int px = 0; px < 2; px++) {
             ConvGeom g = {};
@@ -2004,9 +2239,18 @@ int gd_nn_conv3x3_up2_forward(void* stream, const void* x, const void* w_even_ro
             g.osy = g.osx = 2; g.ooy = py; g.oox = px;
             for (int ty = 0; ty < 2; ty++)
                 for (int tx = 0; tx < 2; tx++) add_tap(g, ty + py - 1, tx + px - 1, px * 4 + ty * 2 + tx);
-            const int r = launch_conv((hipStream_t)stream, x, py ? w_odd_rows : w_even_rows, bias, 0, nullptr, y, N, g, Cin, Cout);
-            if (r < 0) return r;
+            gs4[py * 2 + px] = g;
+            ws4[py * 2 + px] = py ? w_odd_rows : w_even_rows;
         }
+    {   // the four parity classes as one launch (round 5)
+        ConvGeom tmp[4] = {gs4[0], gs4[1], gs4[2], gs4[3]};
+        const int r = launch_conv_multi((hipStream_t)stream, x, ws4, bias, 0, nullptr, y, N, tmp, 4, Cin, Cout, false);
+        if (r != 0) return r < 0 ? r : GD_NN_OK;
+    }
+    for (int c = 0; c < 4; c++) {
+        const int r = launch_conv((hipStream_t)stream, x, ws4[c], bias, 0, nullptr, y, N, gs4[c], Cin, Cout);
+        if (r < 0) return r;
+    }
     return GD_NN_OK;
 }
 

@@ -39,6 +39,13 @@
 #define GD_BWD_CUT 12     // cut a window when its fullest block list overshoots a multiple of 16 by <= this many entries (0 = never)
 #endif
 
+#ifndef GD_BWD_ACC_PAD
+#define GD_BWD_ACC_PAD 0   // floats of padding after each half-row of the window's sum table (LDS bank spread; A/B builds)
+#endif
+#ifndef GD_BWD_ENT_PAD
+#define GD_BWD_ENT_PAD 0   // ... after each 12-float entry row
+#endif
+
 namespace gd {
 
 namespace {
@@ -46,6 +53,7 @@ namespace {
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int kAcc = 10;   // colour rgb, depth, mean2D xy, conic x/y/w, opacity
+constexpr int kAccRow = kAcc + GD_BWD_ACC_PAD, kEntRow = 12 + GD_BWD_ENT_PAD;
 constexpr int kWin = 64;   // strip entries per window (one per lane when the window is loaded)
 
 struct PixPair {           // per (block, pixel pair): 48 B, read as broadcast by the 16 lanes of the block's row
@@ -86,9 +94,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 {
     __shared__ PixPair s_px[4][8];              //  1.5 KB
     __shared__ f2 s_ga[4][8];                   //  256 B  dL/dalpha_image of the pixel pairs
-    __shared__ float s_ent[kWin][12];           //  3 KB   x, y, conic a b c, opacity, colour r g b, depth, ballot lo, hi
+    __shared__ __attribute__((aligned(16))) float s_ent[kWin][kEntRow];   //  3 KB   x, y, conic a b c, opacity, colour r g b, depth, ballot lo, hi
     __shared__ uint8_t s_sub[4][kWin];          //  256 B  per block: its entries' indices in the window, back to front
-    __shared__ float s_acc[kWin][2][kAcc];      //  5 KB   the ten sums of each entry of the window: blocks 0/1 | 2/3
+    __shared__ __attribute__((aligned(16))) float s_acc[kWin][2][kAccRow];   //  5 KB   the ten sums of each entry of the window: blocks 0/1 | 2/3
 
     // workgroup u runs on XCD u % 8: the four strips of a tile and neighbouring tiles share an XCD (and its L2)
     const uint32_t nblk = tiles_total * 4u;
@@ -192,8 +200,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint32_t my_n = blk == 0 ? nb[0] : blk == 1 ? nb[1] : blk == 2 ? nb[2] : nb[3];
         {
             float2* z = reinterpret_cast<float2*>(&s_acc[lane][0][0]);
+            float2* z1 = reinterpret_cast<float2*>(&s_acc[lane][1][0]);
 #pragma unroll
-            for (int k = 0; k < 10; k++) z[k] = make_float2(0.f, 0.f);
+            for (int k = 0; k < 5; k++) z[k] = z1[k] = make_float2(0.f, 0.f);
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -311,8 +320,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             float v[kAcc];
             {
                 const float2* src = reinterpret_cast<const float2*>(&s_acc[lane][0][0]);
+                const float2* src1 = reinterpret_cast<const float2*>(&s_acc[lane][1][0]);
 #pragma unroll
-                for (int k = 0; k < 5; k++) { const float2 t = src[k], u = src[k + 5]; v[2 * k] = t.x + u.x; v[2 * k + 1] = t.y + u.y; }
+                for (int k = 0; k < 5; k++) { const float2 t = src[k], u = src1[k]; v[2 * k] = t.x + u.x; v[2 * k + 1] = t.y + u.y; }
             }
             float2* dst = reinterpret_cast<float2*>(my_rows + (size_t)(n_listed - 1u - (w0 + lane)) * kAcc);
             dst[0] = make_float2(v[0], v[1]);
