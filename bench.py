@@ -312,7 +312,7 @@ def vsd_main(args):
     with torch.device(device):
         lora = sd21.init_random_(sd21.LoraUNet2DConditionModel(), 2)
     lora = lora.to(torch.bfloat16).to(memory_format=torch.channels_last)
-    lora.adapters_to_fp32()          # the reference trains the rank-4 adapters in fp32 (sd_vsd_utils.py:35); base weights bf16
+    lora.trainables_to_fp32()        # the reference trains adapters, camera MLP and shading embeddings in fp32 (sd_vsd_utils.py:35); base weights bf16
     train = lora.freeze_base()
     q = LoraUnet(lora)
     # trainer.py:137 steps torch.optim.Adam over the adapters + embeddings: here one launch over the flat fp32 adapter buffer

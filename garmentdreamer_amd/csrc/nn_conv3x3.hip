@@ -115,14 +115,7 @@ struct ConvGeom {
 
 // Tile = BN output channels x BM pixels, WN x WM waves, each wave (BN/WN) x (BM/WM) built from
 // 32x32x16 MFMAs.  bias_img_stride: 0 -> bias[co]; Cout -> bias[n][co].
-// TR: the epilogue goes through LDS -- a wave parks its 64-channel x 64-pixel fp32 block in the (now free) stage memory and
-// reads it back pixel-major, so a lane adds bias / residual to EIGHT consecutive channels of one pixel and stores 16 bytes,
-// eight lanes covering the pixel's 128 contiguous bytes (the direct form: 64 scattered 8-byte stores per instruction).  Same
-// operations in the same order as the direct epilogue: bit-identical results.  Used where the K loop is short and the
-// epilogue IS the kernel: the parity classes of a stride-2 input gradient (1, 2, 2, 4 taps).  Needs FA = FB = 2, Cout % 8 = 0.
-constexpr int kTrPitch = 64 * 4 + 16;                  // bytes per pixel row of a wave's transposition block
-
-template <int BN, int BM, int WN, int WM, bool TR = false>
+template <int BN, int BM, int WN, int WM>
 __device__ __forceinline__ void conv3x3_nhwc_bf16_body(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const uint16_t* __restrict__ bias,
     int bias_img_stride, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, const ConvGeom& g,
@@ -300,56 +293,6 @@ __device__ __forceinline__ void conv3x3_nhwc_bf16_body(
         }
     }
 
-    if constexpr (TR) {
-        static_assert(FA == 2 && FB == 2, "transposed epilogue: 64 x 64 wave tiles");
-        __syncthreads();                               // every wave is past its last fragment read: the stages are free
-        char* tr = smem + wave * (64 * kTrPitch);
-#pragma unroll
-        for (int b = 0; b < FB; b++)
-#pragma unroll
-            for (int a = 0; a < FA; a++)
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    *(float4*)(tr + (b * 32 + frow) * kTrPitch + (a * 32 + 8 * q + 4 * fk) * 4) =
-                        make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
-        __builtin_amdgcn_wave_barrier();               // (a wave's LDS operations execute in order: no counter wait needed)
-        const int cgrp = lane & 7, prow = lane >> 3;
-        const int co = n0 + wc * (BN / WN) + cgrp * 8;
-        // GEMM row of the lane's first pixel -> (image, grid point); the seven later ones are 8 rows further each
-        int64_t m = (int64_t)m0 + wp * (BM / WM) + prow;
-        int nimg = (int)(m / HW);
-        int rem = (int)(m - (int64_t)nimg * HW);
-        int ga = rem / g.Wg, gb = rem - ga * g.Wg;
-#pragma unroll 1
-        for (int it = 0; it < 8; it++) {
-            if (m < M && co < Cout) {
-                const char* src = tr + (it * 8 + prow) * kTrPitch + cgrp * 32;
-                const float4 lo = *(const float4*)src, hi = *(const float4*)(src + 16);
-                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const size_t opix = ((size_t)nimg * g.Hout + (size_t)(ga * g.osy + g.ooy)) * g.Wout + (size_t)(gb * g.osx + g.oox);
-                if (bias) {
-                    const uint4 bb = *(const uint4*)(bias + (size_t)nimg * bias_img_stride + co);
-                    const uint32_t w[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((uint16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((uint16_t)(w[e] >> 16)); }
-                }
-                if (residual) {
-                    const uint4 rr = *(const uint4*)(residual + opix * Cout + co);
-                    const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((uint16_t)(w[e] & 0xffff)); v[2 * e + 1] += bf2f((uint16_t)(w[e] >> 16)); }
-                }
-                uint4 o;
-                o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
-                *(uint4*)(out + opix * Cout + co) = o;
-            }
-            m += 8;
-            gb += 8;
-            while (gb >= g.Wg) { gb -= g.Wg; ga++; }
-            while (ga >= g.Hg) { ga -= g.Hg; nimg++; }
-        }
-        return;
-    }
     // ---- epilogue: D[i = channel][j = pixel]; lane: pixel column lane&31, rows (reg&3)+8*(reg>>2)+4*(lane>>5)
 #pragma unroll
     for (int b = 0; b < FB; b++) {
@@ -420,7 +363,7 @@ struct ConvGeomSet {
     int n;
 };
 
-template <int BN, int BM, int WN, int WM, bool TR>
+template <int BN, int BM, int WN, int WM>
 __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_multi_kernel(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ bias, int bias_img_stride,
     const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int Nimg, const ConvGeomSet gs, int Cin, int Cout,
@@ -429,8 +372,8 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_nhwc_bf16_multi_kernel(
     const int cls = (int)blockIdx.z;
     const int nwg = gs.nwg[cls];
     if ((int)blockIdx.x >= nwg) return;          // (workgroup-uniform) classes of ragged images differ by a tile row
-    conv3x3_nhwc_bf16_body<BN, BM, WN, WM, TR>(in, gs.wt[cls], bias, bias_img_stride, residual, out, Nimg, gs.g[cls], Cin,
-                                               Cout, tiles_n, nwg, nullptr, 0, (int)blockIdx.x, 0);
+    conv3x3_nhwc_bf16_body<BN, BM, WN, WM>(in, gs.wt[cls], bias, bias_img_stride, residual, out, Nimg, gs.g[cls], Cin, Cout,
+                                           tiles_n, nwg, nullptr, 0, (int)blockIdx.x, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1597,11 +1540,10 @@ static int launch_conv_multi(hipStream_t s, const void* x, const void* const* we
         ea = g_cprof.get(); eb = g_cprof.get();
         if (ea && eb) (void)hipEventRecord(ea, s);
     }
-#define GD_LAUNCH_M(BN_, BM_, WN_, WM_, TR_)                                                                       \
+#define GD_LAUNCH_M(BN_, BM_, WN_, WM_)                                                                            \
     do {                                                                                                           \
-        auto kern = conv3x3_nhwc_bf16_multi_kernel<BN_, BM_, WN_, WM_, TR_>;                                       \
-        constexpr int lds_st = 2 * (BN_ + BM_) * BK * 2, lds_tr = TR_ ? WN_ * WM_ * 64 * kTrPitch : 0;             \
-        constexpr int lds = lds_st > lds_tr ? lds_st : lds_tr;                                                     \
+        auto kern = conv3x3_nhwc_bf16_multi_kernel<BN_, BM_, WN_, WM_>;                                            \
+        constexpr int lds = 2 * (BN_ + BM_) * BK * 2;                                                              \
         static bool attr_set[16] = {false};                                                                        \
         if (!attr_set[dev]) {                                                                                      \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);         \
@@ -1622,21 +1564,11 @@ static int launch_conv_multi(hipStream_t s, const void* x, const void* const* we
                            (const uint16_t*)bias, bias_img_stride, (const uint16_t*)residual, (uint16_t*)y, N, gs, \
                            Cin, Cout, tiles_n);                                                                    \
     } while (0)
-    // short K loops (the parity classes of a stride-2 input gradient: at most 4 taps): the LDS-transposed epilogue, which
-    // needs the 64 x 64 wave tile -- the 128-channel x 256-pixel tile then stands in for the 256 x 256 one
-    int max_steps = 0;
-    for (int c = 0; c < ncls; c++) max_steps = geoms[c].ntaps * (Cin / BK) > max_steps ? geoms[c].ntaps * (Cin / BK) : max_steps;
-    static int tr_mode = -1;      // GD_NN_CONV_TR=0: direct stores everywhere (A/B); 2: the transposed epilogue for every multi launch
-    if (tr_mode < 0) { const char* e = getenv("GD_NN_CONV_TR"); tr_mode = e ? atoi(e) : 1; }
-    const bool tr = Cout % 8 == 0 && (tr_mode == 2 || (tr_mode == 1 && max_steps <= 32));
-    if (tr) {
-        if (variant >= 1) GD_LAUNCH_M(128, 256, 2, 4, true);
-        else GD_LAUNCH_M(128, 128, 2, 2, true);
-    } else {
-        if (variant == 2) GD_LAUNCH_M(256, 256, 2, 4, false);
-        else if (variant == 1) GD_LAUNCH_M(128, 256, 2, 4, false);
-        else GD_LAUNCH_M(128, 128, 2, 2, false);
-    }
+    // (An LDS-transposed epilogue for the short-K classes -- 16-byte stores, eight lanes per pixel row -- was built and measured
+    // in round 5: 43.68 / 43.76 ms per 8-view step against 43.62 / 43.63 with the direct 8-byte stores, same box; removed.)
+    if (variant == 2) GD_LAUNCH_M(256, 256, 2, 4);
+    else if (variant == 1) GD_LAUNCH_M(128, 256, 2, 4);
+    else GD_LAUNCH_M(128, 128, 2, 2);
 #undef GD_LAUNCH_M
     if (ea && eb) {
         (void)hipEventRecord(eb, s);

@@ -20,7 +20,8 @@ the reference's behaviour for tensors that DO receive a gradient on every step, 
 names it (``flat=`` -- the rank-4 adapters, every one of which is on the path of every UNet call; ``for_lora_unet``
 picks exactly those).  Everything else -- the camera MLP, the three shading embeddings of which one is used per step
 (lora_unet.py:632-645), anything not fp32 or not on the GPU -- is stepped by a plain ``torch.optim.Adam`` over just
-those few tensors, with torch's skipping and per-parameter step counts.
+those few tensors, with torch's skipping and per-parameter step counts (round 5: for fp32 GPU tensors by the same HIP
+kernel, one small launch per tensor that has a gradient -- same update rule, no foreach host work).
 
 ``param_groups`` is ONE list holding ONE dict, created once: ``for g in opt.param_groups: g["lr"] = x`` changes the
 learning rate of both halves, as with a torch optimizer; ``step()`` reads lr / betas / eps from that dict.
@@ -59,6 +60,15 @@ class FlatAdam:
         ids = {id(p) for p in flat}
         rest = [p for p in self.params if id(p) not in ids]
         self._flat_set = flat
+        # the others: fp32 GPU tensors keep torch's semantics (skipped while .grad is None, their own step count) but are
+        # stepped by the same HIP kernel, one small launch per tensor THAT HAS A GRADIENT (the NeTF stage: the camera MLP's
+        # four tensors and the one shading embedding of the step) -- torch.optim.Adam's foreach path over them was ~0.4 ms of
+        # host work with the GPU idle between the backward pass and the optimizer (profiles/r04_bench_vsd_gaps.txt);
+        # anything else (bf16, CPU) goes to torch.optim.Adam
+        self._solo = [p for p in rest if p.is_cuda and p.dtype == torch.float32]
+        self._solo_state = {}
+        solo_ids = {id(p) for p in self._solo}
+        rest = [p for p in rest if id(p) not in solo_ids]
         self._rest = torch.optim.Adam(rest, lr=self.lr, betas=self.betas, eps=self.eps) if rest else None
         if not flat:
             return
@@ -90,13 +100,19 @@ class FlatAdam:
     def zero_grad(self, set_to_none: bool = True):
         if self._flat_set:
             self._grad.zero_()
+        for p in self._solo:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
         if self._rest is not None:
             self._rest.zero_grad(set_to_none=set_to_none)
 
     @classmethod
     def for_lora_unet(cls, unet, params: Iterable[torch.Tensor], **kw):
         """The optimizer of ``sd21.LoraUNet2DConditionModel``: its rank-4 adapters (``unet.lora_layers``, on the path of every
-        UNet call) in the flat set, the camera MLP and the shading embeddings under torch's Adam."""
+        UNet call) in the flat set, the camera MLP and the shading embeddings stepped with torch's skip semantics."""
         return cls(params, flat=list(unet.lora_layers.parameters()), **kw)
 
     @property
@@ -139,6 +155,23 @@ class FlatAdam:
                     torch.cuda.current_stream(dev).cuda_stream, self._flat.data_ptr(), self._grad.data_ptr(),
                     self._exp_avg.data_ptr(), self._exp_avg_sq.data_ptr(), self._flat.numel(), 1, self._ends, lrs,
                     self.betas[0], self.betas[1], self.eps, self.step_count), "gd_scene_adam_step")
+        for p in self._solo:
+            g = p.grad
+            if g is None:
+                continue                      # torch.optim.Adam skips it: no moment decay, its step count stands still
+            st = self._solo_state.get(id(p))
+            if st is None:
+                st = self._solo_state[id(p)] = [0, torch.zeros_like(p, memory_format=torch.contiguous_format),
+                                                torch.zeros_like(p, memory_format=torch.contiguous_format)]
+            if not (p.is_contiguous() and g.is_contiguous() and g.dtype == torch.float32):
+                raise RuntimeError("FlatAdam: fp32 parameters and their gradients must be contiguous fp32 tensors")
+            st[0] += 1
+            n = p.numel()
+            with torch.cuda.device(p.device):
+                _native.check_scene(_native.lib().gd_scene_adam_step(
+                    torch.cuda.current_stream(p.device).cuda_stream, p.data_ptr(), g.data_ptr(), st[1].data_ptr(),
+                    st[2].data_ptr(), n, 1, (C.c_int64 * 1)(n), (C.c_double * 1)(self.lr), self.betas[0], self.betas[1],
+                    self.eps, st[0]), "gd_scene_adam_step")
         if self._rest is not None:
             for grp in self._rest.param_groups:
                 grp["lr"], grp["betas"], grp["eps"] = self.lr, self.betas, self.eps

@@ -672,6 +672,16 @@ class LoraUNet2DConditionModel(UNet2DConditionModel):
         self.lora_layers.float()
         return self
 
+    def trainables_to_fp32(self):
+        """Adapters AND the camera MLP / shading embeddings in fp32 (the reference trains every one of them in fp32,
+        sd_vsd_utils.py:35 / trainer.py:129-137); the frozen base stays bf16.  ``extra_embedding`` computes in the MLP's dtype
+        and casts the [B, 1280] result to the time embedding's."""
+        self.adapters_to_fp32()
+        self.camera_emb.float()
+        for p in (self.lambertian_emb, self.textureless_emb, self.normal_emb):
+            p.data = p.data.float()
+        return self
+
     def freeze_base(self):
         for p in self.parameters():
             p.requires_grad_(False)

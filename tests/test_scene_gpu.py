@@ -95,8 +95,13 @@ def test_flat_adam_over_many_small_tensors_matches_torch_adam():
     sparse = torch.nn.Parameter(torch.randn(9, device=DEV, generator=g))                                    # excluded, never a gradient
     ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
     unused = torch.nn.Parameter(torch.randn(12, device=DEV, generator=g))      # fp32, NOT named in `flat`: torch's Adam, skipped while .grad is None
-    opt = FlatAdam(mine + [sparse, unused], lr=3e-3, flat=mine + [sparse], exclude=[sparse])
-    ropt = torch.optim.Adam(ref, lr=3e-3)
+    # fp32, not in the flat set, a gradient on SOME steps only (the shading embedding of the step): torch's skip semantics --
+    # no moment decay and no step count on the steps without one -- through the HIP kernel, one launch per tensor with a gradient
+    solo = torch.nn.Parameter(torch.randn(33, 5, device=DEV, generator=g))
+    solo_ref = torch.nn.Parameter(solo.detach().clone())
+    opt = FlatAdam(mine + [sparse, unused, solo], lr=3e-3, flat=mine + [sparse], exclude=[sparse])
+    ropt = torch.optim.Adam(ref + [solo_ref], lr=3e-3)
+    assert opt._rest is not None and len(opt._solo) == 3 and not hasattr(solo, "_gd_grad_sink")
     assert all(p.data_ptr() % 256 == 0 and p.grad is p._gd_grad_sink for p in mine[:-1])    # re-seated, aligned views of one buffer
     assert mine[-1].grad is None and not hasattr(sparse, "_gd_grad_sink") and not hasattr(unused, "_gd_grad_sink")
     unused0 = unused.detach().clone()
@@ -117,6 +122,11 @@ def test_flat_adam_over_many_small_tensors_matches_torch_adam():
             else:
                 p._gd_grad_sink.add_(gr / 2)     # what the LoRA backward kernels do, twice (accumulation)
                 p._gd_grad_sink.add_(gr / 2)
+        if it in (0, 2, 3, 5):
+            gr = torch.randn(solo.shape, device=DEV, generator=g)
+            solo.grad, solo_ref.grad = gr.clone(), gr.clone()
+        else:
+            assert solo.grad is None and solo_ref.grad is None
         if it == 4:
             for grp in opt.param_groups:         # the torch idiom (it used to edit a throw-away dict)
                 grp["lr"] = 1e-3
@@ -129,6 +139,8 @@ def test_flat_adam_over_many_small_tensors_matches_torch_adam():
             tol = dict(rtol=2e-6, atol=2e-7) if p.dtype == torch.float32 else dict(rtol=0, atol=0)
             assert torch.allclose(p.detach().float(), q.detach().float(), **tol), (it, p.shape)
         assert all(p.grad is p._gd_grad_sink for p in mine[:-1])
+        assert torch.allclose(solo.detach(), solo_ref.detach(), rtol=2e-6, atol=2e-7), it
+    assert opt._solo_state[id(solo)][0] == 4
     assert torch.equal(sparse.detach(), sparse0) and torch.equal(unused.detach(), unused0)
     assert opt.flat_grad.numel() == sum((p.numel() + 63) // 64 * 64 for p in mine[:-1])
 
