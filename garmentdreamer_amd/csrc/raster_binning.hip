@@ -332,6 +332,33 @@ __global__ void tile_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t L
     if (idx == L - 1) ranges[cur].y = L;
 }
 
+// perm = the tiles ordered by descending list length (buckets of 8 entries, 256 buckets; the order inside a bucket is whatever
+// the atomics give: it only decides WHEN a tile's workgroup runs, never a result).  One workgroup.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, uint32_t n, uint32_t* __restrict__ perm)
+{
+    __shared__ uint32_t cnt[256], off[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 256u) cnt[tid] = 0u;
+    __syncthreads();
+    for (uint32_t t = tid; t < n; t += 1024u) {
+        const uint2 r = ranges[t];
+        const uint32_t b = 255u - min((r.y - r.x) >> 3, 255u);
+        atomicAdd(&cnt[b], 1u);
+    }
+    __syncthreads();
+    if (tid < 256u) {            // exclusive scan of 256 counters: serial per thread over its predecessors (tiny)
+        uint32_t acc = 0u;
+        for (uint32_t i = 0; i < tid; i++) acc += cnt[i];
+        off[tid] = acc;
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < n; t += 1024u) {
+        const uint2 r = ranges[t];
+        const uint32_t b = 255u - min((r.y - r.x) >> 3, 255u);
+        perm[atomicAdd(&off[b], 1u)] = t;
+    }
+}
+
 template <int BITS>
 void sort_pass(hipStream_t s, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, uint32_t n,
                int shift, int width, uint32_t* hist, uint32_t nblk, const uint32_t* n_dev)
@@ -346,6 +373,11 @@ void sort_pass(hipStream_t s, const uint64_t* kin, const uint32_t* vin, uint64_t
 }
 
 }  // namespace
+
+void launch_tile_order(hipStream_t s, const uint2* ranges, uint32_t tiles_total, uint32_t* perm)
+{
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, tiles_total, perm);
+}
 
 void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks, uint32_t* info, uint32_t capacity)
 {

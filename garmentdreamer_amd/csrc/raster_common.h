@@ -41,6 +41,7 @@ struct ImageState {
     uint32_t* n_contrib;  // [V*H*W]
     uint2* pair_counts;   // [V*H*W] {visited, blended} per pixel (work accounting for the roofline)
     uint32_t* strip_count;  // [V*tiles*4] entries of each 16x4 strip's compact list (see BinningState::clist)
+    uint32_t* tile_perm;    // [V*tiles] tiles by descending list length (launch order of the blend kernels; tile_order_kernel)
 };
 struct BinningState {
     uint32_t* point_list;      // [R] sort payload = instance SLOT (see slot_vp); after tile_ranges: the Gaussian (vp) ids
@@ -110,17 +111,18 @@ void launch_radix_sort(hipStream_t s, BinningState b, uint32_t R, SortPlan plan,
 void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* ranges, uint32_t tiles_total,
                         uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of, const uint32_t* n_dev = nullptr);
 
+void launch_tile_order(hipStream_t s, const uint2* ranges, uint32_t tiles_total, uint32_t* perm);
 void launch_blend_exp(hipStream_t s, const float* x, float* y, int n);   // y = gd_expf(x): parity test hook
 void launch_poison_lds(hipStream_t s);                                   // NaN patterns into every CU's LDS: test hook
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
                            float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts,
-                           const uint32_t* slot_of, uint4* clist, uint32_t* strip_count, uint32_t* rowpos);
+                           const uint32_t* slot_of, uint4* clist, uint32_t* strip_count, uint32_t* rowpos, const uint32_t* tile_perm = nullptr);
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const GeomState& g, const float* bg, const float* alphas, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas,
                             float* rows /*[4R][10]: the row of sums of clist entry i at index i*/, const uint4* clist,
-                            const uint32_t* strip_count);
+                            const uint32_t* strip_count, const uint32_t* tile_perm = nullptr);
 
 
 }  // namespace gd

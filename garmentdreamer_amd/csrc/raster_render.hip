@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     const float* __restrict__ bg_color,
     float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     uint32_t* __restrict__ n_contrib, uint2* __restrict__ pair_counts, const uint32_t* __restrict__ slot_of,
-    uint4* __restrict__ clist, uint32_t* __restrict__ strip_count, uint32_t* __restrict__ rowpos)
+    uint4* __restrict__ clist, uint32_t* __restrict__ strip_count, uint32_t* __restrict__ rowpos,
+    const uint32_t* __restrict__ tile_perm)
 {
     // every blend operation is rounded on its own, like the oracle's (-ffp-contract=off): images match it bit for bit
 #pragma clang fp contract(off)
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kTilePix) void render_forward_kernel(
     __shared__ uint32_t s_mask[kTilePix];  // strip_alive_mask per staged entry (0 beyond the list end)
     __shared__ __attribute__((aligned(4))) uint8_t s_idx[4][68];   // per wave: compact list of the current 64 entries it must walk
 
-    const uint32_t tile = block_to_tile(blockIdx.x, tiles_total);
+    const uint32_t tile = tile_perm ? tile_perm[blockIdx.x] : block_to_tile(blockIdx.x, tiles_total);
     const uint32_t tpv = gx * gy;
     const uint32_t view = tile / tpv;
     const uint32_t lt = tile - view * tpv;
@@ -273,12 +274,13 @@ void launch_blend_exp(hipStream_t s, const float* x, float* y, int n)
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                            const uint32_t* point_list, const GeomState& g, const float* bg, float* out_color,
                            float* out_depth, float* out_alpha, uint32_t* n_contrib, uint2* pair_counts,
-                           const uint32_t* slot_of, uint4* clist, uint32_t* strip_count, uint32_t* rowpos)
+                           const uint32_t* slot_of, uint4* clist, uint32_t* strip_count, uint32_t* rowpos,
+                           const uint32_t* tile_perm)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
     hipLaunchKernelGGL(render_forward_kernel, dim3(tiles_total), dim3(kTilePix), 0, s, W, H, (uint32_t)tiles_x,
                        (uint32_t)tiles_y, tiles_total, ranges, point_list, g.means2D, g.conic_opacity, g.alpha_thr, g.rgbd, bg,
-                       out_color, out_depth, out_alpha, n_contrib, pair_counts, slot_of, clist, strip_count, rowpos);
+                       out_color, out_depth, out_alpha, n_contrib, pair_counts, slot_of, clist, strip_count, rowpos, tile_perm);
 }
 
 }  // namespace gd

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd,
     const float* __restrict__ bg_color, const float* __restrict__ alphas, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dalphas, float* __restrict__ rows,
-    const uint4* __restrict__ clist, const uint32_t* __restrict__ strip_count)
+    const uint4* __restrict__ clist, const uint32_t* __restrict__ strip_count, const uint32_t* __restrict__ tile_perm)
 {
     __shared__ PixPair s_px[4][8];              //  1.5 KB
     __shared__ f2 s_ga[4][8];                   //  256 B  dL/dalpha_image of the pixel pairs
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // workgroup u runs on XCD u % 8: the four strips of a tile and neighbouring tiles share an XCD (and its L2)
     const uint32_t nblk = tiles_total * 4u;
     uint32_t unit = blockIdx.x;
-    if ((nblk & 7u) == 0) unit = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+    if (tile_perm) unit = tile_perm[blockIdx.x >> 2] * 4u + (blockIdx.x & 3u);      // longest tile lists first (tile_order_kernel)
+    else if ((nblk & 7u) == 0) unit = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
     const uint32_t n_listed = strip_count[unit];     // strip_count[tile * 4 + strip]
     if (n_listed == 0) return;                       // nobody in this strip blended anything: no rows
     const uint32_t tile = unit >> 2;
@@ -357,12 +358,12 @@ void launch_poison_lds(hipStream_t s)
 void launch_render_backward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,
                             const GeomState& g, const float* bg, const float* alphas, const float* dL_dpix,
                             const float* dL_dpix_depth, const float* dL_dalphas, float* rows, const uint4* clist,
-                            const uint32_t* strip_count)
+                            const uint32_t* strip_count, const uint32_t* tile_perm)
 {
     const uint32_t tiles_total = (uint32_t)V * tiles_x * tiles_y;
     hipLaunchKernelGGL(render_backward_block_kernel, dim3(tiles_total * 4u), dim3(64), 0, s, W, H, (uint32_t)tiles_x,
                        (uint32_t)tiles_y, tiles_total, ranges, g.means2D, g.conic_opacity, g.rgbd, bg, alphas, dL_dpix,
-                       dL_dpix_depth, dL_dalphas, rows, clist, strip_count);
+                       dL_dpix_depth, dL_dalphas, rows, clist, strip_count, tile_perm);
 }
 
 }  // namespace gd
