@@ -11,10 +11,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # steady part: the last 6 iterations; an iteration ends with AdamW's multi-tensor kernel -> use time: last 60 % of the span is safe
 t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
-# iteration marks: the first AdamW multi-tensor kernel of each optimizer step (successive ones > 5 ms apart)
+# iteration marks: the first optimizer kernel of each step (gd::adam_kernel since round 5, torch's multi-tensor kernel before;
+# successive ones > 5 ms apart)
 marks, last = [], -1e18
 for i, r in enumerate(rows):
-    if "multi_tensor_apply" in r["Kernel_Name"]:
+    if "multi_tensor_apply" in r["Kernel_Name"] or "adam_kernel" in r["Kernel_Name"]:
         t = int(r["Start_Timestamp"])
         if t - last > 5e6:
             marks.append(i)
