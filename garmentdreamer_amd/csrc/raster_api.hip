@@ -272,11 +272,14 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     return (int)num_rendered;
 }
 
+// The backward blend keeps the index order: in the forward pass's longest-first order it is 5 % faster (0.221 -> 0.208 ms) but
+// fetches 5 x the bytes (FETCH_SIZE 80 -> 402 MB per launch: the four strips of a tile and its neighbours no longer run together,
+// so the gathered centres / conics / colours miss L2) -- profiles/r05_lpt_ab.txt.  GD_RASTER_LPT_BWD=1 turns it on for A/B.
 static bool bwd_lpt()
 {
     static const bool on = [] {
         const char* a = getenv("GD_RASTER_LPT"); const char* b = getenv("GD_RASTER_LPT_BWD");
-        return (!a || atoi(a) != 0) && (!b || atoi(b) != 0);
+        return (!a || atoi(a) != 0) && (b && atoi(b) != 0);
     }();
     return on;
 }
@@ -319,7 +322,6 @@ int backward_impl(hipStream_t stream, int V, int P, int D, int M, int R, const f
         { ProfScope ps(stream, GD_K_RENDER_BWD);
         launch_render_backward(stream, V, W, H, dm.tiles_x, dm.tiles_y, img.ranges, geom, background, alphas, dL_dpix,
                                dL_dpix_depth, dL_dalphas, rows, bin.clist, img.strip_count,
-                               // the forward pass's tile order (longest lists first), if it made one: GD_RASTER_LPT_BWD=0 for A/B
                                bwd_lpt() && dm.tiles_total >= 512 ? img.tile_perm : nullptr); }
     }
     if (int e = check_debug(stream, debug, "render backward")) return e;

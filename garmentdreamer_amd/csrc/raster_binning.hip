@@ -332,30 +332,35 @@ __global__ void tile_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t L
     if (idx == L - 1) ranges[cur].y = L;
 }
 
-// perm = the tiles ordered by descending list length (buckets of 8 entries, 256 buckets; the order inside a bucket is whatever
-// the atomics give: it only decides WHEN a tile's workgroup runs, never a result).  One workgroup.
+// perm = the launch order of the blend kernels' workgroups: longest tile lists first, XCD by XCD.  Workgroup b runs on XCD
+// b % 8 (observed; a speed hint only) and every XCD has its own L2, so -- as in the index order it replaces -- XCD x keeps the
+// contiguous BAND x of n / 8 tiles (neighbouring tiles share most of their Gaussians); inside a band the tiles go by descending
+// list length (buckets of 8 entries; the order inside a bucket is whatever the atomics give: it only decides WHEN a tile's
+// workgroup runs, never a result).  perm[8 r + x] = the r-th longest tile of band x.  n % 8 != 0: one band, plain descending order.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, uint32_t n, uint32_t* __restrict__ perm)
 {
-    __shared__ uint32_t cnt[256], off[256];
+    __shared__ uint32_t cnt[8][256], off[8][256];
     const uint32_t tid = threadIdx.x;
-    if (tid < 256u) cnt[tid] = 0u;
+    const uint32_t nb = (n & 7u) == 0u ? 8u : 1u, per = n / nb;
+    for (uint32_t i = tid; i < 8u * 256u; i += 1024u) (&cnt[0][0])[i] = 0u;
     __syncthreads();
     for (uint32_t t = tid; t < n; t += 1024u) {
         const uint2 r = ranges[t];
-        const uint32_t b = 255u - min((r.y - r.x) >> 3, 255u);
-        atomicAdd(&cnt[b], 1u);
+        atomicAdd(&cnt[t / per][255u - min((r.y - r.x) >> 3, 255u)], 1u);
     }
     __syncthreads();
-    if (tid < 256u) {            // exclusive scan of 256 counters: serial per thread over its predecessors (tiny)
+    for (uint32_t i = tid; i < nb * 256u; i += 1024u) {     // exclusive scan per band: serial over the predecessors (tiny)
+        const uint32_t band = i >> 8, bk = i & 255u;
         uint32_t acc = 0u;
-        for (uint32_t i = 0; i < tid; i++) acc += cnt[i];
-        off[tid] = acc;
+        for (uint32_t j = 0; j < bk; j++) acc += cnt[band][j];
+        off[band][bk] = acc;
     }
     __syncthreads();
     for (uint32_t t = tid; t < n; t += 1024u) {
         const uint2 r = ranges[t];
-        const uint32_t b = 255u - min((r.y - r.x) >> 3, 255u);
-        perm[atomicAdd(&off[b], 1u)] = t;
+        const uint32_t band = t / per;
+        const uint32_t rank = atomicAdd(&off[band][255u - min((r.y - r.x) >> 3, 255u)], 1u);
+        perm[rank * nb + band] = t;
     }
 }
 
