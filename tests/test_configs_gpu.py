@@ -342,8 +342,8 @@ def test_config4_lora_gradients_at_a_trained_state_match_eager_fp32():
     one vector) is all two runs of ANY implementation agree to.  Here the fp32 eager network first takes five Adam steps
     (lr 1e-3) on the LoRA denoising loss -- the up-projections are then non-zero and the gradient is a signal, not a
     cancellation residue --, the trained adapters / embeddings are copied into the bf16 HIP network, and the gradients of one
-    more iteration on identical inputs are compared: bar cos >= 0.99 on all adapter gradients as one vector, and the median
-    per-tensor cosine >= 0.95."""
+    more iteration on identical inputs are compared: bar cos >= 0.999 on all adapter gradients as one vector and on the median
+    tensor, >= 0.99 on the worst tensor (measured 0.99997 / 0.99997 / 0.9998)."""
     kw_u = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4))
     kw_v = dict(block_out_channels=(64, 64, 128, 128))
     gd32, lora32, train32, q32 = _vsd_objects(kw_u, kw_v, torch.float32)
@@ -370,8 +370,9 @@ def test_config4_lora_gradients_at_a_trained_state_match_eager_fp32():
                          cos_all_lora_grads=c_all, cos_median_per_tensor=c_med, cos_min_per_tensor=c_min,
                          cos_latents=_cos(lat32, lat16), cos_dL_dimage=_cos(di32, di16), rel_dlora_loss=abs(lu32 - lu16) / abs(lu32))
     assert abs(lu32 - lu16) <= 2e-2 * abs(lu32)
-    assert c_all >= 0.99, (c_all, c_med, c_min)
-    assert c_med >= 0.95, (c_all, c_med, c_min)
+    # measured 0.99997 / 0.99997 / 0.9998 (profiles/r05_parity_report.json); the review's bar was 0.99
+    assert c_all >= 0.999, (c_all, c_med, c_min)
+    assert c_med >= 0.999 and c_min >= 0.99, (c_all, c_med, c_min)
 
 
 def test_config4_vsd_step_hipgraph_replay_matches_eager():
