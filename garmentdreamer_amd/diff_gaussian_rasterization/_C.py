@@ -180,14 +180,16 @@ class InstanceCapacity:
     (rasterizer_impl.cu:282) -- the only stream synchronisation of the iteration.  With an ``InstanceCapacity`` handed to
     ``rasterize_gaussians_batched`` the binning buffer is sized for ``capacity`` instances instead, the kernels read the live
     count on the device, and the count comes back through a DEFERRED asynchronous copy into pinned memory that the NEXT call
-    looks at (by then it landed long ago): it re-sizes the capacity (``margin`` x the last count, rounded up to ``quantum``)
-    and RAISES if the previous call overflowed -- that call binned nothing (every view shows the background), so its results,
+    looks at (by then it landed long ago): it re-sizes the capacity (``margin`` x the LARGEST count of the last ``window`` calls,
+    rounded up to ``quantum`` -- a training loop draws a new random camera batch every iteration, so the count moves from call
+    to call) and RAISES if the previous call overflowed -- that call binned nothing (every view shows the background), so its results,
     and whatever an optimizer did with them, are void; a loop that cannot tolerate that uses a larger margin or
     ``reset()`` (the next call then takes the synchronising path once and re-seeds the capacity) whenever the scene changes
     abruptly (densification).  The first call, or any call after ``reset()``, synchronises like the reference."""
 
-    def __init__(self, margin: float = 1.5, quantum: int = 1 << 16):
-        self.margin, self.quantum = float(margin), int(quantum)
+    def __init__(self, margin: float = 1.5, quantum: int = 1 << 16, window: int = 32):
+        self.margin, self.quantum, self.window = float(margin), int(quantum), int(window)
+        self._recent = []            # counts of the last `window` calls
         self.value = None            # capacity of the next call; None -> synchronising path
         self.last_count = None       # num_rendered of the most recent call whose count has been read
         self.calls_sync_free = 0
@@ -197,10 +199,12 @@ class InstanceCapacity:
     def reset(self):
         self.collect()
         self.value = None
+        self._recent = []
 
     def _round(self, n: int) -> int:
+        self._recent = (self._recent + [int(n)])[-self.window:]
         q = self.quantum
-        return max(q, (int(n * self.margin) + q - 1) // q * q)
+        return max(q, (int(max(self._recent) * self.margin) + q - 1) // q * q)
 
     def seed(self, num_rendered: int):
         self.last_count = int(num_rendered)
