@@ -272,14 +272,14 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     return (int)num_rendered;
 }
 
-// The backward blend keeps the index order: in the forward pass's longest-first order it is 5 % faster (0.221 -> 0.208 ms) but
-// fetches 5 x the bytes (FETCH_SIZE 80 -> 402 MB per launch: the four strips of a tile and its neighbours no longer run together,
-// so the gathered centres / conics / colours miss L2) -- profiles/r05_lpt_ab.txt.  GD_RASTER_LPT_BWD=1 turns it on for A/B.
+// The backward blend runs in the forward pass's longest-first order too, its four strips of a tile kept back to back on the
+// tile's XCD (raster_render_bwd.hip): 0.222 -> 0.209 ms per 8-view launch at FETCH_SIZE 80 -> 99 MB.  (Dealing the strips of a
+// tile round-robin over the XCDs gave the same time at 402 MB: they gather the same Gaussians.)  GD_RASTER_LPT_BWD=0: index order.
 static bool bwd_lpt()
 {
     static const bool on = [] {
         const char* a = getenv("GD_RASTER_LPT"); const char* b = getenv("GD_RASTER_LPT_BWD");
-        return (!a || atoi(a) != 0) && (b && atoi(b) != 0);
+        return (!a || atoi(a) != 0) && (!b || atoi(b) != 0);
     }();
     return on;
 }

@@ -101,7 +101,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // workgroup u runs on XCD u % 8: the four strips of a tile and neighbouring tiles share an XCD (and its L2)
     const uint32_t nblk = tiles_total * 4u;
     uint32_t unit = blockIdx.x;
-    if (tile_perm) unit = tile_perm[blockIdx.x >> 2] * 4u + (blockIdx.x & 3u);      // longest tile lists first (tile_order_kernel)
+    if (tile_perm && (nblk & 31u) == 0) {
+        // longest tile lists first, XCD by XCD (tile_order_kernel: perm[8 r + x] = r-th longest tile of band x): workgroup b runs
+        // on XCD b % 8, and the FOUR STRIPS of a tile -- which gather the same Gaussians -- stay on that XCD, back to back
+        const uint32_t x = blockIdx.x & 7u, r = blockIdx.x >> 3;
+        unit = tile_perm[8u * (r >> 2) + x] * 4u + (r & 3u);
+    }
     else if ((nblk & 7u) == 0) unit = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
     const uint32_t n_listed = strip_count[unit];     // strip_count[tile * 4 + strip]
     if (n_listed == 0) return;                       // nobody in this strip blended anything: no rows
