@@ -1021,6 +1021,9 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
 
 #include "nn_conv_wino.h"
 #include "nn_conv_wide.h"
+#ifdef GD_NN_EXPERIMENTAL_STREAM   // -Itools/experimental: the weight-streaming small-map experiment, built by tools/ only
+#include "nn_conv_stream.h"
+#endif
 #ifdef GD_NN_EXPERIMENTAL_REGW   // -Itools/experimental: the filter-bank-in-registers experiment, built by tools/ only
 #include "nn_conv_regw.h"
 #endif
@@ -1883,6 +1886,10 @@ int gd_nn_conv3x3_wide_weights(void* stream, const void* weight, void* u, int Co
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
 }
+
+#ifdef GD_NN_EXPERIMENTAL_STREAM   // tools/stream_variants.sh only: a measured negative, not in libgd_nn.so
+#include "nn_conv_stream_api.h"
+#endif
 
 int gd_nn_conv3x3_wide_supported(int N, int H, int W, int Cin, int Cout)
 {
