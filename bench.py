@@ -208,6 +208,25 @@ def parse():
     return ap.parse_args()
 
 
+def observed_host_syncs(step_fn) -> dict:
+    """One extra, untimed step under torch's sync debug mode: the calls of the step in which the HOST waited for the GPU (pageable
+    copies, .item(), nonzero, ...), by source line.  It sees torch's own calls; the rasterizer's read-back of the instance count goes
+    through the C-ABI and is reported separately (``raster_forward_host_syncs_in_timed_region``)."""
+    import collections
+    import warnings
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("warn")
+    try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            step_fn()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    sites = collections.Counter(f"{os.path.basename(w.filename)}:{w.lineno}" for w in caught if "synchroniz" in str(w.message))
+    return {"count": sum(sites.values()), "sites": dict(sites)}
+
+
 def camera_batch(args, step, view_ids):
     from garmentdreamer_amd import cameras as gcam
     # SURVEY 8d benchmark default orbit; the ring of azimuths rotates a little every step
@@ -365,6 +384,7 @@ def vsd_main(args):
                   "image_grad_nonzero": bool(img.grad is not None and float(img.grad.abs().sum()) > 0)}
     if not all(health.values()):
         raise SystemExit(f"bench.py --vsd: unhealthy run {health}")
+    host_syncs = observed_host_syncs(step)
     if rk == 0:
         tfl = 3 * UNET_TFLOP_PER_SAMPLE + 2 * VAE_TFLOP_PER_IMAGE + 3 * UNET_TFLOP_PER_SAMPLE
         emit({"metric": "NeTF VSD iters/sec (VAE + 3 UNet fwd + LoRA-UNet fwd/bwd), 512^2, 1 view/GPU",
@@ -376,6 +396,8 @@ def vsd_main(args):
                           "config": {"workload": f"VSD step, SD-2.1 UNet + LoRA UNet (rank 4) random-init, batch 1, {res}^2 image leaf"
                                                  + (" reduced to 512^2 for the VAE" if res != 512 else ""),
                                      "hip_graphs": bool(gd.use_hip_graphs), "fp8_unet": bool(gd.fp8_unet),
+                                     "torch_host_syncs_per_step_observed": host_syncs["count"],
+                                     "torch_host_sync_sites": host_syncs["sites"],
                                      "fp8_sites_run": sum(getattr(n, "fp8").sites_run for n in (gd.unet, lora)
                                                           if getattr(n, "fp8", None) is not None)},
                           "health": health,
@@ -594,6 +616,7 @@ def main():
     prof = _native.profile_read()
     conv_ms, conv_n, conv_flops = nn_ops.conv_profile(enable=False) if not args.raster_only else (0.0, 0, 0.0)
     conv_bytes = nn_ops.conv_profile_bytes() if not args.raster_only else 0.0
+    host_syncs = observed_host_syncs(lambda: one_step(args.warmup + args.steps + 1000))     # untimed, after the counters are read
     conv_steps = args.steps
     conv_note = "HIP events around every launch inside the timed region"
     graphs_active = bool(guidance is not None and guidance.cfg.use_hip_graphs)   # False if capture failed / was refused
@@ -769,6 +792,7 @@ def main():
                            0 if loop.capacity is not None and loop.capacity.calls_sync_free >= args.warmup + args.steps - 1
                            else args.steps),
                        "raster_instance_capacity": None if loop.capacity is None else loop.capacity.value,
+                       "torch_host_syncs_per_step_observed": host_syncs["count"], "torch_host_sync_sites": host_syncs["sites"],
                        "library_fallbacks": sum(fallbacks.values()),
                        "library_fallback_sites": fallbacks or None,
                        "library_override": {"nn": args.nn_lib, "raster": args.raster_lib}

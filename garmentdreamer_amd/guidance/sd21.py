@@ -49,6 +49,9 @@ _LORA_FUSED = _os.environ.get("GD_LORA_FUSED", "1") != "0"   # A/B toggle: own r
 _VAE_ATTN_NODE = _os.environ.get("GD_VAE_ATTN_NODE", "1") != "0"  # A/B toggle: VAE mid attention as one autograd node with own softmax
 _CTX_VT = _os.environ.get("GD_CTX_VT", "1") != "0"           # A/B toggle: cross-attention V^T of all layers from one GEMM (round 5)
 _LORA_LINEAR = _os.environ.get("GD_LORA_LINEAR", "1") != "0"  # A/B toggle: adapted projection as ONE autograd node (nn_ops.lora_linear)
+_CONV_BIAS_GRAD = _os.environ.get("GD_CONV_BIAS_GRAD", "1") != "0"  # A/B toggle (round 5): trainable per-image bias inside the conv node
+_PINNED_TABLES = _os.environ.get("GD_PAGEABLE_COPIES", "0") != "1"  # A/B toggle (round 5): =1 restores the per-call pageable host-to-device copies (each a full sync)
+_TEMB_TRAIN_CAT = _os.environ.get("GD_TEMB_TRAIN_CAT", "1") != "0"  # A/B toggle (round 5): the 22 time_emb_proj of a TRAINING pass as one GEMM
 from .. import nn_ops  # noqa: E402
 _FP8_ACTIVE = [None]   # the nn_ops.Fp8State of the UNet whose no-grad forward is running (set by its forward)
 
@@ -65,9 +68,10 @@ def _conv3(conv: nn.Conv2d, x, image_bias=None, residual=None):
     bias = conv.bias if image_bias is None else image_bias
     frozen = not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
     if frozen and conv3x3_supported(x, conv.weight) and conv.stride == (1, 1) and conv.padding == (1, 1):
-        if bias is not None and bias.requires_grad:   # LoRA training: the time/camera embedding bias needs a gradient
+        if bias is not None and bias.requires_grad and not _CONV_BIAS_GRAD:   # round-4 form (same-box A/B): bias and residual as aten adds
             y = conv3x3(x, conv.weight, None, None) + (bias[:, :, None, None] if bias.dim() == 2 else bias[None, :, None, None])
             return y if residual is None else y + residual
+        # LoRA training: the time / camera embedding bias needs a gradient -- the node returns it (the sum of dy over the pixels)
         return conv3x3(x, conv.weight, bias, residual)
     nn_ops._note_fallback("sd21._conv3", x, "needs frozen bf16 channels_last weights, stride 1, pad 1, Cin % 64 == 0")
     y = F.conv2d(x, conv.weight, None if image_bias is not None else conv.bias, conv.stride, conv.padding)
@@ -579,9 +583,13 @@ class UNet2DConditionModel(nn.Module):
         return ContextProjections(ctx, kv, vt)
 
     def _project_temb(self, temb):
-        """All blocks' per-image conv1 biases in one GEMM (``TembProjections``) when nothing on the way needs a
-        gradient; otherwise the time embedding itself (each block then projects it, with autograd)."""
-        if not temb.is_cuda or (torch.is_grad_enabled() and temb.requires_grad):
+        """All blocks' per-image conv1 biases in one GEMM (``TembProjections``).  The projection weights must be frozen; the
+        time embedding itself may need a gradient (the LoRA UNet's camera / shading embedding is part of it): the GEMM and the
+        SiLU before it then run under autograd ONCE, the blocks take ``torch.split`` views of the result, and the backward pass
+        is one concatenation of the 22 bias gradients, one GEMM and one SiLU backward instead of 22 of each plus 21
+        accumulations into the embedding's gradient (round 5; ``GD_TEMB_TRAIN_CAT=0`` = per block as before)."""
+        train = torch.is_grad_enabled() and temb.requires_grad
+        if not temb.is_cuda or (train and not _TEMB_TRAIN_CAT):
             return temb
         blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
         if not blocks or any(b.time_emb_proj.weight.requires_grad or b.conv1.bias.requires_grad for b in blocks):
@@ -595,6 +603,9 @@ class UNet2DConditionModel(nn.Module):
                 w = torch.cat([b.time_emb_proj.weight for b in blocks], dim=0).to(temb.dtype).contiguous()
                 bias = torch.cat([b.time_emb_proj.bias + b.conv1.bias for b in blocks], dim=0).to(temb.dtype)
             cache = self._temb_cat = (key, w, bias)
+        if train:
+            parts = torch.split(_lib_linear(F.silu(temb), cache[1], cache[2]), [b.time_emb_proj.out_features for b in blocks], dim=1)
+            return TembProjections(temb, {id(b): p for b, p in zip(blocks, parts)})
         with torch.no_grad():
             allp = _lib_linear(F.silu(temb), cache[1], cache[2])
         out, off = {}, 0
@@ -928,8 +939,22 @@ class DDIMScheduler:
             prev = prev + std * variance_noise
         return {"prev_sample": prev.to(sample.dtype), "pred_original_sample": x0.to(sample.dtype)}
 
+    def _alphas_on(self, device, dtype):
+        """``alphas_cumprod`` on ``device`` in ``dtype``, copied there ONCE: the table lives on the host (diffusers keeps it there),
+        and a pageable host-to-device copy per call waits for everything queued on the stream -- three full synchronisations per
+        VSD iteration before round 5 (tools/vsd_host_timeline.py)."""
+        if not _PINNED_TABLES:
+            return self.alphas_cumprod.to(device=device, dtype=dtype)
+        key = (str(device), dtype)
+        hit = self._alphas_cache.get(key) if hasattr(self, "_alphas_cache") else None
+        if hit is None or hit[0] is not self.alphas_cumprod:
+            if not hasattr(self, "_alphas_cache"):
+                self._alphas_cache = {}
+            hit = self._alphas_cache[key] = (self.alphas_cumprod, self.alphas_cumprod.to(device=device, dtype=dtype))
+        return hit[1]
+
     def add_noise(self, original_samples, noise, timesteps):
-        ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        ac = self._alphas_on(original_samples.device, original_samples.dtype)
         sqrt_a = ac[timesteps] ** 0.5
         sqrt_1ma = (1 - ac[timesteps]) ** 0.5
         while sqrt_a.dim() < original_samples.dim():
@@ -939,7 +964,7 @@ class DDIMScheduler:
 
     def get_velocity(self, sample, noise, timesteps):
         """v-prediction target: sqrt(abar) * eps - sqrt(1 - abar) * x0."""
-        ac = self.alphas_cumprod.to(device=sample.device, dtype=sample.dtype)
+        ac = self._alphas_on(sample.device, sample.dtype)
         sqrt_a = ac[timesteps] ** 0.5
         sqrt_1ma = (1 - ac[timesteps]) ** 0.5
         while sqrt_a.dim() < sample.dim():

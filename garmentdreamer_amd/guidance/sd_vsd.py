@@ -28,6 +28,34 @@ from . import sd21
 from .. import _runtime_env
 
 
+import os as _os
+_DRAIN = _os.environ.get("GD_VSD_DRAIN", "1") != "0"    # A/B toggle (round 5): drain the stream before the two training graphs
+
+
+def _drain(device):
+    """Wait for the stream before a training graph of the LoRA UNet is launched.  Measured, not derived: launched onto a busy stream
+    the two graphs of the training pass (about 1500 nodes each) leave the GPU idle for about 1 ms per iteration more than launched
+    onto a drained one (36.0-36.3 -> 35.1-35.4 ms per iteration, two interleaved runs on each of two boxes; the frozen networks'
+    and the VAE's graphs show the opposite or nothing, and no runtime queue / kernarg-pool / signal-pool setting moves it:
+    profiles/r05_vsd_drain_ab.txt).  The host has nothing else to do at these two points."""
+    if _DRAIN and device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(device).synchronize()
+
+
+class _DrainBeforeBackward(torch.autograd.Function):
+    """Identity whose backward drains the stream first: it sits on the training UNet's output, so it runs right before the
+    graphed backward pass of ``lu.backward()`` without the caller doing anything."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        _drain(g.device)
+        return g
+
+
 class SpecifyGradient(torch.autograd.Function):
     """sd_vsd_utils.py:15-28: forward returns sum(grad) as a dummy loss value, backward hands
     ``gt_grad / batch_size`` to the latents."""
@@ -276,9 +304,14 @@ class StableDiffusionVSD(nn.Module):
                 noise = torch.randn(latents_clean.shape, device=self.device)
             latents_noisy = self.scheduler.add_noise(latents_clean, noise, timesteps)
             target = self.scheduler.get_velocity(latents_clean, noise, timesteps) if v_pred else noise
+        graphed = self.use_hip_graphs and latents_noisy.is_cuda
+        if graphed:
+            _drain(latents_noisy.device)
         out = self._q_train(q_unet, latents_noisy, timesteps,
-                            self.embeddings["pos"].expand(unet_bs, -1, -1).contiguous(), pose_b, shading).float()
-        return F.mse_loss(out, target)
+                            self.embeddings["pos"].expand(unet_bs, -1, -1).contiguous(), pose_b, shading)
+        if graphed and out.requires_grad:
+            out = _DrainBeforeBackward.apply(out)
+        return F.mse_loss(out.float(), target)
 
 
 class LoraUnet(nn.Module):

@@ -510,7 +510,14 @@ class PromptEmbeddings:
             idx[(azi > -self.front_threshold) & (azi < self.front_threshold)] = 1
             idx[(azi > 180 - self.back_threshold) | (azi < -180 + self.back_threshold)] = 2
             idx[elevation > self.overhead_threshold] = 3
-            idx = idx.to(self.text_embeddings_vd.device)
+            dev = self.text_embeddings_vd.device
+            if idx.device != dev:
+                # cameras usually live on the host: a pageable host-to-device copy waits for everything queued on the stream (the
+                # rasterizer forward of this very step) -- the one synchronising call torch's sync debug mode still found in the
+                # SDS step in round 5; a pinned staging buffer + non_blocking copy does not wait
+                if dev.type == "cuda" and not idx.is_cuda and sd21._PINNED_TABLES:
+                    idx = idx.pin_memory()
+                idx = idx.to(dev, non_blocking=True)
             text, uncond = self.text_embeddings_vd[idx], self.uncond_text_embeddings_vd[idx]
         else:
             text = self.text_embeddings.expand(batch_size, -1, -1)

@@ -589,6 +589,7 @@ class _Conv3x3(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual):
         ctx.weight = weight
         ctx.has_res = residual is not None
+        ctx.bias_meta = None if bias is None else (bias.dim(), bias.dtype)
         return _conv_launch(x, weight, bias, residual, weight.shape[0])
 
     @staticmethod
@@ -617,7 +618,13 @@ class _Conv3x3(torch.autograd.Function):
                     memory_format=torch.channels_last)
                 dyp[:, :Cout] = dy
                 dx = _conv_launch(dyp, fp, None, None, w.shape[1])
-        return dx, None, None, (dy if ctx.has_res else None)
+        db = None
+        if ctx.needs_input_grad[2]:
+            # a bias that trains (the LoRA UNet's camera / shading embedding reaches every ResnetBlock2D's conv1 as its per-image
+            # bias): the sum of dy over the pixels (and the images for a [Cout] bias), fp32 accumulation, one rounding
+            dim, dt = ctx.bias_meta
+            db = dy.sum(dim=(2, 3) if dim == 2 else (0, 2, 3), dtype=torch.float32).to(dt)
+        return dx, None, db, (dy if ctx.has_res else None)
 
 
 class _ConvSmallCin(torch.autograd.Function):
@@ -723,8 +730,8 @@ def conv3x3(x, weight, bias=None, residual=None):
     """3x3 / stride 1 / pad 1 convolution (+ bias [Cout] or per-image bias [N,Cout]) (+ residual).
     MFMA implicit-GEMM HIP kernel for bf16 NHWC GPU tensors; torch ops otherwise (CPU / fp32)."""
     if conv3x3_supported(x, weight):
-        if weight.requires_grad or (bias is not None and bias.requires_grad):
-            raise RuntimeError("conv3x3 HIP kernel computes input gradients only (frozen weights)")
+        if weight.requires_grad:
+            raise RuntimeError("conv3x3 HIP kernel computes input and bias gradients only (frozen weights)")
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):

@@ -195,7 +195,64 @@ def test_batched_time_embedding_projection_equals_per_block_projection():
     assert (y_batched.float() - y_plain.float()).abs().max().item() <= 4e-2 * scale
     assert F.cosine_similarity(y_batched.float().flatten(), y_plain.float().flatten(), dim=0).item() > 0.999
     temb = torch.randn(3, 256, device=DEV).to(torch.bfloat16).requires_grad_(True)
-    assert unet._project_temb(temb) is temb      # gradient wanted (LoRA / camera embedding training): per block
+    # gradient wanted (LoRA / camera embedding training): still ONE GEMM since round 5, under autograd, split views per block
+    packed = unet._project_temb(temb)
+    assert isinstance(packed, sd21.TembProjections) and all(v.requires_grad for v in packed.image_bias.values())
+
+
+def test_training_time_embedding_as_one_gemm_and_bias_gradient_inside_the_conv_node(monkeypatch):
+    """Round 5, NeTF stage: with the camera / shading embedding training, the 22 ``time_emb_proj`` of the LoRA UNet run as ONE GEMM
+    under autograd (split views per block; backward = one concatenation + one GEMM + one SiLU backward) and each conv1 takes its
+    per-image bias in the kernel epilogue, the autograd node returning the bias gradient -- instead of 22 x (SiLU, GEMM, two adds)
+    forward and 22 x (pixel sum, GEMM, SiLU backward, accumulation) backward.  Same network output and same gradients for the camera
+    MLP, the shading embedding and the adapters as the per-block path, to the bf16 rounding of the two forms, and against fp32
+    eager on the same weights."""
+    from garmentdreamer_amd.guidance import sd21
+    kw = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4))
+    with torch.device(DEV):
+        lora = sd21.init_random_(sd21.LoraUNet2DConditionModel(**kw), 2)
+        g = torch.Generator(DEV).manual_seed(11)
+        for layer in lora.lora_layers:                        # non-zero up-projections: the adapter gradients carry signal
+            for m in layer.values():
+                m.up.weight.data.normal_(0, 0.02, generator=g)
+    import copy
+    ref = copy.deepcopy(lora).float()
+    ref_train = ref.freeze_base()
+    lora = lora.to(torch.bfloat16).to(memory_format=torch.channels_last)
+    lora.trainables_to_fp32()
+    train = lora.freeze_base()
+    x = torch.randn(2, 4, 32, 32, device=DEV, generator=g)
+    ctx = torch.randn(2, 77, 1024, device=DEV, generator=g)
+    pose = torch.randn(2, 16, device=DEV, generator=g)
+    t = torch.tensor([317.0, 611.0], device=DEV)
+    wgt = torch.randn(2, 4, 32, 32, device=DEV, generator=g)
+
+    def run(net, params, dtype):
+        for p_ in params:
+            p_.grad = None
+        y = net(x.to(dtype), t, ctx.to(dtype), c=pose, shading="lambertian")
+        (y.float() * wgt).sum().backward()
+        names = {id(p_): n for n, p_ in net.named_parameters()}
+        return y.detach().float(), {names[id(p_)]: p_.grad.detach().float().clone() for p_ in params if p_.grad is not None}
+
+    monkeypatch.setattr(sd21, "_TEMB_TRAIN_CAT", False)
+    monkeypatch.setattr(sd21, "_CONV_BIAS_GRAD", False)
+    y_old, g_old = run(lora, train, torch.bfloat16)
+    monkeypatch.setattr(sd21, "_TEMB_TRAIN_CAT", True)
+    monkeypatch.setattr(sd21, "_CONV_BIAS_GRAD", True)
+    y_new, g_new = run(lora, train, torch.bfloat16)
+    y_ref, g_ref = run(ref, ref_train, torch.float32)
+    cos = lambda a, b: F.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+    assert cos(y_new, y_old) > 0.9995 and cos(y_new, y_ref) > 0.999
+    assert set(g_new) == set(g_old) == set(g_ref)
+    emb = [n for n in g_new if n.startswith("camera_emb") or n.endswith("_emb")]
+    assert len(emb) == 5                                    # the camera MLP's four tensors + the lambertian embedding
+    for n in emb:
+        assert cos(g_new[n], g_ref[n]) > 0.99, (n, cos(g_new[n], g_ref[n]), cos(g_old[n], g_ref[n]))
+        assert cos(g_new[n], g_old[n]) > 0.99, (n, cos(g_new[n], g_old[n]))
+    lo = [n for n in g_new if "lora" in n]
+    cat = lambda d: torch.cat([d[n].flatten() for n in lo])
+    assert cos(cat(g_new), cat(g_ref)) > 0.995 and cos(cat(g_new), cat(g_old)) > 0.995
 
 
 @pytest.mark.parametrize("N,cin,cout,H,W", [(8, 128, 128, 128, 128), (2, 128, 256, 32, 32), (1, 256, 256, 24, 40)])
