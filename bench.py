@@ -603,6 +603,7 @@ def main():
     gdist.barrier()
     torch.cuda.synchronize()
     tele.start()
+    loop.time_collectives = ws > 1 and not args.raster_only      # HIP events either side of the gradient all-reduce
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step(args.warmup + s)
@@ -611,6 +612,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     telemetry = tele.stop()
+    coll_n, coll_ms, coll_bytes = loop.collective_times()
+    loop.time_collectives = False
     fallbacks = nn_ops.library_fallbacks()
     _native.profile_enable(False)
     prof = _native.profile_read()
@@ -782,6 +785,10 @@ def main():
                                     f"SD-2.1 UNet+VAE random-init, {V} view(s)/GPU"),
                        "gaussians": args.gaussians, "views": args.views, "resolution": args.res,
                        "views_per_gpu": V, "parallelism": f"view-sharded dp{ws}",
+                       "grad_allreduce": None if not coll_n else {
+                           "ms_per_step": coll_ms * coll_n / args.steps, "bytes": coll_bytes, "calls_per_step": coll_n / args.steps,
+                           "note": "HIP events on the step's stream either side of the ONE data-path collective (flat fp32 Gaussian "
+                                   "gradients incl. the view-space tail, in place, blocking after the backward pass); rank 0's view"},
                        "raster": "per-view loop" if args.per_view_raster else "batched",
                        "raster_only": bool(args.raster_only), "hip_graphs": graphs_active,
                        "fp8_unet_sites": (guidance.unet.fp8.sites_run if guidance is not None and

@@ -130,6 +130,8 @@ class SDSLoop:
             self.denom = torch.zeros((P, 1), device=dev)
             self.max_radii2D = torch.zeros((P,), device=dev)
         self.global_step = 0
+        self.time_collectives = False          # bench.py --gpus N: time the gradient all-reduce (collective_times())
+        self._collective_events = []
         self._bucket = None
         # densify_and_prune(0.0002, 0.05, cameras_extent, size_threshold), GaussianDreamer.py:279-283,426
         self.densify = densify and self.native_scene
@@ -231,7 +233,16 @@ class SDSLoop:
                 vs_grad = self.gaussians.viewspace_grad
                 torch.sum(out["viewspace_points"].grad, dim=0, out=vs_grad)
                 if gdist.collectives_on():
-                    gdist.all_reduce_mean_(self.gaussians.grad_bucket)
+                    if self.time_collectives and vs_grad.is_cuda:
+                        # measured, not assumed (the one data-path collective of the step): events on the step's stream either
+                        # side of the flat gradient all-reduce; read with collective_times()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        gdist.all_reduce_mean_(self.gaussians.grad_bucket)
+                        e1.record()
+                        self._collective_events.append((e0, e1))
+                    else:
+                        gdist.all_reduce_mean_(self.gaussians.grad_bucket)
                 if self.global_step < 900:
                     self.gaussians.add_densification_stats(vs_grad, radii)
                     if self.densify and self.global_step > 300 and self.global_step % 100 == 0:
@@ -264,6 +275,19 @@ class SDSLoop:
         self.global_step += 1
         return {"loss": loss.detach(), "loss_sds": loss_sds.detach(), "loss_sparsity": loss_sparsity.detach(),
                 "grad_norm": g_out["grad_norm"], "num_visible": (radii > 0).sum(), "densified": densified}
+
+    def collective_times(self, reset: bool = True):
+        """(calls, mean ms, bytes per call) of the flat gradient all-reduce since the last reset (``time_collectives`` on)."""
+        ev = self._collective_events
+        if not ev:
+            return 0, 0.0, 0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        n = len(ev)
+        nbytes = self.gaussians.grad_bucket.numel() * self.gaussians.grad_bucket.element_size() if self.native_scene else 0
+        if reset:
+            self._collective_events = []
+        return n, ms, nbytes
 
     def _densification_stats(self, viewspace_grad, radii):
         """on_before_optimizer_step (:268-279) + add_densification_stats (gaussian_model.py:415-419)."""

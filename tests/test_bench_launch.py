@@ -66,3 +66,6 @@ def test_the_real_step_under_the_launcher_two_ranks_share_one_gpu_over_gloo():
     assert line["health"]["params_finite"] and line["health"]["visible_after_timed_steps"] > 0
     assert line["config"]["batch_invariant"] is False and line["config"]["library_fallbacks"] == 0
     assert "cpu_baseline" not in line and line["metric"].startswith("SDS iters/sec")
+    # the one data-path collective is timed inside the timed region (HIP events either side of it) and sized
+    ar = line["config"]["grad_allreduce"]
+    assert ar["calls_per_step"] == 1 and ar["ms_per_step"] > 0 and ar["bytes"] >= 100000 * 14 * 4
