@@ -1021,6 +1021,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_patch_stream_kernel(
 
 #include "nn_conv_wino.h"
 #include "nn_conv_wide.h"
+#include "nn_conv_first_dgrad.h"
 #ifdef GD_NN_EXPERIMENTAL_STREAM   // -Itools/experimental: the weight-streaming small-map experiment, built by tools/ only
 #include "nn_conv_stream.h"
 #endif
@@ -2256,6 +2257,38 @@ int gd_nn_conv_profile_read_bytes(double* total_bytes)
 {
     std::lock_guard<std::mutex> lk(g_cprof.mu);
     if (total_bytes) *total_bytes = g_cprof.total_bytes;
+    return GD_NN_OK;
+}
+
+// Input gradient of the first convolution (Cin <= 3, Cout = 128; nn_conv_first_dgrad.h).  `wpack`: 32 x 128 bf16 from
+// gd_nn_conv3x3_first_dgrad_weights (once per frozen weight); dx4: [N, H, W, 4] bf16 (channel Cin.. = 0).
+int gd_nn_conv3x3_first_dgrad_supported(int N, int H, int W, int Cin, int Cout)
+{
+    return N > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 3 && Cout == 128 && (double)H * W * 256.0 < 2147483648.0 &&
+           (double)N * ((H + 15) / 16) * ((W + 15) / 16) < 2147483648.0;
+}
+
+int gd_nn_conv3x3_first_dgrad_weights(void* stream, const void* weight, void* wpack, int Cout, int Cin)
+{
+    if (!weight || !wpack) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (Cout != 128 || Cin < 1 || Cin > 3) return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first_dgrad: need Cout == 128 and 1 <= Cin <= 3");
+    hipLaunchKernelGGL(conv3x3_first_dgrad_weights_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)weight,
+                       (uint16_t*)wpack, Cin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
+
+int gd_nn_conv3x3_first_dgrad(void* stream, const void* dy, const void* wpack, void* dx4, int N, int H, int W, int Cin, int Cout)
+{
+    if (!dy || !wpack || !dx4) return fail(GD_NN_ERR_INVALID_ARG, "null pointer");
+    if (!gd_nn_conv3x3_first_dgrad_supported(N, H, W, Cin, Cout))
+        return fail(GD_NN_ERR_INVALID_ARG, "conv3x3_first_dgrad: need Cout == 128, 1 <= Cin <= 3 and an image below 2 GiB");
+    const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+    hipLaunchKernelGGL(conv3x3_first_dgrad_kernel, dim3((unsigned)(N * tx * ty)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)dy, (const uint16_t*)wpack, (uint16_t*)dx4, H, W, tx, ty);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
 }
 

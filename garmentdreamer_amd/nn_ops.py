@@ -42,6 +42,9 @@ SIGNATURES = {
     "gd_nn_conv_force_split": (_i, [_i]),
     "gd_nn_conv_set_route_scale": (_i, [_i]),
     "gd_nn_conv3x3_flip_weights": (_i, [_vp, _vp, _vp, _i, _i]),
+    "gd_nn_conv3x3_first_dgrad_supported": (_i, [_i, _i, _i, _i, _i]),
+    "gd_nn_conv3x3_first_dgrad_weights": (_i, [_vp, _vp, _vp, _i, _i]),
+    "gd_nn_conv3x3_first_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "gd_nn_groupnorm_silu_forward_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _f]),
     "gd_nn_conv3x3_gn_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i]),
@@ -627,6 +630,10 @@ class _Conv3x3(torch.autograd.Function):
         return dx, None, db, (dy if ctx.has_res else None)
 
 
+# GD_NN_FIRST_DGRAD=0: the first convolution's input gradient on the padded implicit-GEMM kernel as before round 5 (same-box A/B)
+_FIRST_DGRAD = os.environ.get("GD_NN_FIRST_DGRAD", "1") != "0"
+
+
 class _ConvSmallCin(torch.autograd.Function):
     """First VAE convolution (Cin = 3): forward on gd_nn_conv3x3_first_forward (matrix-core kernel for the VAE's 128
     output channels, VALU kernel otherwise; an output-write stream), input gradient through the MFMA kernel with the
@@ -679,6 +686,26 @@ class _ConvSmallCin(torch.autograd.Function):
             return None, None, None, None
         w = ctx.weight
         Cout, Cin = w.shape[0], w.shape[1]
+        N, _, H, W = dy.shape
+        if _FIRST_DGRAD and dy.dtype == torch.bfloat16 and lib().gd_nn_conv3x3_first_dgrad_supported(N, H, W, Cin, Cout):
+            # round 5: dy read once -- a 128 -> 9 x 3 product per pixel on the matrix cores, the nine shifted partial results summed
+            # through LDS (csrc/nn_conv_first_dgrad.h); the padded implicit-GEMM form below read every dy element nine times
+            wp = getattr(w, "_gd_first_dgrad", None)
+            key = (w.data_ptr(), w._version)
+            L = lib()
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            with torch.cuda.device(w.device):
+                stream = torch.cuda.current_stream(w.device).cuda_stream
+                if wp is None or wp.device != w.device or getattr(w, "_gd_first_dgrad_key", None) != key:
+                    wp = torch.empty(32 * 128, dtype=torch.bfloat16, device=w.device)
+                    wc = w.contiguous(memory_format=torch.channels_last)
+                    _check(L.gd_nn_conv3x3_first_dgrad_weights(stream, wc.data_ptr(), wp.data_ptr(), Cout, Cin),
+                           "gd_nn_conv3x3_first_dgrad_weights", "gd_nn_conv_last_error")
+                    w._gd_first_dgrad, w._gd_first_dgrad_key = wp, key
+                dx4 = torch.empty((N, 4, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+                _check(L.gd_nn_conv3x3_first_dgrad(stream, dy.data_ptr(), wp.data_ptr(), dx4.data_ptr(), N, H, W, Cin, Cout),
+                       "gd_nn_conv3x3_first_dgrad", "gd_nn_conv_last_error")
+            return dx4[:, :Cin], None, None, None
         f = getattr(w, "_gd_flipped4", None)
         key = (w.data_ptr(), w._version)
         if f is None or f.device != w.device or getattr(w, "_gd_flipped4_key", None) != key:

@@ -59,6 +59,15 @@ int gd_nn_conv3x3_forward(void* stream, const void* x, const void* weight, const
  * input gradient dx = conv3x3(dy, flipped) (weights are frozen in the guidance; no wgrad). */
 int gd_nn_conv3x3_flip_weights(void* stream, const void* weight, void* flipped, int Cout, int Cin);
 
+/* Input gradient of the FIRST convolution of the VAE encoder (1 <= Cin <= 3 image channels, Cout = 128; autograd of diffusers'
+ * AutoencoderKL.encoder.conv_in under stable_diffusion_guidance.py:165-166 encode_images): dy [N,H,W,128] bf16 is read once --
+ * a 128 -> 9 taps x 3 channels product on the matrix cores per 16x16 tile + halo, the nine shifted partial results of each pixel
+ * summed in fp32 through LDS.  wpack: 32 x 128 bf16 from gd_nn_conv3x3_first_dgrad_weights (weight: [Cout][3][3][Cin]; once per
+ * frozen weight); dx4: [N,H,W,4] bf16, channels >= Cin written as 0.  Replaces the Cout-padded-to-32 implicit-GEMM launch. */
+int gd_nn_conv3x3_first_dgrad_supported(int N, int H, int W, int Cin, int Cout);
+int gd_nn_conv3x3_first_dgrad_weights(void* stream, const void* weight, void* wpack, int Cout, int Cin);
+int gd_nn_conv3x3_first_dgrad(void* stream, const void* dy, const void* wpack, void* dx4, int N, int H, int W, int Cin, int Cout);
+
 /* Tuning hook: force the tile variant (0 = 128x128/4 waves, 1 = 128 ch x 256 px/8 waves,
  * 2 = 256x256/8 waves, -1 = built-in heuristic). */
 int gd_nn_conv_force_variant(int v);

@@ -447,6 +447,37 @@ def test_unet_and_vae_bf16_hip_path_tracks_fp32_torch_path():
     assert F.cosine_similarity(i32.grad.flatten(), i16.grad.flatten(), dim=0).item() > 0.98
 
 
+@pytest.mark.parametrize("N,Cin,H,W", [(2, 3, 64, 64), (1, 3, 37, 53), (3, 1, 16, 16), (1, 2, 129, 17), (8, 3, 128, 128)])
+def test_first_conv_input_gradient_reads_dy_once_and_matches_fp32_reference(N, Cin, H, W, monkeypatch):
+    """csrc/nn_conv_first_dgrad.h (round 5): input gradient of the VAE's first convolution as a 128 -> 9 x Cin product per pixel +
+    the nine shifted sums through LDS.  Against fp32 autograd of F.conv2d on the same bf16 operands and against the padded
+    implicit-GEMM form it replaced; ragged tiles (image edges inside a 16x16 tile), 1-3 channels, asymmetric data."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(DEV).manual_seed(17 * N + Cin + H)
+    w = (torch.randn(128, Cin, 3, 3, device=DEV, generator=g) / 3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(128, device=DEV, generator=g).to(torch.bfloat16)
+    x = torch.randn(N, Cin, H, W, device=DEV, generator=g).to(torch.bfloat16)
+    dy = torch.randn(N, 128, H, W, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert nn_ops.lib().gd_nn_conv3x3_first_dgrad_supported(N, H, W, Cin, 128)
+    out = {}
+    for new in (True, False):
+        monkeypatch.setattr(nn_ops, "_FIRST_DGRAD", new)
+        xi = x.clone().requires_grad_(True)
+        y = nn_ops.conv3x3_small_cin(xi, w, b)
+        y.backward(dy)
+        out[new] = xi.grad.float()
+    x32 = x.float().requires_grad_(True)
+    F.conv2d(x32, w.float(), b.float(), padding=1).backward(dy.float())
+    ref = x32.grad
+    scale = ref.abs().max().item()
+    for new in (True, False):
+        err = (out[new] - ref).abs().max().item()
+        assert err <= 1.5e-2 * scale, (new, err, scale)
+        assert F.cosine_similarity(out[new].flatten(), ref.flatten(), dim=0).item() > 0.9999
+    # fp32 accumulation of all 9 x 128 terms, one rounding: at least as close as the form it replaces
+    assert (out[True] - ref).abs().max().item() <= (out[False] - ref).abs().max().item() + 4e-3 * scale
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,per_image_bias,res", [
     (2, 64, 128, 16, 16, False, False), (1, 128, 128, 32, 40, False, True), (3, 320, 320, 16, 16, True, True),
     (2, 192, 64, 9, 13, True, False), (1, 64, 8, 16, 16, False, False), (2, 640, 320, 8, 8, False, True),
