@@ -1656,6 +1656,43 @@ def test_conv_routing_picks_the_measured_kernel_and_all_routes_agree():
     assert torch.equal(ys[1], ys[3])         # 128 wide tiles are too few: the router sent this shape to the Winograd kernel
 
 
+_STEP_CONV_SHAPES = [   # (N, Cin, Cout, H): every stride-1 3x3 shape of the 8-view step that leaves the direct kernels (profiles/r04_conv_shapes.txt)
+    (8, 128, 128, 512), (8, 256, 128, 256), (8, 512, 256, 128), (8, 512, 512, 128), (8, 512, 512, 64),
+    (16, 320, 320, 64), (16, 640, 320, 64), (16, 960, 320, 64), (16, 640, 640, 64), (16, 320, 640, 32), (16, 640, 640, 32),
+    (16, 1920, 640, 32), (16, 1280, 640, 32), (16, 960, 640, 32), (16, 1280, 1280, 32), (16, 640, 1280, 16), (16, 1280, 1280, 16),
+    (16, 2560, 1280, 16), (16, 1920, 1280, 16)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H", _STEP_CONV_SHAPES)
+def test_every_routed_shape_of_the_step_holds_the_stated_error_bound_against_fp32(N, Cin, Cout, H):
+    """The round-4 advisor's Winograd item: the F(2,3) kernel rounds the TRANSFORMED inputs and filters to bf16 (a second rounding
+    the direct kernels do not have), and a layer's forward pass may run on it while its gradient runs elsewhere.  Stated bound,
+    asserted for every shape of the 8-view step that `nn_ops._conv_route` sends to the Winograd or the wide-tile kernel, AT the
+    step's batch and map size, against fp32 convolution of the same bf16 operands: max error <= 6e-3 of the output scale,
+    relative rms <= 3.2e-3, cosine > 0.99999 (measured on all 19 shapes: Winograd rms 2.57-2.66e-3, max 3.0-3.8e-3; wide tile rms
+    1.66e-3 -- the bf16 rounding of the output alone --, max 1.9-2.3e-3; profiles/r05_parity_report.json).  Unit-variance
+    activations with a mean (GroupNorm+SiLU outputs are not centred), filters of the networks' scale."""
+    from garmentdreamer_amd import nn_ops
+    from tests import parity_report
+    route = nn_ops._conv_route(N, H, H, Cin, Cout)
+    assert route in ("wino", "wide"), route
+    g = torch.Generator(DEV).manual_seed(Cin + Cout + H)
+    cl = torch.channels_last
+    x = (torch.randn(N, Cin, H, H, device=DEV, generator=g) + 0.3).to(torch.bfloat16).contiguous(memory_format=cl)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (3 * Cin ** 0.5)).to(torch.bfloat16).contiguous(memory_format=cl)
+    b = torch.randn(Cout, device=DEV, generator=g).to(torch.bfloat16)
+    with torch.no_grad():
+        y = nn_ops._conv_launch(x, w, b, None, Cout).float()
+        # fp32 reference image by image (the 512^2 activations are 1 GB in fp32)
+        ref = torch.cat([F.conv2d(x[i:i + 1].float(), w.float(), b.float(), padding=1) for i in range(N)])
+    scale = ref.abs().max().item()
+    err = (y - ref).abs().max().item() / scale
+    rms = ((y - ref).square().mean().sqrt() / ref.square().mean().sqrt()).item()
+    cos = F.cosine_similarity(y.flatten(), ref.flatten(), dim=0).item()
+    parity_report.record(f"conv3x3 {route} route, N{N} {Cin}->{Cout} @{H}^2 vs fp32", "kernel", max_err_of_scale=err, rel_rms=rms, cos=cos)
+    assert err <= 6e-3 and rms <= 3.2e-3 and cos > 0.99999, (route, err, rms, cos)
+
+
 def test_linear_320_counted_waits_under_competing_traffic():
     """The streaming K = 320 GEMM waits with ``s_waitcnt vmcnt(n)``, n counted per instruction (csrc/nn_linear.hip): a tile
     consumed before its LDS-DMA landed would be off by O(1).  Many launches on fresh data, alone and with a second stream
