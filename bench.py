@@ -349,6 +349,9 @@ def vsd_main(args):
     if args.warmup < gd.fp8_calibration_steps + 3 and args.fp8:
         args.warmup = gd.fp8_calibration_steps + 3      # calibration forwards + graph capture stay outside the timed region
 
+    import contextlib
+    _LORA_STREAM = os.environ.get("GD_VSD_LORA_STREAM", "1") != "0"
+
     def step():
         nonlocal bucket
         pose = torch.randn(1, 16, device=device, generator=g)
@@ -358,13 +361,16 @@ def vsd_main(args):
         loss.backward()
         lu = gd.lora_train_loss(q, latents, pose, shading="albedo", unet_bs=1)
         opt.zero_grad(set_to_none=True)
-        lu.backward()
-        if gdist.collectives_on():
-            grads = [p.grad for p in train if p.grad is not None]
-            if bucket is None:
-                bucket = gdist.GradBucket(grads)
-            bucket.all_reduce_mean_(grads)
-        opt.step()
+        # the adapters' backward pass + optimizer step on the guidance's LoRA stream (the two lines a maintainer
+        # wraps in trainer.py:250-256); GD_VSD_LORA_STREAM=0: on the caller's stream like the reference
+        with (gd.lora_stream() if _LORA_STREAM else contextlib.nullcontext()):
+            lu.backward()
+            if gdist.collectives_on():
+                grads = [p.grad for p in train if p.grad is not None]
+                if bucket is None:
+                    bucket = gdist.GradBucket(grads)
+                bucket.all_reduce_mean_(grads)
+            opt.step()
 
     for _ in range(args.warmup):
         step()

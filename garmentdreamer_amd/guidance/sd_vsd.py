@@ -29,6 +29,8 @@ from .. import _runtime_env
 
 
 import os as _os
+_CONCURRENT = _os.environ.get("GD_VSD_CONCURRENT", "1") != "0"   # A/B toggle (round 5): frozen UNet and LoRA no-grad forward on two streams
+_TRAIN_STREAM = _os.environ.get("GD_VSD_TRAIN_STREAM", "1") != "0"   # A/B toggle (round 5): the LoRA training pass on the side stream
 _DRAIN = _os.environ.get("GD_VSD_DRAIN", "1") != "0"    # A/B toggle (round 5): drain the stream before the two training graphs
 
 
@@ -117,6 +119,37 @@ class StableDiffusionVSD(nn.Module):
                            "side": side if side is not None else pos, "back": back if back is not None else pos}
 
     # ---- hipGraph replay (same scheme as StableDiffusionGuidance._graphed_unet / _graphed_vae_moments) ----
+    def lora_stream(self):
+        """``with guidance.lora_stream(): lu.backward(); lora_optimizer.step()`` -- the LoRA UNet's backward pass and optimizer step on
+        the stream its forward passes already run on, WITHOUT the caller's stream waiting for them: the next iteration's VAE
+        encoder and frozen UNet (which do not depend on the adapters) then run beside them, and ``train_step`` joins exactly where
+        it needs the updated adapters (its LoRA forward runs on this stream, behind the optimizer step).  Entering waits for what
+        the caller queued so far (``zero_grad``); leaving does NOT join: code that touches the adapters or their gradients outside
+        ``train_step`` / ``lora_train_loss`` calls ``join_lora_stream()`` first.  A no-op context on the CPU / without hipGraphs."""
+        import contextlib
+        if not (_CONCURRENT and _TRAIN_STREAM and self.use_hip_graphs and torch.cuda.is_available()
+                and torch.device(self.device).type == "cuda"):
+            return contextlib.nullcontext()
+        dev = torch.device(self.device)
+        side = self._side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:          # the leaves were created on the caller's stream and accumulate on this one, on purpose
+            quiet(False)
+        return torch.cuda.stream(side)
+
+    def join_lora_stream(self):
+        """The caller's stream waits for everything queued on the LoRA stream (see ``lora_stream``)."""
+        st = getattr(self, "_side", None)
+        if st is not None:
+            torch.cuda.current_stream(st.device).wait_stream(st)
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = self._side = torch.cuda.Stream(device=device)
+        return st
+
     def _graphs_failed(self, err):
         import warnings
         warnings.warn(f"hipGraph capture failed ({err}); continuing with eager kernel launches")
@@ -135,15 +168,20 @@ class StableDiffusionVSD(nn.Module):
             dev = static[0].device
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(2):
-                    fn(*static)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g), torch.no_grad():
-                out = fn(*static)
-            entry = self._graphs[key] = (g, static, out)
-        g, static, out = entry
+            from .. import nn_ops
+            with nn_ops.workspace_tag(key):        # its own GroupNorm accumulators: graphs of two networks may replay concurrently
+                with torch.cuda.stream(side), torch.no_grad():
+                    for _ in range(2):
+                        fn(*static)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                # ... and its own CAPTURE stream: the library GEMMs' workspace (stream-K partial tiles) is keyed by the stream the
+                # call was captured on, so two graphs captured on torch's default capture stream would share one
+                cap = torch.cuda.Stream(device=dev)
+                with torch.cuda.graph(g, stream=cap), torch.no_grad():
+                    out = fn(*static)
+            entry = self._graphs[key] = (g, static, out, cap)
+        g, static, out = entry[:3]
         for st, t in zip(static, tensors):
             st.copy_(t)
         g.replay()
@@ -165,7 +203,19 @@ class StableDiffusionVSD(nn.Module):
                     base = sink._base if sink._base is not None else sink
                     bases[id(base)] = base
             saved = [(b, b.clone()) for b in bases.values()]
-            fn = self._graphs[key] = torch.cuda.make_graphed_callables(module, sample, allow_unused_input=True)
+            # own capture stream (= own library-GEMM workspace) and own GroupNorm accumulators, as in _replay_nograd: the VAE's
+            # backward graph and the LoRA UNet's training graphs may replay concurrently.  make_graphed_callables captures on
+            # torch.cuda.graph's class-level default capture stream: swapped for the duration of the call
+            from .. import nn_ops
+            cap = torch.cuda.Stream(device=tensors[0].device)
+            prev_cap = torch.cuda.graph.default_capture_stream
+            torch.cuda.graph.default_capture_stream = cap
+            try:
+                with nn_ops.workspace_tag(key):
+                    fn = self._graphs[key] = torch.cuda.make_graphed_callables(module, sample, allow_unused_input=True)
+            finally:
+                torch.cuda.graph.default_capture_stream = prev_cap
+            self._capture_streams = getattr(self, "_capture_streams", []) + [cap]
             with torch.no_grad():
                 for b, c in saved:
                     b.copy_(c)
@@ -252,6 +302,11 @@ class StableDiffusionVSD(nn.Module):
         assert pred_rgb.shape[2] == pred_rgb.shape[3] == 512
         assert not as_latent
         latents = self.encode_imgs(pred_rgb, vae_noise).float()
+        if latents.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # lora_train_loss needs the latents and nothing that comes after them (not the frozen UNet, not the VAE backward the
+            # caller runs in between): it waits for THIS event on its own stream
+            self._ev_latents = torch.cuda.Event()
+            self._ev_latents.record(torch.cuda.current_stream(latents.device))
         if timesteps is not None:
             t = timesteps.to(self.device).long()
         elif t5:
@@ -272,13 +327,32 @@ class StableDiffusionVSD(nn.Module):
                     return "front" if abs(h) < 60 else ("side" if abs(h) < 120 else "back")
                 embeddings = torch.cat([self.embeddings[_dir(h)] for h in hors] +
                                        [self.embeddings["neg"].expand(batch_size, -1, -1)])
+            if q_unet is None or pose is None:
+                raise NotImplementedError("VSD needs the LoRA UNet and a pose (sd_vsd_utils.py:192-197)")
+            text_q = self.embeddings["pos"].expand(batch_size, -1, -1).contiguous()
+            overlap = _CONCURRENT and self.use_hip_graphs and latents_noisy.is_cuda and \
+                not torch.cuda.is_current_stream_capturing()
+            if overlap:
+                # the frozen UNet (2 latents) and the LoRA UNet's no-grad forward (1 latent) are independent and each far too
+                # small to fill the chip (launch-bound, ~700 kernels of ~7 us): the second graph replays on the LoRA side stream
+                # beside the first (round 5; GD_VSD_CONCURRENT=0 = one after the other).  The frozen UNet is queued FIRST: the side
+                # stream may still hold the previous iteration's LoRA backward pass and optimizer step (lora_stream()), and a
+                # graph launch keeps the host for about as long as the work in front of it on its stream takes.
+                cur = torch.cuda.current_stream(latents_noisy.device)
+                side = self._side_stream(latents_noisy.device)
+                inputs_ready = torch.cuda.Event()
+                inputs_ready.record(cur)
             noise_pred = self._frozen_unet(latent_model_input, tt, embeddings).float()
             noise_pred_cond, noise_pred_uncond = noise_pred.chunk(2)
             noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_cond - noise_pred_uncond)
-            if q_unet is None or pose is None:
-                raise NotImplementedError("VSD needs the LoRA UNet and a pose (sd_vsd_utils.py:192-197)")
-            v_q = self._q_nograd(q_unet, latents_noisy, t, self.embeddings["pos"].expand(batch_size, -1, -1).contiguous(),
-                                 pose, shading or "albedo").float()
+            if overlap:
+                side.wait_event(inputs_ready)
+                with torch.cuda.stream(side):
+                    v_q = self._q_nograd(q_unet, latents_noisy, t, text_q, pose, shading or "albedo").float()
+                cur.wait_stream(side)
+                v_q.record_stream(cur)
+            else:
+                v_q = self._q_nograd(q_unet, latents_noisy, t, text_q, pose, shading or "albedo").float()
             a = self.alphas[t].view(-1, 1, 1, 1)
             noise_pred_q = a.sqrt() * v_q + (1 - a).sqrt() * latents_noisy   # v -> eps
         w = (1 - self.alphas[t]).view(batch_size, 1, 1, 1)
@@ -291,27 +365,46 @@ class StableDiffusionVSD(nn.Module):
                         timesteps=None, noise=None, drop_pose: Optional[bool] = None):
         """One denoising-loss evaluation for the LoRA UNet (trainer.py:228-256): MSE to the velocity
         (or noise) target on the current latents; the caller backprops and steps its optimizer."""
-        with torch.no_grad():
-            latents_clean = latents.detach().expand(unet_bs, *latents.shape[1:]).contiguous()
-            pose_b = pose.expand(unet_bs, 16).contiguous()
-            if drop_pose is None:
-                drop_pose = bool(torch.rand(()) < uncond_p)
-            if drop_pose:
-                pose_b = torch.zeros_like(pose_b)
-            if timesteps is None:
-                timesteps = torch.randint(0, 1000, (unet_bs,), device=self.device).long()
-            if noise is None:
-                noise = torch.randn(latents_clean.shape, device=self.device)
-            latents_noisy = self.scheduler.add_noise(latents_clean, noise, timesteps)
-            target = self.scheduler.get_velocity(latents_clean, noise, timesteps) if v_pred else noise
-        graphed = self.use_hip_graphs and latents_noisy.is_cuda
-        if graphed:
-            _drain(latents_noisy.device)
-        out = self._q_train(q_unet, latents_noisy, timesteps,
-                            self.embeddings["pos"].expand(unet_bs, -1, -1).contiguous(), pose_b, shading)
-        if graphed and out.requires_grad:
-            out = _DrainBeforeBackward.apply(out)
-        return F.mse_loss(out.float(), target)
+        import contextlib
+        ctx = contextlib.nullcontext()
+        if _CONCURRENT and _TRAIN_STREAM and self.use_hip_graphs and latents.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # The training pass depends on the latents only -- not on the frozen UNet's score, not on the VAE backward pass the
+            # caller has queued since train_step.  It runs on the LoRA side stream (round 5): forward beside the VAE backward;
+            # autograd runs its backward on the stream of its forward and joins the caller's stream when backward() returns.
+            cur = torch.cuda.current_stream(latents.device)
+            side = self._side_stream(latents.device)
+            ev = getattr(self, "_ev_latents", None)
+            if ev is None or timesteps is not None or noise is not None:
+                side.wait_stream(cur)          # caller-made inputs (tests): produced on the caller's stream at an unknown time
+            else:
+                side.wait_event(ev)
+            ctx = torch.cuda.stream(side)
+        with ctx:
+            with torch.no_grad():
+                latents_clean = latents.detach().expand(unet_bs, *latents.shape[1:]).contiguous()
+                pose_b = pose.expand(unet_bs, 16).contiguous()
+                if drop_pose is None:
+                    drop_pose = bool(torch.rand(()) < uncond_p)
+                if drop_pose:
+                    pose_b = torch.zeros_like(pose_b)
+                if timesteps is None:
+                    timesteps = torch.randint(0, 1000, (unet_bs,), device=self.device).long()
+                if noise is None:
+                    noise = torch.randn(latents_clean.shape, device=self.device)
+                latents_noisy = self.scheduler.add_noise(latents_clean, noise, timesteps)
+                target = self.scheduler.get_velocity(latents_clean, noise, timesteps) if v_pred else noise
+            graphed = self.use_hip_graphs and latents_noisy.is_cuda
+            if graphed:
+                _drain(latents_noisy.device)
+            out = self._q_train(q_unet, latents_noisy, timesteps,
+                                self.embeddings["pos"].expand(unet_bs, -1, -1).contiguous(), pose_b, shading)
+            if graphed and out.requires_grad:
+                out = _DrainBeforeBackward.apply(out)
+            loss = F.mse_loss(out.float(), target)
+        if not isinstance(ctx, contextlib.nullcontext):
+            cur.wait_stream(side)            # the caller reads / differentiates the loss on ITS stream (the VAE backward queued there
+            loss.record_stream(cur)          # before this call still ran beside the forward pass)
+        return loss
 
 
 class LoraUnet(nn.Module):

@@ -154,15 +154,33 @@ def _check(ret, what, err="gd_nn_last_error"):
 
 
 _gn_ws_cache = {}
+_WS_TAG = [None]
+
+
+class workspace_tag:
+    """Kernels launched (or CAPTURED) inside use a GroupNorm workspace of their own: two hipGraphs that may be replayed
+    concurrently on different streams (sd_vsd.StableDiffusionVSD: the frozen UNet beside the LoRA UNet) were both captured on
+    torch's one capture stream, so the stream alone would hand them the same accumulators."""
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        self.prev, _WS_TAG[0] = _WS_TAG[0], self.tag
+        return self
+
+    def __exit__(self, *exc):
+        _WS_TAG[0] = self.prev
+        return False
 
 
 def _gn_workspace(x, N, groups):
-    """The zero-initialised GroupNorm statistics workspace of (device, current stream): every call leaves it zero
+    """The zero-initialised GroupNorm statistics workspace of (device, current stream, workspace_tag): every call leaves it zero
     (include/gd_nn.h), so it is allocated once and never memset again.  Keyed by stream because two streams may
     run GroupNorms concurrently; a workspace first needed during hipGraph capture is allocated (and kept alive
     here) in that graph's pool."""
     stream = torch.cuda.current_stream(x.device)
-    key = (x.device.index, stream.cuda_stream)
+    key = (x.device.index, stream.cuda_stream, _WS_TAG[0])
     need = lib().gd_nn_groupnorm_ws_bytes(N, groups)
     ws = _gn_ws_cache.get(key)
     if ws is None or ws.numel() < need:

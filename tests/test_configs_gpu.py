@@ -240,7 +240,7 @@ def _vsd_objects(kw_unet, kw_vae, dtype, graphs=False, fp32_adapters=True, **gd_
     return gd, lora, train, LoraUnet(lora)
 
 
-def _vsd_step(gd, q, train, seed, res=512, zero_grad=None):
+def _vsd_step(gd, q, train, seed, res=512, zero_grad=None, lora_stream=False):
     g = torch.Generator(DEV).manual_seed(seed)
     gd.set_text_embeds(torch.randn(1, 77, 1024, device=DEV, generator=g), torch.randn(1, 77, 1024, device=DEV, generator=g))
     leaf = torch.rand(1, 3, res, res, device=DEV, generator=g).requires_grad_(True)
@@ -261,7 +261,12 @@ def _vsd_step(gd, q, train, seed, res=512, zero_grad=None):
     else:
         for p in train:
             p.grad = None
-    lu.backward()
+    if lora_stream:                  # the adapters' backward pass on the guidance's LoRA stream, the caller's stream not waiting
+        with gd.lora_stream():
+            lu.backward()
+        gd.join_lora_stream()
+    else:
+        lu.backward()
     torch.cuda.synchronize()
     return leaf.grad.detach().float(), latents.detach().float(), float(lu), \
         {i: p.grad.detach().float().clone() for i, p in enumerate(train) if p.grad is not None}
@@ -336,6 +341,24 @@ def test_config4_vsd_step_reduced_width_matches_eager_fp32():
     assert c_lora > 0.8, c_lora
 
 
+_KW_U = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4))
+_KW_V = dict(block_out_channels=(64, 64, 128, 128))
+_TRAINED = []
+
+
+def _trained_fp32_vsd():
+    """The reduced-width fp32 eager VSD objects after five Adam steps (lr 1e-3) on the LoRA denoising loss: the state in which the
+    adapter gradients are a signal (non-zero up-projections that fit the data), built once per test session."""
+    if not _TRAINED:
+        gd32, lora32, train32, q32 = _vsd_objects(_KW_U, _KW_V, torch.float32)
+        opt = torch.optim.Adam(train32, lr=1e-3)
+        for it in range(5):
+            _vsd_step(gd32, q32, train32, seed=100 + it)        # leaves the LoRA loss's gradients in .grad
+            opt.step()
+        _TRAINED.append((gd32, lora32, train32, q32))
+    return _TRAINED[0]
+
+
 def test_config4_lora_gradients_at_a_trained_state_match_eager_fp32():
     """The adapter gradients where they can discriminate (round-4 review, weak 2): at random init every up-projection is zero,
     each adapter gradient is a token sum that cancels to ~1e-3 of its terms, and the bar above (cos > 0.8 on all of them as
@@ -344,13 +367,8 @@ def test_config4_lora_gradients_at_a_trained_state_match_eager_fp32():
     cancellation residue --, the trained adapters / embeddings are copied into the bf16 HIP network, and the gradients of one
     more iteration on identical inputs are compared: bar cos >= 0.999 on all adapter gradients as one vector and on the median
     tensor, >= 0.99 on the worst tensor (measured 0.99997 / 0.99997 / 0.9998)."""
-    kw_u = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4))
-    kw_v = dict(block_out_channels=(64, 64, 128, 128))
-    gd32, lora32, train32, q32 = _vsd_objects(kw_u, kw_v, torch.float32)
-    opt = torch.optim.Adam(train32, lr=1e-3)
-    for it in range(5):
-        _vsd_step(gd32, q32, train32, seed=100 + it)        # leaves the LoRA loss's gradients in .grad
-        opt.step()
+    kw_u, kw_v = _KW_U, _KW_V
+    gd32, lora32, train32, q32 = _trained_fp32_vsd()
     name_of = {id(p): n for n, p in lora32.named_parameters()}
     names = [name_of[id(p)] for p in train32]                # index i of the gradient dicts below = train32[i]
     ups = [p for p, n in zip(train32, names) if n.endswith("up.weight")]
@@ -398,6 +416,65 @@ def test_config4_vsd_step_hipgraph_replay_matches_eager():
         keys = [i for i in g_e if float(g_e[i].abs().max()) > 0]
         assert set(keys) <= set(g_g)
         assert _cos(torch.cat([g_e[i].flatten() for i in keys]), torch.cat([g_g[i].flatten() for i in keys])) > 0.8
+
+
+def test_config4_frozen_and_lora_forwards_on_two_streams_give_the_one_after_the_other_result(monkeypatch):
+    """Round 5: in ``train_step`` the frozen UNet (2 latents) and the LoRA UNet's no-grad forward (1 latent) replay their hipGraphs
+    CONCURRENTLY on two streams (each has its own capture stream, hence its own library-GEMM workspace, and its own GroupNorm
+    accumulators).  Full-size networks, six iterations on fresh inputs each way: the image gradient -- which mixes both networks'
+    outputs -- and the latents agree with the one-after-the-other run to the level two runs of the SAME schedule agree (the
+    library's stream-K GEMMs are not bitwise reproducible), every time."""
+    from garmentdreamer_amd.guidance import sd_vsd
+    out = {}
+    for conc in (False, True):
+        monkeypatch.setattr(sd_vsd, "_CONCURRENT", conc)
+        gd, lora, train, q = _vsd_objects({}, {}, torch.bfloat16, graphs=True)
+        out[conc] = [_vsd_step(gd, q, train, seed=40 + i) for i in range(6)]
+        assert gd.use_hip_graphs, "capture fell back to eager launches"
+        del gd, lora, train, q
+        torch.cuda.empty_cache()
+    worst = 1.0
+    for (di_s, lat_s, lu_s, _), (di_c, lat_c, lu_c, _) in zip(out[False], out[True]):
+        assert torch.isfinite(di_c).all() and float(di_c.abs().sum()) > 0
+        assert _cos(lat_s, lat_c) > 0.99999
+        worst = min(worst, _cos(di_s, di_c))
+        assert abs(lu_s - lu_c) <= 2e-3 * abs(lu_s)
+    parity_report.record("configs[4] VSD step, full size: frozen + LoRA no-grad forwards on two streams vs one after the other", "step",
+                         min_cos_dL_dimage=worst)
+    assert worst > 0.9999, worst
+
+
+def test_config4_lora_backward_on_the_lora_stream_gives_the_callers_stream_gradients():
+    """``StableDiffusionVSD.lora_stream()`` (round 5): the adapters' backward pass runs on the LoRA side stream without the caller's
+    stream waiting for it.  At the trained state of the test above (adapter gradients are a signal there; with untrained
+    up-projections two runs of ANY schedule give uncorrelated adapter gradients, tools/lora_grad_repro.py; profiles/r05_lora_grad_repro.txt) the gradients of
+    four iterations on fresh inputs -- zeroed on the CALLER's stream right before each backward pass, which the side stream
+    therefore has to wait for -- agree with the caller's-stream schedule as well as that schedule reproduces itself."""
+    _, _, train32, _ = _trained_fp32_vsd()
+    runs = {}
+    for name, ls in (("plain", False), ("plain again", False), ("lora stream", True)):
+        gd, lora, train, q = _vsd_objects(_KW_U, _KW_V, torch.bfloat16, graphs=True)
+        with torch.no_grad():
+            for p16, p32 in zip(train, train32):
+                p16.copy_(p32.to(p16.dtype))
+        runs[name] = [_vsd_step(gd, q, train, seed=60 + i, lora_stream=ls) for i in range(4)]
+        assert gd.use_hip_graphs
+        names = {id(p): n for n, p in lora.named_parameters()}
+        idx = [i for i, p in enumerate(train) if "lora" in names[id(p)]]
+        del gd, lora, train, q
+        torch.cuda.empty_cache()
+    cat = lambda gr: torch.cat([gr[i].flatten() for i in idx])
+    worst_self, worst_ls = 1.0, 1.0
+    for it in range(4):
+        ref, again, ls = (runs[k][it] for k in ("plain", "plain again", "lora stream"))
+        assert set(idx) <= set(ls[3]) and all(torch.isfinite(ls[3][i]).all() for i in idx)
+        c_self, c_ls = _cos(cat(ref[3]), cat(again[3])), _cos(cat(ref[3]), cat(ls[3]))
+        worst_self, worst_ls = min(worst_self, c_self), min(worst_ls, c_ls)
+        assert _cos(ref[0], ls[0]) > 0.9999 and abs(ref[2] - ls[2]) <= 1e-2 * abs(ref[2])
+    parity_report.record("configs[4] VSD step, reduced width, trained adapters: LoRA backward on the LoRA stream vs the caller's stream",
+                         "step", min_cos_all_lora_grads=worst_ls, min_cos_same_schedule_twice=worst_self)
+    assert worst_self > 0.99, worst_self                     # the state the comparison needs: reproducible gradients
+    assert worst_ls > 0.99 and worst_ls > worst_self - 5e-3, (worst_self, worst_ls)
 
 
 def test_config4_vsd_graphed_iteration_with_flat_adam_gradient_sinks():
