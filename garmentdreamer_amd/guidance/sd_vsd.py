@@ -165,6 +165,7 @@ class StableDiffusionVSD(nn.Module):
         name = "_side_train" if train and _THREE_STREAMS else "_side"
         st = getattr(self, name, None)
         if st is None or st.device != device:
+            # default priority: a high-priority training stream (priority=-1) measured 61 ms per iteration against 25 (round 5)
             st = torch.cuda.Stream(device=device)
             setattr(self, name, st)
         return st
