@@ -397,8 +397,10 @@ class StableDiffusionVSD(nn.Module):
             cur = torch.cuda.current_stream(latents.device)
             side = self._side_stream(latents.device, train=True)
             ev = getattr(self, "_ev_latents", None)
+            self._ev_latents = None            # good for ONE call: a second training pass after the same train_step (trainer.py's
+            #                                    K loop) must also see the optimizer step the caller ran in between on ITS stream
             if ev is None or timesteps is not None or noise is not None:
-                side.wait_stream(cur)          # caller-made inputs (tests): produced on the caller's stream at an unknown time
+                side.wait_stream(cur)          # caller-made inputs (tests) / repeated call: everything the caller queued so far
             else:
                 side.wait_event(ev)
             ctx = torch.cuda.stream(side)

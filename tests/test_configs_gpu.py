@@ -477,6 +477,48 @@ def test_config4_lora_backward_on_the_lora_stream_gives_the_callers_stream_gradi
     assert worst_ls > 0.99 and worst_ls > worst_self - 5e-3, (worst_self, worst_ls)
 
 
+def test_config4_two_lora_training_passes_after_one_train_step_see_the_optimizer_step_in_between(monkeypatch):
+    """trainer.py's K loop: ``lora_train_loss`` -> backward -> optimizer step TWICE after one ``train_step``, the optimizer on the
+    caller's stream (the reference's unedited sequence).  The training pass runs on its own stream behind an event recorded after
+    the latents -- good for one call only: the second pass has to wait for the optimizer step the caller ran in between.  With a
+    large learning rate the second loss depends on that step: the three-stream schedule reproduces the one-stream losses."""
+    from garmentdreamer_amd.guidance import sd_vsd
+    _, _, train32, _ = _trained_fp32_vsd()
+    out = {}
+    for conc in (False, True):
+        monkeypatch.setattr(sd_vsd, "_CONCURRENT", conc)
+        gd, lora, train, q = _vsd_objects(_KW_U, _KW_V, torch.bfloat16, graphs=True)
+        with torch.no_grad():
+            for p16, p32 in zip(train, train32):
+                p16.copy_(p32.to(p16.dtype))
+        opt = torch.optim.Adam(train, lr=3e-2)
+        g = torch.Generator(DEV).manual_seed(5)
+        gd.set_text_embeds(torch.randn(1, 77, 1024, device=DEV, generator=g), torch.randn(1, 77, 1024, device=DEV, generator=g))
+        leaf = torch.rand(1, 3, 512, 512, device=DEV, generator=g).requires_grad_(True)
+        pose = torch.randn(1, 16, device=DEV, generator=g)
+        losses = []
+        for it in range(3):                          # iteration 0 captures the graphs
+            torch.manual_seed(1000 + it)
+            loss, _, latents = gd.train_step(leaf, guidance_scale=7.5, q_unet=q, pose=pose, shading="albedo")
+            loss.backward()
+            for k in range(2):
+                lu = gd.lora_train_loss(q, latents, pose, shading="albedo", unet_bs=1, drop_pose=False)
+                opt.zero_grad(set_to_none=True)
+                lu.backward()
+                opt.step()
+                losses.append(float(lu))
+        torch.cuda.synchronize()
+        assert gd.use_hip_graphs and all(math.isfinite(v) for v in losses)
+        out[conc] = losses
+        del gd, lora, train, q, opt
+        torch.cuda.empty_cache()
+    a, b = out[False], out[True]
+    assert max(abs(x - y) / abs(x) for x, y in zip(a, b)) <= 3e-2, (a, b)
+    # the state the test needs: at this learning rate the losses move by far more than that from pass to pass (1.25 ... 0.2 measured),
+    # so a pass that read the adapters before (or while) the optimizer step in front of it wrote them would not land within 3 %
+    assert max(a) / min(a) > 3.0, a
+
+
 def test_config4_vsd_graphed_iteration_with_flat_adam_gradient_sinks():
     """The graphed VSD iteration with flat_adam.FlatAdam owning the adapters' gradients (the LoRA backward kernels inside the
     hipGraph add into slices of its flat buffer) against eager launches with plain autograd gradients, same weights (lr = 0).
