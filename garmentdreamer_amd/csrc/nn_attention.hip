@@ -21,7 +21,11 @@
 namespace {
 
 thread_local char g_err[256] = "";
+#ifndef GD_ATTN_ABLATE
+#define GD_ATTN_ABLATE 0   // timing builds only (tools/attn_ablate.sh): 1 no exp2, 2 no LDS-DMA after the prologue, 3 no MFMA, 4 no LDS fragment reads, 5 no running-maximum pass, 6 no per-tile barrier
+#endif
 int g_attn_waves = 0;   // GD_NN_ATTN_WAVES = 4 / 8 forces the workgroup size (tuning)
+int g_attn_xcd = 1;     // GD_NN_ATTN_XCD=0: query tiles dealt round-robin over the XCDs (A/B)
 int fail(int code, const char* msg)
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -104,17 +108,31 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
                                                            int Skv, int H, int64_t q_bs, int q_rs, int64_t k_bs, int k_rs,
                                                            int64_t o_bs, int o_rs, float c /* scale * log2(e) */, int kv_len,
                                                            float* __restrict__ lse /* [B][H][S] natural-log sum-exp of the scaled scores, or NULL */,
-                                                           int64_t vt_bs /* elements between the V^T images of two batch entries */)
+                                                           int64_t vt_bs /* elements between the V^T images of two batch entries */,
+                                                           int xcd_remap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                 // 3 stages
     char* sV = smem + 3 * kTile;     // 3 stages
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y / H, h = blockIdx.y - b * H;
+    // XCD-aware order (round 5): workgroups are dealt to the eight XCDs round-robin by their linear index, and every workgroup of a
+    // (batch, head) streams that head's whole K / V^T (1 MB at 4096 keys): with the query tiles of a head spread over all XCDs each
+    // private L2 fetched every head.  The linear index is re-dealt so that consecutive query tiles -- one head -- share an XCD.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const unsigned gx = gridDim.x, total = gx * gridDim.y;
+        if (xcd_remap && (total & 7u) == 0) {
+            const unsigned id = blockIdx.x + gx * blockIdx.y;
+            const unsigned id2 = (id & 7u) * (total >> 3) + (id >> 3);
+            by = (int)(id2 / gx);
+            bx = (int)(id2 - (unsigned)by * gx);
+        }
+    }
+    const int b = by / H, h = by - b * H;
     const int fh = lane >> 5, fn = lane & 31;
     constexpr int THREADS = 64 * WAVES, NP = 512 / THREADS;   // 16-byte pieces of a 64 x 64 tile per thread
-    const int qrow = blockIdx.x * (32 * WAVES) + wave * 32 + fn;
+    const int qrow = bx * (32 * WAVES) + wave * 32 + fn;
     const int qld = qrow < S ? qrow : S - 1;
 
     // Q fragments (B operand of S^T = K Q^T): lane (query fn, half fh) holds d = 16 kk + 8 fh .. + 7
@@ -167,10 +185,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
         for (int r = 0; r < 16; r++) s0[r] = s1[r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
+#if GD_ATTN_ABLATE == 4
+            const bf16x8_t k0 = qf[kk ^ 1], k1 = qf[kk ^ 2];
+#else
             const bf16x8_t k0 = *(const bf16x8_t*)(pk + (krd[0] ^ (uint32_t)(kk << 5)));
             const bf16x8_t k1 = *(const bf16x8_t*)(pk + (krd[1] ^ (uint32_t)(kk << 5)));
+#endif
+#if GD_ATTN_ABLATE == 3
+            s0[kk] += __builtin_bit_cast(float, (int)k0[0]); s1[kk] += __builtin_bit_cast(float, (int)k1[1]);
+#else
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kk], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], s1, 0, 0, 0);
+#endif
         }
         if ((tile + 1) * kTk > kv_len) {      // last tile of a key count that is not a multiple of 64 (cross-attention:
 #pragma unroll                                   // 77 text tokens): padded keys get no weight
@@ -184,6 +210,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
     };
     // Part 1 of the online softmax of the lane's 64 scores: the (deferred) running maximum.
     auto update_max = [&](const f32x16& s0, const f32x16& s1) {
+        // (a tree of v_max3_f32 instead of this chain measured the same, 457 us either way: tools/attn_ablate.sh)
         float mx = s0[0];
 #pragma unroll
         for (int r = 1; r < 16; r++) mx = fmaxf(mx, s0[r]);
@@ -216,10 +243,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const f2 a = f2{s0[r], s0[r + 1]} * c2 + nmc, b = f2{s1[r], s1[r + 1]} * c2 + nmc;
+#if GD_ATTN_ABLATE == 1
+            s0[r] = a.x; s0[r + 1] = a.y; s1[r] = b.x; s1[r + 1] = b.y;
+#else
             s0[r] = __builtin_amdgcn_exp2f(a.x);
             s0[r + 1] = __builtin_amdgcn_exp2f(a.y);
             s1[r] = __builtin_amdgcn_exp2f(b.x);
             s1[r + 1] = __builtin_amdgcn_exp2f(b.y);
+#endif
             psum += f2{s0[r], s0[r + 1]} + f2{s1[r], s1[r + 1]};
         }
         l_run += psum.x + psum.y;
@@ -238,10 +269,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
         }
 #pragma unroll
         for (int g16 = 0; g16 < 4; g16++) {      // 16-key group g16 = 2j + u -> chunks 2 g16 + fh
+#if GD_ATTN_ABLATE == 4
+            const bf16x8_t v0 = pb[g16 ^ 1], v1 = pb[g16 ^ 2];
+#else
             const bf16x8_t v0 = *(const bf16x8_t*)(pv + (vrd[0] ^ (uint32_t)(g16 << 5)));
             const bf16x8_t v1 = *(const bf16x8_t*)(pv + (vrd[1] ^ (uint32_t)(g16 << 5)));
+#endif
+#if GD_ATTN_ABLATE == 3
+            o0[g16] += __builtin_bit_cast(float, (int)v0[0]) + __builtin_bit_cast(float, (int)pb[g16][0]);
+            o1[g16] += __builtin_bit_cast(float, (int)v1[1]) + __builtin_bit_cast(float, (int)pb[g16][1]);
+#else
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb[g16], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb[g16], o1, 0, 0, 0);
+#endif
         }
     };
 
@@ -256,10 +296,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
     f32x16 sa0, sa1, sb0, sb1;
     qk(sK, sa0, sa1, 0);
     auto iteration = [&](int t, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+        if (GD_ATTN_ABLATE != 6) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t+1 (issued one iteration ago) has landed
         __syncthreads();                                      // ... for every wave; stage (t+2)%3 is free again
-        if (t + 2 < ntiles) issue((t + 2) % 3, t + 2);
-        update_max(c0, c1);
+        }
+        if (GD_ATTN_ABLATE != 2 && t + 2 < ntiles) issue((t + 2) % 3, t + 2);
+        if (GD_ATTN_ABLATE != 5) update_max(c0, c1);
         qk(sK + ((t + 1) % 3) * kTile, n0, n1, t + 1);
         exp_pv(c0, c1, sV + (t % 3) * kTile);
     };
@@ -582,17 +624,18 @@ static int launch_attention(hipStream_t s, const void* q, const void* k, const v
 {
     if (vt_bs < 0) vt_bs = (int64_t)H * kD * Skv;      // contiguous [B][H][64][Skv]
     if (const char* e = getenv("GD_NN_ATTN_WAVES")) g_attn_waves = atoi(e);
+    if (const char* e = getenv("GD_NN_ATTN_XCD")) g_attn_xcd = atoi(e);      // 0: round-robin over the XCDs as before round 5 (A/B)
     const float c = scale * 1.4426950408889634f;
     int waves = 4;     // 8 waves per workgroup measured the same at batch 16 and worse on small grids (tools/attn_bench.py)
     if (g_attn_waves == 4 || g_attn_waves == 8) waves = g_attn_waves;
     if (waves == 8)
         hipLaunchKernelGGL(attn_fwd_d64_kernel<8>, dim3((S + 255) / 256, B * H), dim3(512), 6 * kTile, s, (const uint16_t*)q,
                            (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
-                           o_rs, c, kv_len, lse, vt_bs);
+                           o_rs, c, kv_len, lse, vt_bs, g_attn_xcd);
     else
         hipLaunchKernelGGL(attn_fwd_d64_kernel<4>, dim3((S + 127) / 128, B * H), dim3(256), 6 * kTile, s, (const uint16_t*)q,
                            (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, S, Skv, H, q_bs, q_rs, k_bs, k_rs, o_bs,
-                           o_rs, c, kv_len, lse, vt_bs);
+                           o_rs, c, kv_len, lse, vt_bs, g_attn_xcd);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
     return GD_NN_OK;
