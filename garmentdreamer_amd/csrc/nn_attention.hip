@@ -22,7 +22,7 @@ namespace {
 
 thread_local char g_err[256] = "";
 #ifndef GD_ATTN_ABLATE
-#define GD_ATTN_ABLATE 0   // timing builds only (tools/attn_ablate.sh): 1 no exp2, 2 no LDS-DMA after the prologue, 3 no MFMA, 4 no LDS fragment reads, 5 no running-maximum pass, 6 no per-tile barrier
+#define GD_ATTN_ABLATE 0   // timing builds only (tools/attn_ablate.sh): 1 no exp2, 2 no LDS-DMA after the prologue, 3 no MFMA, 4 no LDS fragment reads, 5 no running-maximum pass, 6 no per-tile barrier, 9 / 10 orders of the loop head
 #endif
 int g_attn_waves = 0;   // GD_NN_ATTN_WAVES = 4 / 8 forces the workgroup size (tuning)
 int g_attn_xcd = 1;     // GD_NN_ATTN_XCD=0: query tiles dealt round-robin over the XCDs (A/B)
@@ -300,9 +300,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_fwd_d64_kernel(const uint1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t+1 (issued one iteration ago) has landed
         __syncthreads();                                      // ... for every wave; stage (t+2)%3 is free again
         }
-        if (GD_ATTN_ABLATE != 2 && t + 2 < ntiles) issue((t + 2) % 3, t + 2);
-        if (GD_ATTN_ABLATE != 5) update_max(c0, c1);
+#if GD_ATTN_ABLATE == 9      // the round-4 order (same-box A/B): DMA issue, running maximum, THEN the next tile's score MFMAs
+        if (t + 2 < ntiles) issue((t + 2) % 3, t + 2);
+        update_max(c0, c1);
         qk(sK + ((t + 1) % 3) * kTile, n0, n1, t + 1);
+#elif GD_ATTN_ABLATE == 10   // experiment: the DMA issue behind the score MFMAs too
+        qk(sK + ((t + 1) % 3) * kTile, n0, n1, t + 1);
+        if (t + 2 < ntiles) issue((t + 2) % 3, t + 2);
+        update_max(c0, c1);
+#else
+        // the next tile's score MFMAs go FIRST: they do not depend on the running maximum, and issued in front of it they are in
+        // flight under its 31 dependent v_max, the cross-half shuffle and the (rarely taken) rescale branch -- the matrix pipe
+        // idled through that block before (450 -> 432 us at 16 x 5 heads x 4096^2, profiles/r05_attn_ablation.txt)
+        if (GD_ATTN_ABLATE != 2 && t + 2 < ntiles) issue((t + 2) % 3, t + 2);
+        qk(sK + ((t + 1) % 3) * kTile, n0, n1, t + 1);
+        if (GD_ATTN_ABLATE != 5) update_max(c0, c1);
+#endif
         exp_pv(c0, c1, sV + (t % 3) * kTile);
     };
     int t = 0;
