@@ -374,8 +374,10 @@ def vsd_main(args):
 
     for _ in range(args.warmup):
         step()
+    tele = Telemetry(device.index)
     gdist.barrier()
     torch.cuda.synchronize()
+    tele.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -383,6 +385,7 @@ def vsd_main(args):
     gdist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    telemetry = tele.stop()
     # health (untimed): a replayed graph that went wrong shows up as non-finite adapters / image gradient
     with torch.no_grad():
         health = {"lora_params_finite": all(bool(torch.isfinite(p).all()) for p in train),
@@ -402,11 +405,14 @@ def vsd_main(args):
                           "config": {"workload": f"VSD step, SD-2.1 UNet + LoRA UNet (rank 4) random-init, batch 1, {res}^2 image leaf"
                                                  + (" reduced to 512^2 for the VAE" if res != 512 else ""),
                                      "hip_graphs": bool(gd.use_hip_graphs), "fp8_unet": bool(gd.fp8_unet),
+                                     "streams": ("three (caller: VAE + frozen UNet; LoRA no-grad forward; LoRA training pass + optimizer "
+                                                 "step inside guidance.lora_stream())" if _LORA_STREAM else
+                                                 "three inside the guidance, the reference's unedited call sequence"),
                                      "torch_host_syncs_per_step_observed": host_syncs["count"],
                                      "torch_host_sync_sites": host_syncs["sites"],
                                      "fp8_sites_run": sum(getattr(n, "fp8").sites_run for n in (gd.unet, lora)
                                                           if getattr(n, "fp8", None) is not None)},
-                          "health": health,
+                          "health": health, "telemetry": telemetry,
                           "roofline_dense": {"bound": "mfma", "achieved": tfl / (el / args.steps),
                                              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                              "frac": tfl / (el / args.steps) / PEAK_BF16_TFLOPS}})
