@@ -325,7 +325,7 @@ def vsd_main(args):
     from garmentdreamer_amd.guidance.sd_vsd import LoraUnet, StableDiffusionVSD
     check_world(args, int(os.environ.get("WORLD_SIZE", "1")), need_gpus=True)
     rk, lr, ws = gdist.init_from_env()
-    device = torch.device("cuda", lr)
+    device = torch.device("cuda", lr % torch.cuda.device_count())   # (ranks may share a GPU only under GD_DIST_BACKEND=gloo)
     torch.cuda.set_device(device)
     gd = StableDiffusionVSD(device, fp16=True, use_hip_graphs=not args.no_graphs, fp8_unet=bool(args.fp8))
     with torch.device(device):
