@@ -198,6 +198,9 @@ def parse():
                     help="SDSLoop(batch_invariant=True): kernels (and bf16 summation orders) selected for the WHOLE camera batch "
                          "on every rank, so a sharded run reproduces the single-rank gradients per view bit for bit; off by "
                          "default (each rank tunes its launches for its own share); recorded in the line's config")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="diagnostic, one process: with --batch-invariant route the kernels as rank 0 of a K-rank run would (what "
+                         "the bit-for-bit sharded mode costs a rank with 1/K of the views); recorded in the line's config")
     ap.add_argument("--stub-step", action="store_true",
                     help="TEST ONLY (tests/test_bench_launch.py): replace the SDS iteration by one small all-reduce so the "
                          "launch / rank-accounting logic of --gpus N can be exercised on CPU over gloo; the line it prints "
@@ -568,7 +571,8 @@ def main():
                                            device=device)
         prompt = PromptEmbeddings.random(device)
     loop = SDSLoop(gaussians, guidance, prompt, bg, batch_invariant=bool(args.batch_invariant),
-                   sync_free=not args.host_sync_raster)
+                   sync_free=not args.host_sync_raster,
+                   route_as=(args.simulate_world, 0) if args.simulate_world > 1 else None)
     if args.per_view_raster:
         from garmentdreamer_amd.gaussian_renderer import render
 
@@ -807,6 +811,7 @@ def main():
                                           getattr(guidance.unet, "fp8", None) is not None else 0),
                        "kernels_per_step": kernels_per_step,
                        "batch_invariant": bool(loop.batch_invariant),
+                       "batch_invariant_route_scale": (loop._route_kr()[0] if loop.batch_invariant else 1),
                        "raster_forward_host_syncs_in_timed_region": (
                            0 if loop.capacity is not None and loop.capacity.calls_sync_free >= args.warmup + args.steps - 1
                            else args.steps),

@@ -48,7 +48,8 @@ def _newer(target: str, deps) -> bool:
 
 def _headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hs.append(os.path.join(HERE, "..", "include", "gd_raster.h"))
+    inc = os.path.join(HERE, "..", "include")
+    hs += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]   # gd_raster.h, gd_nn.h, gd_scene.h
     return hs
 
 

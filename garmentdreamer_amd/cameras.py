@@ -168,6 +168,34 @@ def orbit_batch(n_views: int, elevation_deg: float = 15.0, camera_distance: floa
     }
 
 
+def random_batch(n_views: int, generator=None, camera_distance_range=(1.5, 4.0), fovy_range_deg=(40.0, 70.0),
+                 elevation_range_deg=(-10.0, 60.0), height: int = 512, width: int = 512, view_ids=None):
+    """A camera batch drawn like the reference's training data module draws one: per view an independent
+    ``camera_distance`` in [1.5, 4.0], ``fovy`` in [40, 70] degrees (configs/gaussiandreamer-sd.yaml:11-12), elevation and
+    azimuth uniform in their ranges (threestudio/data/uncond.py, RandomCameraIterableDataset.collate: default elevation range
+    (-10, 60), azimuth (-180, 180)).  The projected area of the scene varies up to ~25x from view to view, which is what the
+    rasterizer's sync-free instance capacity has to survive (tests/test_scene_gpu.py).  Same dict as ``orbit_batch``;
+    ``view_ids`` selects this rank's views AFTER the draw so that every rank draws the same batch from a same-seeded
+    generator."""
+    u = torch.rand(n_views, 4, generator=generator)
+    dist = camera_distance_range[0] + (camera_distance_range[1] - camera_distance_range[0]) * u[:, 0]
+    fovy = fovy_range_deg[0] + (fovy_range_deg[1] - fovy_range_deg[0]) * u[:, 1]
+    elev = elevation_range_deg[0] + (elevation_range_deg[1] - elevation_range_deg[0]) * u[:, 2]
+    az = -180.0 + 360.0 * u[:, 3]
+    ids = list(range(n_views)) if view_ids is None else list(view_ids)
+    c2w = torch.stack([c2w_3dgs(float(az[i]), float(elev[i]), float(dist[i])) for i in ids], 0)
+    sel = torch.tensor(ids, dtype=torch.long)
+    return {
+        "c2w_3dgs": c2w,
+        "fovy": torch.deg2rad(fovy[sel]),
+        "height": height,
+        "width": width,
+        "elevation": elev[sel].clone(),
+        "azimuth": az[sel].clone(),
+        "camera_distances": dist[sel].clone(),
+    }
+
+
 class CameraBatch:
     """V cameras packed for the batched rasterizer: one upload for all matrices."""
 

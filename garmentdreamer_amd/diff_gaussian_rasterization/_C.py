@@ -193,8 +193,15 @@ class InstanceCapacity:
         self.value = None            # capacity of the next call; None -> synchronising path
         self.last_count = None       # num_rendered of the most recent call whose count has been read
         self.calls_sync_free = 0
+        self.overflows = 0           # sync-free calls that overflowed and were noticed through overflowed() / collect()
+        self.last_capacity = None
         self._dev = self._host = self._event = None
         self._pending = False
+
+    @property
+    def pending(self) -> bool:
+        """The most recent call ran sync-free and its count has not been looked at yet."""
+        return self._pending
 
     def reset(self):
         self.collect()
@@ -224,19 +231,32 @@ class InstanceCapacity:
         self._pending = True
         self.calls_sync_free += 1
 
-    def collect(self):
-        """Look at the previous sync-free call's count (a wait only if the GPU has not reached that copy yet)."""
+    def overflowed(self) -> bool:
+        """Look at the most recent sync-free call's count NOW (a wait only if the GPU has not reached that copy yet) and say
+        whether that call overflowed -- without raising.  A training loop calls this BEFORE it lets the call's results reach
+        an optimizer (SDSLoop.step: after the guidance forward, when the copy landed long ago) and, on True, repeats the render:
+        the capacity has been dropped, so the repeat takes the synchronising path and re-seeds it."""
         if not self._pending:
-            return
+            return False
         self._event.synchronize()
         self._pending = False
         total, _live, over, cap = (int(v) & 0xffffffff for v in self._host.tolist())
-        self.last_count = total
+        self.last_count, self.last_capacity = total, cap
         if over:
             self.value = None
-            raise RuntimeError(f"rasterizer: the previous sync-free forward pass overflowed its instance capacity "
-                               f"({total} instances > capacity {cap}): it rendered nothing and its results are void")
+            self._recent = []
+            self.overflows += 1
+            return True
         self.value = self._round(total)
+        return False
+
+    def collect(self):
+        """Look at the previous sync-free call's count (a wait only if the GPU has not reached that copy yet); RAISES if that
+        call overflowed and nobody asked ``overflowed()`` in between (its results were used unchecked)."""
+        if self.overflowed():
+            raise RuntimeError(f"rasterizer: the previous sync-free forward pass overflowed its instance capacity "
+                               f"({self.last_count} instances > capacity {self.last_capacity}): it rendered nothing and its "
+                               f"results are void")
 
 
 def rasterize_gaussians_batched(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,

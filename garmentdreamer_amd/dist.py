@@ -124,26 +124,72 @@ class PendingMax:
     rides in the tail slot of the integer buffer.  ``start`` right after the rasterizer's forward pass, ``finish``
     where the results are first needed -- the collective then runs beside the guidance forward on RCCL's stream."""
 
-    def __init__(self, radii_local: torch.Tensor, local_max: torch.Tensor):
+    def __init__(self, radii_local: torch.Tensor, local_max: torch.Tensor, flag: Optional[torch.Tensor] = None):
+        """``flag``: optional int32 [1] device tensor that rides in one more tail slot (max over ranks = logical OR of a 0/1
+        flag): the sync-free rasterizer's overflow flag, so that every rank takes the same repeat-the-render decision
+        (SDSLoop.step).  Its reduced value travels to pinned host memory on a side stream as soon as the collective ends;
+        ``flag_any()`` waits for that copy only -- not for the work queued on the caller's stream in the meantime."""
         if radii_local.dtype != torch.int32 or local_max.dtype != torch.float32:
             raise TypeError("PendingMax: radii must be int32 and the depth maximum fp32")
         self.local_max = local_max
         self.n = radii_local.numel()
         # clamp: a negative zero / negative value would order wrongly as an integer (depths are sums of w * depth >= 0)
         tail = local_max.detach().clamp_min(0.0).reshape(1).view(torch.int32)
-        self.buf = torch.cat([radii_local.reshape(-1), tail])
+        parts = [radii_local.reshape(-1), tail]
+        self._has_flag = flag is not None
+        if self._has_flag:
+            parts.append(flag.reshape(1).to(torch.int32))
+        self.buf = torch.cat(parts)
         self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.MAX, async_op=True) if collectives_on() else None
+        self._flag_host = self._flag_event = None
+        if self._has_flag:
+            if self.buf.is_cuda:
+                cur = torch.cuda.current_stream(self.buf.device)
+                side = _flag_stream(self.buf.device)
+                side.wait_stream(cur)                     # the buffer was assembled on the caller's stream
+                with torch.cuda.stream(side):
+                    if self.work is not None:
+                        self.work.wait()                  # RCCL: orders `side` behind the collective, no host wait
+                    self._flag_host = torch.empty(1, dtype=torch.int32).pin_memory()
+                    self._flag_host.copy_(self.buf[self.n + 1:], non_blocking=True)
+                    self._flag_event = torch.cuda.Event()
+                    self._flag_event.record(side)
+                self.buf.record_stream(side)
+            else:
+                if self.work is not None:
+                    self.work.wait()
+                    self.work = None
+                self._flag_host = self.buf[self.n + 1:].clone()
+
+    def flag_any(self) -> bool:
+        """Whether ANY rank raised the flag (identical on every rank)."""
+        if not self._has_flag:
+            return False
+        if self._flag_event is not None:
+            self._flag_event.synchronize()
+        return bool(int(self._flag_host[0]))
 
     def finish(self):
         """-> (radii max over every rank's views [P] int32, global depth maximum attached to the autograd graph)."""
         if self.work is not None:
             self.work.wait()
             self.work = None
-        g = self.buf[self.n:].view(torch.float32).reshape(())
+        g = self.buf[self.n:self.n + 1].view(torch.float32).reshape(())
         radii = self.buf[:self.n]
         if collectives_on():
             return radii, _GlobalMaxKnown.apply(self.local_max, g)
         return radii, self.local_max
+
+
+_FLAG_STREAMS = {}
+
+
+def _flag_stream(device):
+    """One side stream per device for the reduced overflow flag's trip to the host (PendingMax)."""
+    key = torch.device(device).index
+    if key not in _FLAG_STREAMS:
+        _FLAG_STREAMS[key] = torch.cuda.Stream(device)
+    return _FLAG_STREAMS[key]
 
 
 class _ScaleGrad(torch.autograd.Function):

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -374,22 +375,32 @@ _WINO = os.environ.get("GD_NN_WINO", "1") != "0"
 _ROUTE_SCALE = 1
 _ROUTE_RANK = 0
 _ROUTE_BATCH = None     # (groups, samples) of the call in flight, see route_batch
+_ROUTE_OWNER = None     # weakref to the object that set the routing last (set_route_scale(owner=), release_route_scale)
 
 
-def set_route_scale(k: int, rank: int = 0) -> None:
+def set_route_scale(k: int, rank: int = 0, owner=None) -> None:
     """Batch-invariant kernel selection (include/gd_nn.h gd_nn_conv_set_route_scale): every routing rule in this
     module and in the library that looks at the batch sees N * k images.  The sharded loop sets k = world size when
     asked for `batch_invariant` gradients, so a rank with 1/k of the views runs the kernels (and bf16 summation
     orders) the single-rank run of the whole camera batch runs; k = 1 tunes each launch for the batch it gets.
     `rank`: this rank's position among the k shares (dist.shard_views deals view v to rank v % k) -- the library GEMMs
     are given their rows at the positions the single-rank batch holds them (route_rows)."""
-    global _ROUTE_SCALE, _ROUTE_RANK
+    global _ROUTE_SCALE, _ROUTE_RANK, _ROUTE_OWNER
     k, rank = int(k), int(rank)
     if not 0 <= rank < max(k, 1):
         raise ValueError(f"rank {rank} outside 0..{k - 1}")
     if lib().gd_nn_conv_set_route_scale(k) != 0:
         raise ValueError(f"route scale must be >= 1, got {k}")
     _ROUTE_SCALE, _ROUTE_RANK = k, rank
+    _ROUTE_OWNER = weakref.ref(owner) if owner is not None else None
+
+
+def release_route_scale(owner) -> None:
+    """Back to k = 1 -- but only if `owner` is still the object that set the routing last (``set_route_scale(...,
+    owner=)``): an old loop's close() / __del__ must not undo the setting of the loop that replaced it."""
+    cur = _ROUTE_OWNER() if _ROUTE_OWNER is not None else None
+    if cur is owner:
+        set_route_scale(1, 0)
 
 
 def route_scale() -> int:

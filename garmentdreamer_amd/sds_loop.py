@@ -88,22 +88,26 @@ class SDSLoop:
                  render_batch_fn: Optional[Callable] = None, lambda_sds: float = 1.0, lambda_sparsity: float = 1.0,
                  lr_scale: float = 1.0, fused_adam: Optional[bool] = None, densify: bool = True,
                  cameras_extent: float = 4.0, densify_seed: int = 0, batch_invariant: bool = False,
-                 sync_free: bool = True, capacity_margin: float = 1.5):
+                 sync_free: bool = True, capacity_margin: float = 1.5, capacity_quantum: int = 1 << 16, route_as: Optional[tuple] = None):
         self.gaussians = gaussians
         # forward pass without the host read-back of the instance count (rasterizer_impl.cu:282; include/gd_raster.h,
         # gd_raster_forward_batched_capacity): the binning buffer is sized from the previous iterations' counts with a margin
         self.capacity = None
         if sync_free and render_batch_fn is None and gaussians.get_xyz.is_cuda:
             from .diff_gaussian_rasterization._C import InstanceCapacity
-            self.capacity = InstanceCapacity(margin=capacity_margin)
+            self.capacity = InstanceCapacity(margin=capacity_margin, quantum=capacity_quantum)
         self.batch_invariant = bool(batch_invariant and gaussians.get_xyz.is_cuda)
+        # (k, rank) the kernel routing pretends to be; None = the process group's.  `route_as=(8, 0)` on ONE process measures
+        # what batch_invariant costs rank 0 of an 8-rank run (bench.py --simulate-world)
+        self._route_as = tuple(route_as) if route_as is not None else None
         if self.batch_invariant:
             # sharded run that must reproduce the single-rank gradients as closely as bf16 allows: the guidance
             # kernels are selected for the whole camera batch (views per rank x world size), not for this rank's
             # share (include/gd_nn.h gd_nn_conv_set_route_scale); costs a few % of step time on small shares.
-            # Process-global routing state: close() (or dropping the loop) puts it back to 1
-            from . import dist as gdist, nn_ops
-            nn_ops.set_route_scale(gdist.world_size(), gdist.rank())
+            # Process-global routing state with an OWNER: close() (or dropping the loop) puts it back to 1 only while this
+            # loop still owns it (a newer loop's setting survives an older loop's __del__), and step() re-asserts it
+            from . import nn_ops
+            nn_ops.set_route_scale(*self._route_kr(), owner=self)
         self.guidance = guidance
         self.prompt_utils = prompt_utils
         self.bg = bg_color
@@ -130,6 +134,7 @@ class SDSLoop:
             self.denom = torch.zeros((P, 1), device=dev)
             self.max_radii2D = torch.zeros((P,), device=dev)
         self.global_step = 0
+        self.render_overflow_retries = 0       # iterations whose sync-free render overflowed and was repeated (step())
         self.time_collectives = False          # bench.py --gpus N: time the gradient all-reduce (collective_times())
         self._collective_events = []
         self._bucket = None
@@ -144,12 +149,15 @@ class SDSLoop:
                                              lr_delay_mult=a.position_lr_delay_mult,
                                              max_steps=a.position_lr_max_steps)
 
+    def _route_kr(self):
+        return self._route_as if self._route_as is not None else (gdist.world_size(), gdist.rank())
+
     def close(self):
         """Undo the process-global kernel routing of ``batch_invariant=True`` (a later loop or guidance in the same process
         would otherwise inherit the k-fold routing)."""
         if getattr(self, "batch_invariant", False):
             from . import nn_ops
-            nn_ops.set_route_scale(1, 0)
+            nn_ops.release_route_scale(self)
             self.batch_invariant = False
 
     def __del__(self):
@@ -177,7 +185,14 @@ class SDSLoop:
         if gdist.collectives_on():
             # ONE asynchronous max over the ranks for [radii | depth maximum]; finished in step() after the guidance
             # forward, which it overlaps (dist.PendingMax)
-            out["_pending_max"] = gdist.PendingMax(pkg["radii"].max(dim=0).values, local_max)
+            flag = None
+            if self.capacity is not None:
+                # the sync-free forward pass leaves {R, R_binned, overflow, capacity} on the device: the overflow flag rides in
+                # the collective so that every rank takes the same decision in step() (a synchronising call leaves no flag)
+                flag = (self.capacity.buffers(dev)[2:3] if self.capacity.pending
+                        else torch.zeros(1, dtype=torch.int32, device=dev))
+            out["_pending_max"] = gdist.PendingMax(pkg["radii"].max(dim=0).values, local_max, flag)
+            out.flag_source = dict.__getitem__(out, "_pending_max")
             if finish:
                 out.finish()
         else:
@@ -204,17 +219,37 @@ class SDSLoop:
                     g["lr"] = self._xyz_lr(self.global_step)
         if self.global_step > 500:  # GaussianDreamer.py:233-234
             self.guidance.set_min_max_steps(min_step_percent=0.02, max_step_percent=0.55)
-        out = self.render_views(batch, finish=False)
-        if self._guidance_may_capture(out["comp_rgb"].shape[0]):
-            # a call of the guidance that may still CAPTURE a hipGraph: no collective of this process is left in flight across a
-            # capture (the process group's watchdog thread polls pending work with event queries); once the graphs exist the
-            # [radii | depth maximum] collective overlaps their replays
-            out.finish()
-        g_out = self.guidance(out["comp_rgb"], self.prompt_utils, batch["elevation"], batch["azimuth"],
-                              batch["camera_distances"], rgb_as_latents=False, guidance_eval=False, noise=noise,
-                              timesteps=timesteps, vae_noise=vae_noise)
-        loss_sds = g_out["loss_sds"]
         from . import nn_ops
+        if self.batch_invariant:
+            nn_ops.set_route_scale(*self._route_kr(), owner=self)   # process-global routing: re-asserted
+        for attempt in (0, 1):
+            out = self.render_views(batch, finish=False)
+            if self._guidance_may_capture(out["comp_rgb"].shape[0]):
+                # a call of the guidance that may still CAPTURE a hipGraph: no collective of this process is left in flight
+                # across a capture (the process group's watchdog thread polls pending work with event queries); once the
+                # graphs exist the [radii | depth maximum] collective overlaps their replays
+                out.finish()
+            g_out = self.guidance(out["comp_rgb"], self.prompt_utils, batch["elevation"], batch["azimuth"],
+                                  batch["camera_distances"], rgb_as_latents=False, guidance_eval=False, noise=noise,
+                                  timesteps=timesteps, vae_noise=vae_noise)
+            # sync-free forward pass: its instance count left for the host right behind the rasterizer's kernels and has
+            # landed by now (the guidance forward was queued behind it), so this look costs nothing -- and an overflowed
+            # render (nothing binned: every view is the background) must not reach backward / densification / Adam.  The
+            # capacity is dropped by overflowed(): the repeat takes the synchronising path (rasterizer_impl.cu:282) and
+            # cannot overflow.  With N ranks every rank must take the same decision (the collectives below pair up):
+            # the flag is OR-ed over the ranks.
+            over = self.capacity is not None and self.capacity.overflowed()
+            if self.capacity is not None and getattr(out, "flag_source", None) is not None:
+                over = out.flag_source.flag_any()
+                out.flag_source = None
+            if not over:
+                break
+            out.finish()
+            self.render_overflow_retries += 1
+            if attempt == 1:
+                raise RuntimeError("rasterizer: the synchronising forward pass reported an overflow")
+            self.capacity.value = None
+        loss_sds = g_out["loss_sds"]
         radii_all = out.get("radii_all")       # sharded run: max over every rank's views (finishes the pending collective)
         loss_sparsity = nn_ops.sparsity_loss(out["depth"], out["depth_max"])   # mean(sqrt(opacity^2 + 0.01)), :253
         loss = loss_sds * self.lambda_sds + loss_sparsity * self.lambda_sparsity

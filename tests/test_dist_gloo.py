@@ -151,6 +151,14 @@ def _gmax_worker(rank, world, port, ret):
     radii_all, m2 = pend.finish()
     ((x2 / (m2 + 1e-5)).sum() + 0.0 * side).backward()
     ret[f"p{rank}"] = (float(m2), x2.grad.clone(), radii_all.clone())
+    # the sync-free rasterizer's overflow flag as a third payload: raised on rank 1 only, seen by both (SDSLoop.step)
+    x3 = x.detach().clone().requires_grad_(True)
+    pend = gdist.PendingMax(radii, x3.max(), torch.tensor([rank], dtype=torch.int32))
+    any_flag = pend.flag_any()
+    radii_f, m3 = pend.finish()
+    pend0 = gdist.PendingMax(radii, x3.max().detach(), torch.zeros(1, dtype=torch.int32))
+    ret[f"f{rank}"] = (any_flag, float(m3), radii_f.clone(), pend0.flag_any(), gdist.PendingMax(radii, x3.max().detach()).flag_any())
+    pend0.finish()
     b = gdist.GradBucket([torch.zeros(3), torch.zeros(2, 2)])
     a1, a2 = torch.full((3,), float(rank + 1)), torch.full((2, 2), 10.0 * (rank + 1))
     b.all_reduce_mean_([a1, a2])
@@ -170,6 +178,9 @@ def test_global_max_routes_gradient_to_owner_and_bucket_averages():
     for r in (0, 1):
         m2, g2, radii_all = ret[f"p{r}"]
         assert m2 == 5.0 and torch.equal(g2, ret[r][1]) and radii_all.tolist() == [3, 9, 7, 1]
+    for r in (0, 1):
+        any_flag, m3, radii_f, none_raised, no_flag = ret[f"f{r}"]
+        assert any_flag is True and m3 == 5.0 and radii_f.tolist() == [3, 9, 7, 1] and not none_raised and not no_flag
     for r in (0, 1):
         a1, a2 = ret[f"b{r}"]
         assert torch.equal(a1, torch.full((3,), 1.5)) and torch.equal(a2, torch.full((2, 2), 15.0))

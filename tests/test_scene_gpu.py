@@ -233,6 +233,44 @@ def test_loop_without_the_forward_host_sync_moves_the_scene_exactly_like_the_syn
     assert loops[1].capacity.last_count > 0
 
 
+def test_sync_free_loop_survives_reference_range_cameras_an_overflow_never_reaches_the_optimizer():
+    """The reference draws camera_distance in [1.5, 4.0] and fovy in [40, 70] PER VIEW (configs/gaussiandreamer-sd.yaml:11-12):
+    the instance count moves several-fold from one iteration to the next, so a capacity seeded from one iteration overflows.
+    SDSLoop.step looks at the deferred overflow flag after the guidance forward and repeats the render on the synchronising
+    path; backward, densification statistics and Adam only ever see a complete render: after ten iterations on random
+    reference-range batches (a far batch first, so the seed is small) the parameters equal the synchronising loop's bit for
+    bit, and the overflow path was really taken."""
+    from garmentdreamer_amd import cameras as gcam
+    from garmentdreamer_amd.gaussian_model import GaussianModel
+    from garmentdreamer_amd.scene import synthetic_gaussians
+    from garmentdreamer_amd.sds_loop import SDSLoop
+
+    class ToyGuidance:
+        def __call__(self, rgb, *a, **k):
+            return {"loss_sds": ((rgb - 0.5) ** 2).sum() / rgb.shape[0], "grad_norm": torch.zeros((), device=rgb.device)}
+
+        def set_min_max_steps(self, **k):
+            pass
+
+    flats, loops = [], []
+    for sync_free in (False, True):
+        m = GaussianModel.from_activated(synthetic_gaussians(6000, seed=4), device=DEV)
+        loop = SDSLoop(m, ToyGuidance(), None, torch.ones(3, device=DEV), sync_free=sync_free, densify=False,
+                       capacity_margin=1.1, capacity_quantum=256)
+        g = torch.Generator().manual_seed(11)
+        far = dict(camera_distance_range=(3.9, 4.0), fovy_range_deg=(40.0, 41.0))
+        for step in range(10):
+            kw = far if step == 0 else {}
+            loop.step(gcam.random_batch(3, generator=g, height=96, width=96, **kw))
+        torch.cuda.synchronize()
+        flats.append(m._flat.clone())
+        loops.append(loop)
+    assert loops[1].render_overflow_retries >= 1 and loops[1].capacity.overflows == loops[1].render_overflow_retries
+    assert loops[1].capacity.calls_sync_free >= 3
+    assert torch.isfinite(flats[0]).all() and torch.equal(flats[0], flats[1])
+    loops[1].capacity.collect()          # nothing pending: the loop looked at every count itself
+
+
 def test_simple_knn_import_path_is_served_by_the_hip_kernel():
     from simple_knn._C import distCUDA2
     pts = torch.randn(500, 3, device=DEV)
