@@ -258,10 +258,12 @@ def test_sync_free_loop_survives_reference_range_cameras_an_overflow_never_reach
         loop = SDSLoop(m, ToyGuidance(), None, torch.ones(3, device=DEV), sync_free=sync_free, densify=False,
                        capacity_margin=1.1, capacity_quantum=256)
         g = torch.Generator().manual_seed(11)
+        # oracle counts of this scene at 256^2: 14.6k instances per far view, 19.3k per near view (1.32x > the 1.1 margin)
         far = dict(camera_distance_range=(3.9, 4.0), fovy_range_deg=(40.0, 41.0))
+        near = dict(camera_distance_range=(1.5, 1.55), fovy_range_deg=(69.0, 70.0))
         for step in range(10):
-            kw = far if step == 0 else {}
-            loop.step(gcam.random_batch(3, generator=g, height=96, width=96, **kw))
+            kw = far if step in (0, 5) else near if step in (1, 6) else {}
+            loop.step(gcam.random_batch(3, generator=g, height=256, width=256, **kw))
         torch.cuda.synchronize()
         flats.append(m._flat.clone())
         loops.append(loop)
