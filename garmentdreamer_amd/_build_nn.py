@@ -10,6 +10,7 @@ NN_SOURCES = [
     ("nn_fp8.hip", []),
     ("nn_linear.hip", []),
     ("nn_lora.hip", []),
+    ("nn_gemm.hip", []),
 ]
 
 

@@ -80,6 +80,10 @@ SIGNATURES = {
     "gd_nn_conv3x3_up2_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gd_nn_conv_force_variant": (_i, [_i]),
     "gd_nn_linear_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
+    "gd_nn_gemm_supported": (_i, [C.c_int64, _i, _i, _i]),
+    "gd_nn_gemm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
+    "gd_nn_gemm_geglu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
+    "gd_nn_gemm_last_error": (C.c_char_p, []),
     "gd_nn_conv_profile_enable": (_i, [_i]),
     "gd_nn_conv_profile_reset": (_i, []),
     "gd_nn_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -2001,6 +2005,56 @@ def linear_320_geglu(x, weight, bias=None):
                                                 M, inner)
     if ret < 0:
         raise RuntimeError(f"gd_nn_linear_k320_geglu_forward failed ({ret}): {L.gd_nn_linear_320_last_error().decode()}")
+    return y
+
+
+def _gemm_ok(x, weight, bias=None, residual=None) -> bool:
+    K = weight.shape[1]
+    ok = (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous()
+          and weight.is_contiguous() and weight.dim() == 2 and x.shape[-1] == K and x.data_ptr() % 16 == 0
+          and weight.data_ptr() % 16 == 0)
+    for t, al in ((bias, 16), (residual, 8)):
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or t.data_ptr() % al):
+            return False
+    return bool(ok)
+
+
+def gemm_supported(x, weight, bias=None, residual=None, geglu: bool = False) -> bool:
+    """bf16 contiguous GPU operands, K % 64 == 0, N % 8 == 0, tensors < 2 GiB (include/gd_nn.h gd_nn_gemm_supported)."""
+    if not _gemm_ok(x, weight, bias, residual):
+        return False
+    N = weight.shape[0] // 2 if geglu else weight.shape[0]
+    return bool(lib().gd_nn_gemm_supported(x.numel() // x.shape[-1], x.shape[-1], N, int(geglu)))
+
+
+def gemm(x, weight, bias=None, residual=None):
+    """``F.linear(x, weight, bias)``, or with ``residual`` ``torch.addmm(residual + bias, x, weight.T)`` (ONE rounding), on the own
+    GEMM (csrc/nn_gemm.hip: persistent 256 x 256 x 64 tiles, ten-slot LDS-DMA ring), inference only."""
+    K = weight.shape[1]
+    M = x.numel() // K
+    y = torch.empty(x.shape[:-1] + (weight.shape[0],), dtype=torch.bfloat16, device=x.device)
+    p = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    L = lib()
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_gemm_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), weight.data_ptr(), p(bias),
+                                   p(residual), y.data_ptr(), M, K, weight.shape[0])
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_gemm_forward failed ({ret}): {L.gd_nn_gemm_last_error().decode()}")
+    return y
+
+
+def gemm_geglu(x, weight, bias=None):
+    """diffusers ``GEGLU(K, inner)``: ``h, g = F.linear(x, weight, bias).chunk(2, -1); h * gelu(g)`` as ONE kernel -- the GEGLU in
+    the own GEMM's epilogue (the [M][2 inner] projection output is never written)."""
+    K = weight.shape[1]
+    M, inner = x.numel() // K, weight.shape[0] // 2
+    y = torch.empty(x.shape[:-1] + (inner,), dtype=torch.bfloat16, device=x.device)
+    L = lib()
+    with torch.cuda.device(x.device):
+        ret = L.gd_nn_gemm_geglu_forward(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), weight.data_ptr(),
+                                         None if bias is None else bias.data_ptr(), y.data_ptr(), M, K, inner)
+    if ret < 0:
+        raise RuntimeError(f"gd_nn_gemm_geglu_forward failed ({ret}): {L.gd_nn_gemm_last_error().decode()}")
     return y
 
 

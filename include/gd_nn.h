@@ -77,6 +77,23 @@ int gd_nn_conv_force_variant(int v);
  * K % 64 == 0, Nout % 4 == 0 (diffusers Attention / FeedForward / proj_in / proj_out linears). */
 int gd_nn_linear_forward(void* stream, const void* x, const void* weight, const void* bias, const void* residual, void* y,
                          int64_t M, int K, int Nout);
+/* The transformer linears as a GEMM designed as a GEMM (csrc/nn_gemm.hip; replaces hipBLASLt behind diffusers' Attention /
+ * FeedForward projections, call site stable_diffusion_guidance.py:153-157): persistent 256 x 256 x 64 tiles, 8 waves, both
+ * operands through a ten-slot LDS-DMA ring with counted waits, XCD-aware tile order.  bf16 in / out, fp32 accumulation.
+ *   gd_nn_gemm_forward        y[M][N] = bf16(residual[M][N] + bias[N] + x[M][K] . w[N][K]^T): bias and residual are the
+ *                             accumulators' starting value, ONE rounding (torch.addmm's, not the eager `linear` then `add`
+ *                             pair's two); bias / residual may be NULL
+ *   gd_nn_gemm_geglu_forward  diffusers GEGLU(K, inner): w [2 inner][K] (hidden rows, then gate rows), bias [2 inner] or NULL,
+ *                             y[M][inner] = (x w_h^T + b_h) * gelu(x w_g^T + b_g) with the rounding points of the projection
+ *                             followed by gd_nn_geglu_forward (bit-identical to that pair when the projection is this kernel's)
+ * The summation order of an output depends on K only (not on M / the tile / the grid): batch-invariant by construction.
+ * gd_nn_gemm_supported: K % 64 == 0, N % 8 == 0, every tensor < 2 GiB.  Pointers 16-byte aligned (y / residual 8). */
+int gd_nn_gemm_supported(int64_t M, int K, int N, int geglu);
+int gd_nn_gemm_forward(void* stream, const void* x, const void* weight, const void* bias, const void* residual, void* y,
+                       int64_t M, int K, int N);
+int gd_nn_gemm_geglu_forward(void* stream, const void* x, const void* weight, const void* bias, void* y, int64_t M, int K,
+                             int inner);
+const char* gd_nn_gemm_last_error(void);
 int gd_nn_conv_profile_enable(int on);
 int gd_nn_conv_profile_reset(void);
 int gd_nn_conv_profile_read(double* total_ms, int64_t* launches, double* total_flops);

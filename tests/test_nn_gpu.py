@@ -1729,3 +1729,63 @@ def test_linear_320_dispatch_refuses_misaligned_views():
     assert not nn_ops.linear_320_supported(x, w, b[:320].float())                   # fp32 bias
     wbuf = torch.randn(320 * 320 + 8, device=DEV).to(torch.bfloat16)
     assert not nn_ops.linear_320_supported(x, wbuf[1:1 + 320 * 320].view(320, 320))  # weight 2 bytes off a 16-byte boundary
+
+
+# ---- the own GEMM (csrc/nn_gemm.hip): persistent 256 x 256 x 64 tiles, ten-slot LDS-DMA ring, fused epilogues -------------------
+@pytest.mark.parametrize("M,K,N", [(256, 64, 256), (4096, 1280, 1280), (1000, 640, 648), (16384, 640, 5120), (77, 1024, 320),
+                                   (513, 320, 264), (65536, 1280, 320), (300, 5120, 1280)])
+def test_own_gemm_matches_fp32_with_bias_and_residual(M, K, N):
+    """y = x W^T + b (+ residual) against fp32 PyTorch: full tiles, ragged rows and channels (zero fill by the buffer range check,
+    masked stores), one K tile and eighty, a single workgroup and several passes of the persistent grid; rtol of bf16 outputs."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N)
+    x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV, generator=g).to(torch.bfloat16)
+    r = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    assert nn_ops.gemm_supported(x, w, b, r)
+    ref = F.linear(x.float(), w.float(), b.float())
+    scale = ref.abs().max().item()
+    for bias in (None, b):
+        y = nn_ops.gemm(x, w, bias)
+        want = ref if bias is not None else ref - b.float()
+        assert (y.float() - want).abs().max().item() <= 8e-3 * scale, (M, K, N, bias is not None)
+    # residual: the accumulators start as residual + bias -- ONE rounding, like torch.addmm (not the eager pair's two)
+    y = nn_ops.gemm(x, w, b, r)
+    assert (y.float() - (ref + r.float())).abs().max().item() <= 8e-3 * (ref + r.float()).abs().max().item()
+    assert torch.equal(nn_ops.gemm(x, w, None, torch.zeros_like(r)), nn_ops.gemm(x, w))
+    # batch invariance by construction: a row's bits do not depend on which other rows are in the call
+    if M >= 512:
+        part = nn_ops.gemm(x[M // 2 - 100:M // 2 + 157].contiguous(), w, b)
+        assert torch.equal(part, nn_ops.gemm(x, w, b)[M // 2 - 100:M // 2 + 157])
+
+
+@pytest.mark.parametrize("M,K,inner", [(256, 64, 128), (4096, 1280, 5120), (16384, 640, 2560), (1000, 320, 1288), (130, 1280, 5120)])
+def test_own_gemm_geglu_epilogue_is_the_projection_followed_by_the_geglu_kernel(M, K, inner):
+    """diffusers GEGLU(K, inner) as ONE kernel: bit-identical to the own GEMM followed by gd_nn_geglu_forward (same rounding
+    points), and within bf16 tolerance of the fp32 composition."""
+    from garmentdreamer_amd import nn_ops
+    g = torch.Generator(device=DEV).manual_seed(M + inner)
+    x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(2 * inner, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(2 * inner, device=DEV, generator=g).to(torch.bfloat16)
+    assert nn_ops.gemm_supported(x, w, b, geglu=True)
+    for bias in (b, None):
+        y = nn_ops.gemm_geglu(x, w, bias)
+        two = nn_ops.geglu(nn_ops.gemm(x, w, bias))
+        assert torch.equal(y, two)
+        h, gate = F.linear(x.float(), w.float(), None if bias is None else bias.float()).chunk(2, -1)
+        ref = h * F.gelu(gate)
+        assert (y.float() - ref).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
+
+
+def test_own_gemm_repeated_calls_are_bitwise_reproducible_and_refuses_what_it_cannot_do():
+    from garmentdreamer_amd import nn_ops
+    x = torch.randn(5000, 640, device=DEV).to(torch.bfloat16)
+    w = torch.randn(1280, 640, device=DEV).to(torch.bfloat16)
+    a = nn_ops.gemm(x, w)
+    for _ in range(3):
+        assert torch.equal(a, nn_ops.gemm(x, w))
+    assert not nn_ops.gemm_supported(x[:, :100].contiguous(), w[:, :100].contiguous())      # K % 64
+    with pytest.raises(RuntimeError, match="gd_nn_gemm_forward"):
+        nn_ops.gemm(x[:, :96].contiguous(), w[:, :96].contiguous())
