@@ -71,6 +71,7 @@ SIGNATURES = {
     "gd_raster_blend_exp": (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i]),
     "gd_raster_profile_enable": (_i, [_i]),
     "gd_raster_profile_collect": (_i, []),
+    "gd_raster_force_binning": (_i, [_i]),
     "gd_raster_poison_lds": (_i, [_vp]),
     "gd_raster_profile_get": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "gd_raster_profile_reset": (_i, []),

@@ -15,6 +15,8 @@
 #include <mutex>
 #include <vector>
 
+#include <atomic>
+
 #include "raster_common.h"
 
 namespace gd {
@@ -121,6 +123,8 @@ ImageState carve_image(char* chunk, size_t tiles_total, size_t pixels_total, siz
     obtain(p, im.pair_counts, pixels_total);
     obtain(p, im.strip_count, tiles_total * 4);
     obtain(p, im.tile_perm, tiles_total);
+    obtain(p, im.tile_cursor, tiles_total);
+    obtain(p, im.bin_stats, 4);
     if (used) *used = (size_t)(p - chunk);
     return im;
 }
@@ -173,6 +177,9 @@ ViewScalars make_views(int V, const float* tanx, const float* tany, int W, int H
     return vs;
 }
 
+// 1: tile-bucketed binning wherever the longest list allows it (default); 0: radix sort always (gd_raster_force_binning)
+std::atomic<int> g_binning_mode{[] { const char* e = getenv("GD_RASTER_BUCKETS"); return (!e || atoi(e) != 0) ? 1 : 0; }()};
+
 int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_user, gd_alloc_fn binning_alloc,
                  void* binning_user, gd_alloc_fn image_alloc, void* image_user, int P, int D, int M,
                  const float* background, int W, int H, const float* means3D, const float* shs,
@@ -180,7 +187,7 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                  const float* projmatrix, const float* cam_pos, const float* tanx, const float* tany,
                  int prefiltered, float* out_color, float* out_depth, float* out_alpha, int* radii, int debug,
-                 uint32_t capacity = 0, uint32_t* count_dev = nullptr)
+                 uint32_t capacity = 0, uint32_t* count_dev = nullptr, bool force_radix = false)
 {
     // capacity > 0: the sync-free form (gd_raster_forward_batched_capacity) -- the instance count never leaves the device
     g_err[0] = 0;
@@ -227,20 +234,49 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     { ProfScope ps(stream, GD_K_SCAN); launch_scan_block_sums(stream, geom.block_sums, nblk, sync_free ? count_dev : nullptr, capacity); }
     if (int e = check_debug(stream, debug, "scan")) return e;
 
+    // Binning, round 6: TILE-BUCKETED by default -- count the instances of every tile, prefix-sum (= `ranges`), scatter every
+    // instance into its tile's bucket, one LDS sort per tile (raster_binning.hip) -- instead of the global radix sort of all
+    // (tile | depth) keys (rasterizer_impl.cu:304-309): ~5 launches and two passes over the keys instead of ~17 and eleven.
+    // Lists longer than kBucketMax do not fit the per-tile sort: the synchronising form sees the longest list in the same
+    // read-back as num_rendered and takes the radix path; the sync-free form flags the call (count_dev[2] = 2, nothing binned)
+    // and the caller repeats it with force_radix.  GD_RASTER_BUCKETS=0 / gd_raster_force_binning(0): radix path always (A/B, tests).
+    bool buckets = g_binning_mode.load(std::memory_order_relaxed) != 0 && !force_radix;
+    if (buckets) {
+        ProfScope ps(stream, GD_K_RANGES);
+        launch_tile_count(stream, (int)VP, P, radii, geom, img.ranges, dm.tiles_total, dm.tiles_x, dm.tiles_y);
+        launch_tile_scan(stream, img.ranges, dm.tiles_total, img.tile_cursor, img.bin_stats, sync_free ? count_dev : nullptr);
+    }
+    if (int e = check_debug(stream, debug, "tile counts")) return e;
+
     uint32_t num_rendered = capacity;       // sync-free: every buffer, grid and layout below is sized for the capacity
     const uint32_t* n_dev = sync_free ? count_dev + 1 : nullptr;     // ... and the kernels read the live count here
     if (!sync_free) {
         // the one host sync of the forward pass (rasterizer_impl.cu:282)
+        uint32_t longest = 0;
         GD_HIP(hipMemcpyAsync(&num_rendered, geom.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (buckets) GD_HIP(hipMemcpyAsync(&longest, img.bin_stats + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         GD_HIP(hipStreamSynchronize(stream));
         // the compact per-strip lists index 4 * num_rendered cells with 32-bit arithmetic (raster_render.hip: my_base, rowpos)
         if (num_rendered >= (1u << 30)) return fail(GD_ERR_INVALID_ARG, "%s", "num_rendered exceeds 2^30 (32-bit strip-list offsets)");
+        if (longest > kBucketMax) buckets = false;
     }
 
     char* bin_chunk = binning_alloc(binning_user, gd_raster_binning_bytes(num_rendered));
     if (!bin_chunk) return fail(GD_ERR_ALLOC, "%s", "binning allocator returned NULL");
     BinningState bin = carve_binning(bin_chunk, num_rendered, nullptr);
 
+    if (buckets) {
+        { ProfScope ps(stream, GD_K_DUPLICATE);
+        launch_tile_scatter(stream, (int)VP, P, radii, geom, bin.keys_alt, bin.slot_vp, img.tile_cursor, dm.tiles_x, dm.tiles_y,
+                            sync_free ? count_dev : nullptr); }
+        GD_HIP(hipMemsetAsync(bin.rowpos, 0, sizeof(uint4) * (size_t)num_rendered, stream));
+        if (int e = check_debug(stream, debug, "scatter")) return e;
+        { ProfScope ps(stream, GD_K_SORT);
+        if (num_rendered > 0)
+            launch_tile_sort(stream, img.ranges, dm.tiles_total, bin.keys_alt, bin.keys, bin.point_list, bin.point_list_alt,
+                             bin.slot_vp); }
+        if (int e = check_debug(stream, debug, "tile sort")) return e;
+    } else {
     const SortPlan plan = plan_sort(dm.tiles_total);
     const bool start_in_alt = (plan.passes & 1) != 0;
     { ProfScope ps(stream, GD_K_DUPLICATE);
@@ -254,6 +290,7 @@ int forward_impl(hipStream_t stream, int V, gd_alloc_fn geom_alloc, void* geom_u
     { ProfScope ps(stream, GD_K_RANGES); launch_tile_ranges(stream, bin.keys, num_rendered, img.ranges, dm.tiles_total, bin.point_list,
                                                           bin.slot_vp, bin.point_list_alt, n_dev); }
     if (int e = check_debug(stream, debug, "ranges")) return e;
+    }
     // longest tile lists first (a counting sort of the tiles by list length, one small launch): the blend kernels' workgroups
     // last as long as their lists (0 ... 1700 entries on the benchmark scene, 45 % of the tiles empty), and in index order the
     // heavy tiles of the last view started last -- render_forward 0.364 -> 0.335 ms per 8-view launch (profiles/r05_lpt_ab.txt)
@@ -416,11 +453,14 @@ int gd_raster_forward_batched_capacity(void* stream, int V, gd_alloc_fn geom_all
                                        float* out_alpha, int* radii, int debug, int64_t capacity, uint32_t* count_dev)
 {
     if (!tan_fovx || !tan_fovy) return fail(GD_ERR_INVALID_ARG, "%s", "tan_fovx / tan_fovy host arrays are required");
-    if (capacity <= 0 || capacity >= (1ll << 30)) return fail(GD_ERR_INVALID_ARG, "%s", "capacity must be in [1, 2^30)");
+    const bool force_radix = capacity < 0;        // -capacity: the same call on the radix-sort binning (see the header)
+    if (force_radix) capacity = -capacity;
+    if (capacity <= 0 || capacity >= (1ll << 30)) return fail(GD_ERR_INVALID_ARG, "%s", "|capacity| must be in [1, 2^30)");
     return forward_impl((hipStream_t)stream, V, geom_alloc, geom_user, binning_alloc, binning_user, image_alloc,
                         image_user, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
                         scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
-                        tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug, (uint32_t)capacity, count_dev);
+                        tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug, (uint32_t)capacity, count_dev,
+                        force_radix);
 }
 
 int gd_raster_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,
@@ -508,6 +548,17 @@ int gd_raster_blend_exp(void* stream, const float* x, float* y, int n)
     if (!x || !y || n < 0) return GD_ERR_INVALID_ARG;
     launch_blend_exp((hipStream_t)stream, x, y, n);
     return hipGetLastError() == hipSuccess ? GD_OK : GD_ERR_HIP;
+}
+
+int gd_raster_force_binning(int mode)
+{
+    if (mode < -1 || mode > 1) return GD_ERR_INVALID_ARG;
+    if (mode < 0) {
+        const char* e = getenv("GD_RASTER_BUCKETS");
+        mode = (!e || atoi(e) != 0) ? 1 : 0;
+    }
+    g_binning_mode.store(mode, std::memory_order_relaxed);
+    return GD_OK;
 }
 
 int gd_raster_poison_lds(void* stream)

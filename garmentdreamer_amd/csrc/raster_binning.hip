@@ -92,12 +92,18 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
     }
 }
 
+// BUCKET = true (tile-bucketed binning): the instance goes straight into its tile's bucket -- position = atomic cursor of
+// the tile (tile_scan_kernel left it at the bucket's start), key = depth bits << 32 | slot: the per-tile sort orders by depth
+// and, for equal depths, by slot = by Gaussian index, which is the order the reference's stable sort leaves
+// (duplicateWithKeys emits the Gaussians in index order, rasterizer_impl.cu:70-111).
+template <bool BUCKET>
 __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, const int* __restrict__ radii,
                                                                 GeomState gs, uint64_t* __restrict__ keys_out,
                                                                 uint32_t* __restrict__ vals_out,
                                                                 uint32_t* __restrict__ slot_vp,
                                                                 uint4* __restrict__ rowpos, uint32_t gx, uint32_t gy,
-                                                                const uint32_t* __restrict__ info)
+                                                                const uint32_t* __restrict__ info,
+                                                                uint32_t* __restrict__ cursor)
 {
     __shared__ uint32_t wave_incl[kGaussBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,14 +136,19 @@ __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, c
         const uint32_t view_tile0 = (uint32_t)(vp / P) * gx * gy;
         for (uint32_t y = y0; y < y1; y++)
             for (uint32_t x = x0; x < x1; x++) {
-                uint64_t key = (uint64_t)(view_tile0 + y * gx + x);
-                key <<= 32;
-                key |= depth_bits;
-                keys_out[off] = key;
-                // the sort carries the instance's SLOT (its index here), not the Gaussian: the backward blend stores its
-                // per-instance rows BY SLOT, so that a Gaussian's rows are contiguous and can be added without atomics;
-                // the Gaussian of a slot is kept in slot_vp (tile_ranges_kernel turns point_list into Gaussian ids)
-                vals_out[off] = off;
+                if (BUCKET) {
+                    const uint32_t pos = atomicAdd(&cursor[view_tile0 + y * gx + x], 1u);
+                    keys_out[pos] = ((uint64_t)depth_bits << 32) | off;
+                } else {
+                    uint64_t key = (uint64_t)(view_tile0 + y * gx + x);
+                    key <<= 32;
+                    key |= depth_bits;
+                    keys_out[off] = key;
+                    // the sort carries the instance's SLOT (its index here), not the Gaussian: the backward blend stores its
+                    // per-instance rows BY SLOT, so that a Gaussian's rows are contiguous and can be added without atomics;
+                    // the Gaussian of a slot is kept in slot_vp (tile_ranges_kernel turns point_list into Gaussian ids)
+                    vals_out[off] = off;
+                }
                 if (slot_vp) slot_vp[off] = (uint32_t)vp;
                 if (rowpos) rowpos[off] = make_uint4(0, 0, 0, 0);   // "no strip blended this instance" until render_forward says otherwise
                 off++;
@@ -364,6 +375,149 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
     }
 }
 
+// ---------------- tile-bucketed binning (round 6) ----------------
+// The reference sorts all R (tile | depth) keys globally (cub radix sort, rasterizer_impl.cu:304-309); rounds 1-5 did the same
+// with an own 5-pass LSD radix sort: ~17 launches, 0.35 ms per 8-view launch, the largest rasterizer item.  But the tile half
+// of the key is known before any sorting: count the instances of every tile, prefix-sum the counts (= the reference's
+// `ranges`, identifyTileRanges :116-138, for free), scatter each instance into its tile's bucket, and sort every bucket on its
+// own in LDS.  The result is the unique order (tile, depth, Gaussian index) -- bit-identical `keys`, `point_list`, `ranges`.
+
+// counts[tile] (kept in ranges[tile].x, zeroed by the launcher) += 1 per instance
+__global__ __launch_bounds__(kGaussBlock) void tile_count_kernel(int VP, int P, const int* __restrict__ radii, GeomState gs,
+                                                                 uint2* __restrict__ ranges, uint32_t gx, uint32_t gy)
+{
+    const int vp = blockIdx.x * kGaussBlock + threadIdx.x;
+    if (vp >= VP) return;
+    const int r = radii[vp];
+    if (r <= 0) return;
+    const float2 xy = gs.means2D[vp];
+    uint32_t x0, y0, x1, y1;
+    tile_rect(xy.x, xy.y, r, gx, gy, x0, y0, x1, y1);
+    const uint32_t view_tile0 = (uint32_t)(vp / P) * gx * gy;
+    for (uint32_t y = y0; y < y1; y++)
+        for (uint32_t x = x0; x < x1; x++) atomicAdd(&ranges[view_tile0 + y * gx + x].x, 1u);
+}
+
+// One workgroup: exclusive scan of the tile counts -> ranges[t] = [start, end) ((0, 0) for an empty tile, as the reference's
+// zero-initialised array keeps it), cursor[t] = start, stats = {total, longest list}.  Sync-free form (info != NULL): a
+// capacity overflow (info[2] == 1, scan_block_sums_kernel) or a list beyond kBucketMax (-> info[2] = 2, nothing is binned:
+// every view shows the background, the caller repeats the call on the radix path) leaves every range empty.
+__global__ __launch_bounds__(1024) void tile_scan_kernel(uint2* __restrict__ ranges, uint32_t n, uint32_t* __restrict__ cursor,
+                                                         uint32_t* __restrict__ stats, uint32_t* __restrict__ info)
+{
+    __shared__ uint32_t wave_incl[16], wave_max[16];
+    __shared__ uint32_t carry_s, void_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // longest list first (decides whether anything is binned at all)
+    uint32_t mx = 0;
+    for (uint32_t i = tid; i < n; i += 1024) mx = max(mx, ranges[i].x);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    if (lane == 0) wave_max[wave] = mx;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t m = 0;
+        for (int w = 0; w < 16; w++) m = max(m, wave_max[w]);
+        uint32_t vd = 0;
+        if (info) {
+            if (info[2]) vd = 1;
+            else if (m > kBucketMax) { info[2] = 2u; info[1] = 0u; vd = 1; }
+        }
+        stats[1] = m;
+        void_s = vd;
+    }
+    __syncthreads();
+    const bool nothing = void_s != 0;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = (i < n && !nothing) ? ranges[i].x : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        if (lane == 63) wave_incl[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < wave; w++) wave_off += wave_incl[w];
+        const uint32_t carry = carry_s;
+        if (i < n) {
+            const uint32_t start = carry + wave_off + incl - v;
+            ranges[i] = v ? make_uint2(start, start + v) : make_uint2(0u, 0u);
+            cursor[i] = start;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) stats[0] = carry_s;
+}
+
+// One workgroup per tile: the bucket's keys (depth bits << 32 | slot; unique, so any correct sort gives the one order) through
+// a bitonic network in LDS; the epilogue writes what the radix path's sort + tile_ranges_kernel leave: keys[pos] = tile << 32 |
+// depth bits, slot_of[pos] = slot, point_list[pos] = the slot's Gaussian.  Padding keys are all ones (a real key's depth has
+// its sign bit clear).  Steps whose partner distance is below 8 run on the 8 consecutive elements a thread owns, in registers:
+// no barrier, no LDS traffic.
+__global__ __launch_bounds__(256) void tile_sort_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ bkeys,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list,
+                                                        uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ slot_vp)
+{
+    __shared__ uint64_t sk[kBucketMax];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    const uint2 rg = ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0) return;
+    uint32_t np2 = 8;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = tid; i < np2; i += 256) sk[i] = i < n ? bkeys[rg.x + i] : ~0ull;
+    __syncthreads();
+    const uint32_t chunks = np2 >> 3;                   // 8-element chunks, chunk c owned by thread c % 256
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        uint32_t j = k >> 1;
+        for (; j >= 8; j >>= 1) {
+            for (uint32_t i = tid; i < (np2 >> 1); i += 256) {
+                const uint32_t lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                const uint64_t a = sk[lo], b = sk[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) { sk[lo] = b; sk[hi] = a; }
+            }
+            __syncthreads();
+        }
+        // j = 4, 2, 1 (or fewer for k < 16): inside the thread's own chunks
+        for (uint32_t c = tid; c < chunks; c += 256) {
+            uint64_t v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = sk[c * 8 + e];
+            const bool up_c = ((c * 8) & k) == 0;      // k >= 8: one direction for the whole chunk
+#pragma unroll
+            for (uint32_t jj = 4; jj > 0; jj >>= 1) {
+                if (jj <= j) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        if ((e & jj) == 0) {
+                            const bool up = k >= 8 ? up_c : (((c * 8 + e) & k) == 0);
+                            const uint64_t a = v[e], b = v[e | jj];
+                            if ((a > b) == up) { v[e] = b; v[e | jj] = a; }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) sk[c * 8 + e] = v[e];
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint64_t key = sk[i];
+        const uint32_t slot = (uint32_t)key;
+        keys[rg.x + i] = ((uint64_t)tile << 32) | (key >> 32);
+        slot_of[rg.x + i] = slot;
+        point_list[rg.x + i] = slot_vp[slot];
+    }
+}
+
 template <int BITS>
 void sort_pass(hipStream_t s, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, uint32_t n,
                int shift, int width, uint32_t* hist, uint32_t nblk, const uint32_t* n_dev)
@@ -384,6 +538,35 @@ void launch_tile_order(hipStream_t s, const uint2* ranges, uint32_t tiles_total,
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, tiles_total, perm);
 }
 
+void launch_tile_count(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint2* ranges, uint32_t tiles_total,
+                       int tiles_x, int tiles_y)
+{
+    (void)hipMemsetAsync(ranges, 0, (size_t)tiles_total * sizeof(uint2), s);
+    const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, ranges, (uint32_t)tiles_x,
+                       (uint32_t)tiles_y);
+}
+
+void launch_tile_scan(hipStream_t s, uint2* ranges, uint32_t tiles_total, uint32_t* cursor, uint32_t* stats, uint32_t* info)
+{
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, ranges, tiles_total, cursor, stats, info);
+}
+
+void launch_tile_scatter(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* bucket_keys, uint32_t* slot_vp,
+                         uint32_t* cursor, int tiles_x, int tiles_y, const uint32_t* info)
+{
+    const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
+    hipLaunchKernelGGL(duplicate_kernel<true>, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, bucket_keys,
+                       (uint32_t*)nullptr, slot_vp, (uint4*)nullptr, (uint32_t)tiles_x, (uint32_t)tiles_y, info, cursor);
+}
+
+void launch_tile_sort(hipStream_t s, const uint2* ranges, uint32_t tiles_total, const uint64_t* bucket_keys, uint64_t* keys,
+                      uint32_t* point_list, uint32_t* slot_of, const uint32_t* slot_vp)
+{
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles_total), dim3(256), 0, s, ranges, bucket_keys, keys, point_list, slot_of,
+                       slot_vp);
+}
+
 void launch_scan_block_sums(hipStream_t s, uint32_t* block_sums, uint32_t nblocks, uint32_t* info, uint32_t capacity)
 {
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nblocks, info, capacity);
@@ -393,8 +576,8 @@ void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState 
                       uint32_t* vals_out, uint32_t* slot_vp, uint4* rowpos, int tiles_x, int tiles_y, const uint32_t* info)
 {
     const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
-    hipLaunchKernelGGL(duplicate_kernel, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, keys_out, vals_out,
-                       slot_vp, rowpos, (uint32_t)tiles_x, (uint32_t)tiles_y, info);
+    hipLaunchKernelGGL(duplicate_kernel<false>, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, keys_out, vals_out,
+                       slot_vp, rowpos, (uint32_t)tiles_x, (uint32_t)tiles_y, info, (uint32_t*)nullptr);
 }
 
 // Sorts (keys, vals) of length R on the low plan.total_bits bits.  The unsorted input sits in

@@ -42,6 +42,8 @@ struct ImageState {
     uint2* pair_counts;   // [V*H*W] {visited, blended} per pixel (work accounting for the roofline)
     uint32_t* strip_count;  // [V*tiles*4] entries of each 16x4 strip's compact list (see BinningState::clist)
     uint32_t* tile_perm;    // [V*tiles] tiles by descending list length (launch order of the blend kernels; tile_order_kernel)
+    uint32_t* tile_cursor;  // [V*tiles] tile-bucketed binning: next free position of each tile's bucket (tile_scatter)
+    uint32_t* bin_stats;    // [4] tile-bucketed binning: {instances counted, longest tile list, 0, 0} (tile_scan_kernel)
 };
 struct BinningState {
     uint32_t* point_list;      // [R] sort payload = instance SLOT (see slot_vp); after tile_ranges: the Gaussian (vp) ids
@@ -112,6 +114,16 @@ void launch_tile_ranges(hipStream_t s, const uint64_t* keys, uint32_t R, uint2* 
                         uint32_t* point_list, const uint32_t* slot_vp, uint32_t* slot_of, const uint32_t* n_dev = nullptr);
 
 void launch_tile_order(hipStream_t s, const uint2* ranges, uint32_t tiles_total, uint32_t* perm);
+
+// ---- tile-bucketed binning (round 6): counting scatter by tile, then ONE LDS sort per tile ----
+constexpr uint32_t kBucketMax = 4096;   // longest tile list the per-tile LDS sort takes (32 KiB of keys); beyond: radix path
+void launch_tile_count(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint2* ranges /* .x counts */, uint32_t tiles_total,
+                       int tiles_x, int tiles_y);
+void launch_tile_scan(hipStream_t s, uint2* ranges, uint32_t tiles_total, uint32_t* cursor, uint32_t* stats, uint32_t* info);
+void launch_tile_scatter(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* bucket_keys, uint32_t* slot_vp,
+                         uint32_t* cursor, int tiles_x, int tiles_y, const uint32_t* info);
+void launch_tile_sort(hipStream_t s, const uint2* ranges, uint32_t tiles_total, const uint64_t* bucket_keys, uint64_t* keys,
+                      uint32_t* point_list, uint32_t* slot_of, const uint32_t* slot_vp);
 void launch_blend_exp(hipStream_t s, const float* x, float* y, int n);   // y = gd_expf(x): parity test hook
 void launch_poison_lds(hipStream_t s);                                   // NaN patterns into every CU's LDS: test hook
 void launch_render_forward(hipStream_t s, int V, int W, int H, int tiles_x, int tiles_y, const uint2* ranges,

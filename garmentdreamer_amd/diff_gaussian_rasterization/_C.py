@@ -194,6 +194,7 @@ class InstanceCapacity:
         self.last_count = None       # num_rendered of the most recent call whose count has been read
         self.calls_sync_free = 0
         self.overflows = 0           # sync-free calls that overflowed and were noticed through overflowed() / collect()
+        self.radix = False           # a tile list outgrew the tile-bucketed binning: sync-free calls use the radix sort
         self.last_capacity = None
         self._dev = self._host = self._event = None
         self._pending = False
@@ -207,6 +208,7 @@ class InstanceCapacity:
         self.collect()
         self.value = None
         self._recent = []
+        self.radix = False
 
     def _round(self, n: int) -> int:
         self._recent = (self._recent + [int(n)])[-self.window:]
@@ -243,6 +245,10 @@ class InstanceCapacity:
         total, _live, over, cap = (int(v) & 0xffffffff for v in self._host.tolist())
         self.last_count, self.last_capacity = total, cap
         if over:
+            # 1: more instances than the capacity; 2: a tile list longer than the tile-bucketed binning sorts in LDS (4096) --
+            # from now on (until reset()) the sync-free calls ask for the radix-sort binning (a negative capacity, gd_raster.h)
+            if over == 2:
+                self.radix = True
             self.value = None
             self._recent = []
             self.overflows += 1
@@ -295,7 +301,8 @@ def rasterize_gaussians_batched(background, means3D, colors, opacity, scales, ro
                 _ptr(pm), _ptr(cp), tx, ty, int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(),
                 out_alpha.data_ptr(), radii.data_ptr() if P else None, int(bool(debug)))
         if capacity is not None and capacity.value is not None and P > 0:
-            rendered = L.gd_raster_forward_batched_capacity(*head, int(capacity.value), capacity.buffers(dev).data_ptr())
+            rendered = L.gd_raster_forward_batched_capacity(*head, -int(capacity.value) if capacity.radix else int(capacity.value),
+                                                            capacity.buffers(dev).data_ptr())
             _native.check(rendered, "gd_raster_forward_batched_capacity")
             capacity.observe(dev)
         else:

@@ -38,7 +38,7 @@ from ..nn_ops import (add_layer_norm, attention_d64, attention_d64_supported, at
                       conv3x3_supported, geglu, gn_conv3x3, gn_conv3x3_supported, gn_conv_prefers_fused, group_norm_silu,
                       resnet_block_frozen, resnet_block_frozen_supported, upsample2x_conv3x3,
                       upsample2x_conv3x3_supported, linear_320, route_rows, route_scale,
-                      linear_320_geglu, linear_320_supported)
+                      linear_320_geglu, linear_320_supported, gemm_geglu, gemm_supported)
 
 
 import os as _os
@@ -82,6 +82,8 @@ def _conv3(conv: nn.Conv2d, x, image_bias=None, residual=None):
 
 import os as _os0
 _LIN320 = _os0.environ.get("GD_LINEAR320", "1") != "0"      # =0: library GEMM (same-box A/B in tools/, never set in tests)
+_OWN_GEMM = _os0.environ.get("GD_OWN_GEMM", "1") != "0"     # =0: GEGLU projections with K != 320 on the library GEMM + geglu_kernel
+_OWN_GEMM_MIN_ROWS = 1024                                    # below: the 256-row tiles cannot fill the chip (library + geglu_kernel)
 
 
 def _lib_linear(x, w, b=None):
@@ -335,6 +337,13 @@ class GEGLU(nn.Module):
         if _LIN320 and x.is_cuda and not torch.is_grad_enabled() and not w.requires_grad and tuple(w.shape) == (2560, 320) and \
                 linear_320_supported(x, w, self.proj.bias):
             return linear_320_geglu(x, w, self.proj.bias)      # projection + GEGLU in one kernel (64x64-token blocks)
+        if _OWN_GEMM and x.is_cuda and not torch.is_grad_enabled() and not w.requires_grad and w.shape[1] != 320 and \
+                (x.numel() // x.shape[-1]) * route_scale() >= _OWN_GEMM_MIN_ROWS and gemm_supported(x, w, self.proj.bias, geglu=True):
+            # K = 640 / 1280 (the 32^2 / 16^2 / 8^2-token blocks): the own GEMM with the GEGLU as its epilogue -- 1.10-1.22x the
+            # library GEMM + geglu_kernel pair (profiles/r06_gemm_shapes.txt), the [M][2 inner] projection output never
+            # exists, and a row's bits do not depend on M, so batch-invariant selection needs no padded row set here (the
+            # row threshold looks at the single-rank batch: every rank takes the same branch)
+            return gemm_geglu(x, w, self.proj.bias)
         return geglu(_lin(self.proj, x))   # h * gelu(gate), fused on the GPU (nn_ops.geglu)
 
 

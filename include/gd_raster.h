@@ -111,8 +111,10 @@ int gd_raster_forward_batched(void* stream, int V, gd_alloc_fn geom_alloc, void*
  * CAPACITY instead: the binning buffer is allocated for `capacity` instances (gd_raster_binning_bytes(capacity)), every grid
  * is sized for it, and the kernels read the live count from count_dev[1]:
  *   count_dev[0] = num_rendered of this call, [1] = the count the kernels worked on (= [0], or 0 after an overflow),
- *   count_dev[2] = 1 if num_rendered > capacity (NOTHING was binned: every view shows the background; the caller reads the
- *   flag whenever it likes -- a deferred, asynchronous copy -- and must treat the call's results as void), [3] = capacity.
+ *   count_dev[2] = 1 if num_rendered > capacity, 2 if a tile's list is longer than the tile-bucketed binning takes (4096
+ *   instances; round 6) -- either way NOTHING was binned: every view shows the background; the caller reads the flag whenever
+ *   it likes -- a deferred, asynchronous copy -- and must treat the call's results as void; after a 2 it repeats the call with
+ *   a NEGATIVE capacity: |capacity| instances on the radix-sort binning, which has no such limit --, [3] = capacity.
  * Returns `capacity` (>= 0) -- the value to pass as R to gd_raster_backward_batched, gd_raster_backward_scratch_bytes and
  * gd_raster_get_layout, which then use the same layout -- or a negative error.  Results for the live instances are bit-identical
  * to gd_raster_forward_batched.  No reference counterpart (the reference synchronises). */
@@ -160,6 +162,12 @@ int gd_raster_sort_bits(int width, int height, int V);
 /* y[i] = the alpha blend's exp as the kernels evaluate it (device pointers): parity hook -- must equal
  * oracle/gd_oracle.c gd_expf bit for bit. */
 int gd_raster_blend_exp(void* stream, const float* x, float* y, int n);
+
+/* Test / tuning hook: which binning the forward pass uses.  1 (default; environment GD_RASTER_BUCKETS=0 starts at 0): tile-
+ * bucketed -- count per tile, prefix sum (= ranges), scatter into the tile's bucket, one LDS sort per tile; falls back to the
+ * radix path when a list exceeds 4096 instances.  0: the global radix sort of (tile | depth) keys (what the reference does with
+ * cub, rasterizer_impl.cu:304-309) always.  -1: back to the default.  Both leave bit-identical keys / point_list / ranges. */
+int gd_raster_force_binning(int mode);
 
 /* Test hook: fills the LDS of every CU with NaN bit patterns (LDS is not cleared between workgroups), so that a kernel
  * reading a shared-memory cell it never wrote shows up in the parity tests rather than as a rare non-finite step. */

@@ -120,6 +120,53 @@ def test_forward_big_splats_many_tiles():
     _check_forward(inp, st, out)
 
 
+@pytest.fixture
+def radix_binning():
+    """The forward pass on the global radix sort (round 1-5's binning; gd_raster_force_binning(0)), default restored after."""
+    from garmentdreamer_amd import _native
+    assert _native.lib().gd_raster_force_binning(0) == 0
+    yield
+    assert _native.lib().gd_raster_force_binning(-1) == 0
+
+
+@pytest.mark.parametrize("P,HW,deg", [(500, 64, 0), (10000, 256, 0)])
+def test_forward_parity_on_the_radix_binning(P, HW, deg, radix_binning):
+    """Both binnings leave the oracle's keys / point_list / ranges / images bit for bit: the default is the tile-bucketed one
+    (every other test of this file), this is the global radix sort it falls back to for lists beyond 4096 instances."""
+    inp = h.raster_inputs(P=P, H=HW, W=HW, sh_degree=deg, seed=P)
+    st = h.oracle_forward(inp)
+    _, out = _run_gpu_forward(inp)
+    _check_forward(inp, st, out)
+
+
+def test_tile_lists_beyond_the_bucket_sort_fall_back_to_the_radix_path():
+    """6000 huge splats on a 64 x 64 image: the longest tile list holds 5986 instances (> 4096, what the per-tile LDS sort
+    takes).  The synchronising entry reads the longest list with num_rendered and takes the radix path: oracle bits.  The
+    sync-free entry flags the call (count_dev[2] = 2, nothing binned); InstanceCapacity then asks for the radix binning (negative
+    capacity) and the sync-free calls after that reproduce the synchronising bits."""
+    from garmentdreamer_amd.diff_gaussian_rasterization import _C
+    from garmentdreamer_amd.diff_gaussian_rasterization._C import InstanceCapacity
+    inp = h.raster_inputs(P=6000, H=64, W=64, seed=9, scale_mul=30.0)
+    st = h.oracle_forward(inp)
+    assert int((st.ranges[:, 1] - st.ranges[:, 0]).max()) > 4096
+    args, out = _run_gpu_forward(inp)
+    _check_forward(inp, st, out)
+    (bg, means3D, colors, opac, scales, rots, smod, cov, vm, pm, tx, ty, H, W, sh, degree, campos, pre, dbg) = args
+    batched = lambda cap: _C.rasterize_gaussians_batched(bg, means3D, colors, opac, scales, rots, smod, cov, vm[None], pm[None],
+                                                         [tx], [ty], H, W, sh, degree, campos[None], pre, dbg, capacity=cap)
+    cap = InstanceCapacity(margin=1.2, quantum=1 << 10)
+    cap.value = 2 * st.num_rendered                      # a capacity that fits: the call runs sync-free on the buckets ...
+    void = batched(cap)
+    assert cap.overflowed() and cap.radix and cap.value is None          # ... and reports the list it could not sort
+    assert float(void[3].abs().max()) == 0.0                                # nothing was binned: alpha is zero everywhere
+    first = batched(cap)                                 # synchronising call (radix: it sees the longest list), seeds the capacity
+    assert cap.value is not None and torch.equal(first[1][0], out[1])
+    again = batched(cap)                                 # sync-free, radix binning by request
+    assert cap.calls_sync_free == 2 and not cap.overflowed()
+    for a, b in zip(again[1:5], first[1:5]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("P,HW,deg", [(500, 64, 0), (2000, 96, 2), (10000, 256, 0)])
 def test_backward_parity(P, HW, deg):
     from garmentdreamer_amd.diff_gaussian_rasterization import _C

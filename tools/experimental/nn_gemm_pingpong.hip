@@ -1,12 +1,15 @@
+// MEASURED, NOT ROUTED (round 6): csrc/nn_gemm.hip with its K loop as a ping-pong of the two waves of each SIMD (memory segment /
+// compute segment, four workgroup barriers per K tile, waves 4..7 one barrier late).  Correct (the 14 parity cases), and within
+// +-3 % of the single-phase loop on every shape of the step (profiles/r06_gemm_shapes.txt): with all of a wave's DMA issue in its
+// memory segment that segment is ~870 cycles against 512 for the 16 MFMAs of the compute segment, so the loop becomes
+// memory-segment bound instead of sum-bound -- the same time.  Build: tools/gemm_variants.sh "pp:-DGD_GEMM_PIPE=1" (from this file).
 // nn_gemm.hip -- y[M][N] = x[M][K] . W[N][K]^T (+ bias) (+ residual | GEGLU) in bf16 with fp32 accumulation: a GEMM
 // designed as a GEMM for gfx950 (the transformer linears of the SD-2.1 UNet that diffusers hands to cuBLAS and PyTorch-ROCm
 // to hipBLASLt; call site Garment_3DGS/threestudio/models/guidance/stable_diffusion_guidance.py:153-157 -> diffusers
 // BasicTransformerBlock: attn to_q/to_k/to_v/to_out, FeedForward GEGLU projection and output projection).
 //
 // Rounds 1-5 ran these products on the library because the one-tap form of the convolution kernel (two LDS stages,
-// vmcnt(0) + __syncthreads() per 64-deep K step) reaches 70-90 % of it.  This kernel is a different structure (measured
-// per shape against hipBLASLt in profiles/r06_gemm_shapes.txt: 0.75-1.02x plain, 1.10-1.22x with the GEGLU fused against
-// library GEMM + geglu_kernel -- the form the UNet's 32^2 / 16^2 / 8^2-token blocks now run, guidance/sd21.py GEGLU):
+// vmcnt(0) + __syncthreads() per 64-deep K step) reaches 70-90 % of it.  This kernel is a different structure:
 //
 //   * PERSISTENT workgroups (one per CU, 8 wave64) walk 256 x 256 output tiles; the K loop of a tile is a sequence of
 //     64-deep K tiles and the sequence simply continues into the next output tile, so the first operands of tile i + 1
@@ -23,12 +26,10 @@
 //     XOR swizzle applied on the SOURCE side of the DMA (conflict-free fragment reads).
 //   * XCD-aware order: the 32 tiles a pass gives one XCD are consecutive in (row tile, channel tile) order, so a row tile
 //     of x is fetched from HBM once per XCD and the weights stay in that XCD's L2.
-//   * bias and residual are the accumulators' STARTING value (y = bf16(residual + bias + x W^T): one rounding, torch.addmm's),
-//     the bias through scalar loads -- the epilogue is stores only, so nothing waits between the operands in flight for the
-//     next tile and the K tile that needs them; and diffusers' GEGLU as an epilogue the library cannot fuse (hidden *
-//     gelu(gate), nn_math.h: the arithmetic and rounding points of the separate geglu_kernel) with hidden / gate rows
-//     interleaved per wave so that both halves of a pair sit in the same lane -- the [M][2 inner] projection output is
-//     neither written nor read.
+//   * epilogues the library cannot fuse: bias, bias + residual (second rounding exactly where the eager bf16 op sequence
+//     `linear` then `add` has it), and diffusers' GEGLU (hidden * gelu(gate), nn_math.h: the arithmetic and rounding
+//     points of the separate geglu_kernel) with hidden / gate rows interleaved per wave so that both halves of a pair
+//     sit in the same lane -- the [M][2 inner] projection output is neither written nor read.
 //   * the summation order of an output element depends on K only -- never on M, on the tile a row falls in or on how
 //     many workgroups run -- so a rank holding 1/k of the rows reproduces the single-rank bits without the k-fold padded
 //     row set the library needs for that (nn_ops.route_rows).
@@ -37,13 +38,18 @@
 #include <stdio.h>
 
 #include "../../include/gd_nn.h"
-#include "nn_math.h"
+#include "../../garmentdreamer_amd/csrc/nn_math.h"
 
 // Timing-only switches of tools/gemm_variants.sh (never defined in a product build; results are wrong with any of them):
 //   GD_GEMM_ABLATE=1  no LDS-DMA inside the K loop      2  no fragment reads (stale registers)      3  no MFMAs
 //   4  no per-K-tile wait + barrier      5  barrier but no vmcnt wait (is the loop waiting for operands to land?)
 #ifndef GD_GEMM_ABLATE
 #define GD_GEMM_ABLATE 0
+#endif
+//   GD_GEMM_PIPE=0    the round's first K loop (one phase per 16-deep step, every wave issues DMA, reads and MFMAs in turn);
+//                     correct results: the A/B of the ping-pong loop
+#ifndef GD_GEMM_PIPE
+#define GD_GEMM_PIPE 1
 #endif
 //   GD_GEMM_ORDER=1   consecutive tiles share the CHANNEL tile and walk the row tiles (default 0: share the row tile)
 #ifndef GD_GEMM_ORDER
@@ -284,6 +290,7 @@ __global__ __launch_bounds__(kThreads) void gemm256_kernel(const uint16_t* __res
     for (int bb = 0; bb < 2; bb++) abl_x[bb] = *(const bf16x8_t*)(smem + x_rd[bb]);
 #endif
     int c_par = 0, c_third = 0;      // ring positions of the K tile being multiplied
+#if GD_GEMM_PIPE == 0
     int first_after_epilogue = 0;
     for (int pass = 0; tile_of(pass) < ntiles; pass++) {
         const int tile = tile_of(pass);
@@ -382,6 +389,146 @@ __global__ __launch_bounds__(kThreads) void gemm256_kernel(const uint16_t* __res
         init_acc(pass + 1);
         first_after_epilogue = 1;
     }
+#else
+    // ---- the K loop as a PING-PONG of the two waves of each SIMD (waves w and w + 4 share SIMD w % 4) -----------------------
+    // A K tile is two half steps (kk = 0, 1 | kk = 2, 3), each a MEMORY segment (this wave's 4 DMA instructions of the half
+    // tiles due now, the 12 fragment reads of the half step, wait for them) and a COMPUTE segment (16 MFMAs on those
+    // registers), with a workgroup barrier after every segment.  Waves 4..7 start ONE barrier late: between any two barriers
+    // one wave of a SIMD issues nothing but MFMAs while the other issues nothing but memory operations -- the in-order
+    // instruction stream of a wave no longer serialises its own DMA issue (~100 cycles a piece), LDS latency and matrix work
+    // (measured on the single-phase loop: removing ANY one of DMA / fragment reads / MFMAs bought 15-25 %, i.e. each wave
+    // paid their SUM).  Ring safety with the groups one segment apart: K tile f is read in the four intervals 4f .. 4f + 3
+    // (first group 4f, 4f + 2; second group 4f + 1, 4f + 3), so its slots are free from interval 4f + 4 on -- W(f + 1)
+    // (slots of W(f - 1)) is issued in 4f / 4f + 1, x(f + 2) (slots of x(f - 1)) in 4f + 2 / 4f + 3 -- and K tile f + 1 has
+    // landed for everybody before interval 4f + 4 because every wave's `vmcnt(4)` ("all but the x pieces just issued")
+    // stands in front of its barrier at the end of its second memory segment, which is at or before that interval's start.
+    const int late = wave >> 2;                         // second group
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K tile 0 (prologue) has landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (late) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    auto seg_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int pass = 0; tile_of(pass) < ntiles; pass++) {
+        const int tile = tile_of(pass);
+        for (int t = 0; t < T; t++) {
+            const char* sw = smem + (c_par * 2 + wc) * kSlot;
+            const char* sx = smem + (4 + c_third * 2 + (wp >> 1)) * kSlot;
+#pragma unroll
+            for (int hs = 0; hs < 2; hs++) {
+                // ---- memory segment ----
+#if GD_GEMM_ABLATE != 1
+                if (hs == 0) {
+                    issue_w(0);
+                    issue_w(1);
+                    advance_w();
+                } else {
+                    issue_x(0, x_third);
+                    issue_x(1, x_third);
+                    advance_x();
+                    x_third = x_third == 2 ? 0 : x_third + 1;
+                }
+#endif
+                bf16x8_t wf[2][4], xf[2][2];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const uint32_t kx = (uint32_t)((2 * hs + k2) << 5);
+#if GD_GEMM_ABLATE == 2
+#pragma unroll
+                    for (int a = 0; a < 4; a++) wf[k2][a] = abl_w[a];
+#pragma unroll
+                    for (int bb = 0; bb < 2; bb++) xf[k2][bb] = abl_x[bb];
+#else
+#pragma unroll
+                    for (int a = 0; a < 4; a++) wf[k2][a] = *(const bf16x8_t*)(sw + (w_rd[a] ^ kx));
+#pragma unroll
+                    for (int bb = 0; bb < 2; bb++) xf[k2][bb] = *(const bf16x8_t*)(sx + (x_rd[bb] ^ kx));
+#endif
+                }
+#if GD_GEMM_ABLATE != 4
+                if (hs == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                seg_barrier();
+#endif
+                // ---- compute segment ----
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int bb = 0; bb < 2; bb++)
+#if GD_GEMM_ABLATE == 3
+                            acc[a][bb][0] += __builtin_bit_cast(float, (int)wf[k2][a][0] ^ (int)xf[k2][bb][1]);
+#else
+                            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k2][a], xf[k2][bb], acc[a][bb], 0, 0, 0);
+#endif
+                if (hs == 0) {
+#if GD_GEMM_ABLATE != 4
+                    seg_barrier();
+#endif
+                }
+            }
+            c_par ^= 1;
+            c_third = c_third == 2 ? 0 : c_third + 1;
+            if (t + 1 < T) {
+#if GD_GEMM_ABLATE != 4
+                seg_barrier();
+#endif
+            }
+        }
+        // ---- epilogue: D[i = channel][j = row]; lane: row column lane & 31, channels (reg & 3) + 8 (reg >> 2) + 4 fk ----
+        // Stores only (bias and residual went into the accumulators before the first MFMA, init_acc): no load, hence no wait,
+        // sits between the operands in flight for the next tile and the first K tile that needs them.  Exactly 32 (GEGLU: 16)
+        // store instructions per lane, out-of-range lanes masked by the buffer range check -- the vmcnt immediate counts them.
+        {
+            typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+            const int m0 = tile_tm(tile) * 256 + (wp >> 1) * kHalf + (wp & 1) * 64;
+            const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)y, 0, (int)(uint32_t)((size_t)M * (size_t)ldy * 2u), 0x00020000);
+            uint32_t row_off[2];
+#pragma unroll
+            for (int bb = 0; bb < 2; bb++) {
+                const int m = m0 + bb * 32 + frow;
+                row_off[bb] = m < M ? (uint32_t)m * (uint32_t)ldy * 2u : kOOB;
+            }
+            const int n0 = tile_tn(tile) * kChTile + wc * (kChTile / 2);     // this wave's first output channel
+#pragma unroll
+            for (int a = 0; a < (MODE == kModeGeglu ? 2 : 4); a++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int ch = n0 + a * 32 + 8 * q + 4 * fk;
+                    const uint32_t ch_off = ch < N ? (uint32_t)ch * 2u : kOOB;
+#pragma unroll
+                    for (int bb = 0; bb < 2; bb++) {
+                        const f32x16& ah = acc[a][bb];
+                        u32x2 o = {pack_bf16(ah[4 * q], ah[4 * q + 1]), pack_bf16(ah[4 * q + 2], ah[4 * q + 3])};
+                        if (MODE == kModeGeglu) {
+                            // hidden and gate rounded to bf16 (the unfused projection's rounding point), then the GEGLU
+                            const f32x16& ag = acc[a + 2][bb];
+                            o.x = gdnn::geglu2(o.x, pack_bf16(ag[4 * q], ag[4 * q + 1]));
+                            o.y = gdnn::geglu2(o.y, pack_bf16(ag[4 * q + 2], ag[4 * q + 3]));
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(o, rs_y, (int)addr2(row_off[bb], ch_off), 0, 0);
+                    }
+                }
+        }
+        init_acc(pass + 1);
+#if GD_GEMM_ABLATE != 4
+        seg_barrier();          // the barrier behind the tile's last compute segment (epilogue and next tile's bias in front of it)
+#endif
+    }
+    if (!late) {                // the first group is one barrier ahead: pair the second group's last one
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+#endif
     // the ring's tail: DMA instructions issued for tiles past the end were out of range (no LDS write pending that matters),
     // but the wave must not end with DMA outstanding into LDS another workgroup may be given
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

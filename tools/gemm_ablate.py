@@ -44,11 +44,15 @@ for M, K, N in shapes:
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     fl = 2.0 * M * K * N
     row = []
+    best = {n: 1e30 for n in names}
+    t_lib = 1e30
+    for rep in range(3):             # interleaved, best of three (the first entry of a row otherwise pays the clock ramp)
+        for n in names:
+            L = libs[n]
+            t = graph_time(lambda: L.gd_nn_gemm_forward(torch.cuda.current_stream().cuda_stream, x.data_ptr(), w.data_ptr(), None,
+                                                        None, y.data_ptr(), M, K, N))
+            best[n] = min(best[n], t)
+        t_lib = min(t_lib, graph_time(lambda: torch.nn.functional.linear(x, w)))
     for n in names:
-        L = libs[n]
-        st = torch.cuda.current_stream().cuda_stream
-        t = graph_time(lambda: L.gd_nn_gemm_forward(torch.cuda.current_stream().cuda_stream, x.data_ptr(), w.data_ptr(), None, None,
-                                                    y.data_ptr(), M, K, N))
-        row.append(f"{n} {t:7.1f} ({fl / t / 1e6:5.0f})")
-    t_lib = graph_time(lambda: torch.nn.functional.linear(x, w))
+        row.append(f"{n} {best[n]:7.1f} ({fl / best[n] / 1e6:5.0f})")
     print(f"M{M:6d} K{K:5d} N{N:6d}: " + " | ".join(row) + f" | hipBLASLt {t_lib:7.1f} ({fl / t_lib / 1e6:5.0f})", flush=True)
