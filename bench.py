@@ -810,6 +810,10 @@ def main():
                        "fp8_unet_sites": (guidance.unet.fp8.sites_run if guidance is not None and
                                           getattr(guidance.unet, "fp8", None) is not None else 0),
                        "kernels_per_step": kernels_per_step,
+                       "raster_binning": ("tile-bucketed (count / scan / scatter / per-tile LDS counting sort; radix fallback beyond 4096 "
+                                          "instances per tile)" if os.environ.get("GD_RASTER_BUCKETS", "1") != "0"
+                                          else "global radix sort (GD_RASTER_BUCKETS=0)"),
+                       "own_gemm_geglu": os.environ.get("GD_OWN_GEMM", "1") != "0",
                        "batch_invariant": bool(loop.batch_invariant),
                        "batch_invariant_route_scale": (loop._route_kr()[0] if loop.batch_invariant else 1),
                        "raster_forward_host_syncs_in_timed_region": (

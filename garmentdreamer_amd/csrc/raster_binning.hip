@@ -92,18 +92,12 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
     }
 }
 
-// BUCKET = true (tile-bucketed binning): the instance goes straight into its tile's bucket -- position = atomic cursor of
-// the tile (tile_scan_kernel left it at the bucket's start), key = depth bits << 32 | slot: the per-tile sort orders by depth
-// and, for equal depths, by slot = by Gaussian index, which is the order the reference's stable sort leaves
-// (duplicateWithKeys emits the Gaussians in index order, rasterizer_impl.cu:70-111).
-template <bool BUCKET>
 __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, const int* __restrict__ radii,
                                                                 GeomState gs, uint64_t* __restrict__ keys_out,
                                                                 uint32_t* __restrict__ vals_out,
                                                                 uint32_t* __restrict__ slot_vp,
                                                                 uint4* __restrict__ rowpos, uint32_t gx, uint32_t gy,
-                                                                const uint32_t* __restrict__ info,
-                                                                uint32_t* __restrict__ cursor)
+                                                                const uint32_t* __restrict__ info)
 {
     __shared__ uint32_t wave_incl[kGaussBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -136,19 +130,14 @@ __global__ __launch_bounds__(kGaussBlock) void duplicate_kernel(int VP, int P, c
         const uint32_t view_tile0 = (uint32_t)(vp / P) * gx * gy;
         for (uint32_t y = y0; y < y1; y++)
             for (uint32_t x = x0; x < x1; x++) {
-                if (BUCKET) {
-                    const uint32_t pos = atomicAdd(&cursor[view_tile0 + y * gx + x], 1u);
-                    keys_out[pos] = ((uint64_t)depth_bits << 32) | off;
-                } else {
-                    uint64_t key = (uint64_t)(view_tile0 + y * gx + x);
-                    key <<= 32;
-                    key |= depth_bits;
-                    keys_out[off] = key;
-                    // the sort carries the instance's SLOT (its index here), not the Gaussian: the backward blend stores its
-                    // per-instance rows BY SLOT, so that a Gaussian's rows are contiguous and can be added without atomics;
-                    // the Gaussian of a slot is kept in slot_vp (tile_ranges_kernel turns point_list into Gaussian ids)
-                    vals_out[off] = off;
-                }
+                uint64_t key = (uint64_t)(view_tile0 + y * gx + x);
+                key <<= 32;
+                key |= depth_bits;
+                keys_out[off] = key;
+                // the sort carries the instance's SLOT (its index here), not the Gaussian: the backward blend stores its
+                // per-instance rows BY SLOT, so that a Gaussian's rows are contiguous and can be added without atomics;
+                // the Gaussian of a slot is kept in slot_vp (tile_ranges_kernel turns point_list into Gaussian ids)
+                vals_out[off] = off;
                 if (slot_vp) slot_vp[off] = (uint32_t)vp;
                 if (rowpos) rowpos[off] = make_uint4(0, 0, 0, 0);   // "no strip blended this instance" until render_forward says otherwise
                 off++;
@@ -382,20 +371,119 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
 // `ranges`, identifyTileRanges :116-138, for free), scatter each instance into its tile's bucket, and sort every bucket on its
 // own in LDS.  The result is the unique order (tile, depth, Gaussian index) -- bit-identical `keys`, `point_list`, `ranges`.
 
-// counts[tile] (kept in ranges[tile].x, zeroed by the launcher) += 1 per instance
-__global__ __launch_bounds__(kGaussBlock) void tile_count_kernel(int VP, int P, const int* __restrict__ radii, GeomState gs,
+// counts[tile] (kept in ranges[tile].x, zeroed by the launcher) += 1 per instance.  Device-scope atomics are performed at
+// the memory side on this multi-die part (every XCD has its own L2) and sixteen counters share a cache line: one global
+// atomic per instance measured 0.30 ms per 8-view launch (3.5 M atomics).  So a workgroup of 1024 consecutive (view, Gaussian)
+// pairs -- at most two views -- first counts into an LDS window of its two views' tiles, then adds the non-zero cells: ~7x
+// fewer global atomics.  Images with more tiles per view than the window holds take the direct form.
+constexpr uint32_t kAggThreads = 1024;
+constexpr uint32_t kAggWindow = 8192;        // LDS counters: 2 views x up to 4096 tiles (1024 x 1024 pixels)
+
+__device__ __forceinline__ bool agg_rect(int vp, int VP, int P, const int* __restrict__ radii, const GeomState& gs, uint32_t gx,
+                                         uint32_t gy, uint32_t& x0, uint32_t& y0, uint32_t& x1, uint32_t& y1, uint32_t& view)
+{
+    if (vp >= VP) return false;
+    const int r = radii[vp];
+    if (r <= 0) return false;
+    const float2 xy = gs.means2D[vp];
+    tile_rect(xy.x, xy.y, r, gx, gy, x0, y0, x1, y1);
+    view = (uint32_t)(vp / P);
+    return true;
+}
+
+template <bool LDS_WINDOW>
+__global__ __launch_bounds__(kAggThreads) void tile_count_kernel(int VP, int P, const int* __restrict__ radii, GeomState gs,
                                                                  uint2* __restrict__ ranges, uint32_t gx, uint32_t gy)
 {
-    const int vp = blockIdx.x * kGaussBlock + threadIdx.x;
-    if (vp >= VP) return;
-    const int r = radii[vp];
-    if (r <= 0) return;
-    const float2 xy = gs.means2D[vp];
-    uint32_t x0, y0, x1, y1;
-    tile_rect(xy.x, xy.y, r, gx, gy, x0, y0, x1, y1);
-    const uint32_t view_tile0 = (uint32_t)(vp / P) * gx * gy;
+    __shared__ uint32_t h[LDS_WINDOW ? kAggWindow : 1];
+    const uint32_t tpv = gx * gy;
+    const int vp = blockIdx.x * kAggThreads + threadIdx.x;
+    const uint32_t view0 = (uint32_t)((blockIdx.x * kAggThreads) / (uint32_t)P);
+    if (LDS_WINDOW) {
+        for (uint32_t i = threadIdx.x; i < 2 * tpv; i += kAggThreads) h[i] = 0;
+        __syncthreads();
+    }
+    uint32_t x0, y0, x1, y1, view;
+    if (agg_rect(vp, VP, P, radii, gs, gx, gy, x0, y0, x1, y1, view)) {
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) {
+                if (LDS_WINDOW) atomicAdd(&h[(view - view0) * tpv + y * gx + x], 1u);
+                else atomicAdd(&ranges[view * tpv + y * gx + x].x, 1u);
+            }
+    }
+    if (LDS_WINDOW) {
+        __syncthreads();
+        const uint32_t tiles_total_hi = (uint32_t)((VP + P - 1) / P) * tpv;
+        for (uint32_t i = threadIdx.x; i < 2 * tpv; i += kAggThreads) {
+            const uint32_t c = h[i], t = view0 * tpv + i;
+            if (c && t < tiles_total_hi) atomicAdd(&ranges[t].x, c);
+        }
+    }
+}
+
+// The scatter of the tile-bucketed binning with the same aggregation: count into the LDS window, reserve a contiguous piece of
+// every touched tile's bucket with ONE global atomic per (workgroup, tile), then hand out the piece's positions with LDS atomics.
+// Also does duplicate_kernel's bookkeeping: point_offsets (the inclusive scan, from the 256-Gaussian block sums), slot_vp.
+template <bool LDS_WINDOW>
+__global__ __launch_bounds__(kAggThreads) void tile_scatter_kernel(int VP, int P, const int* __restrict__ radii, GeomState gs,
+                                                                   uint64_t* __restrict__ bkeys, uint32_t* __restrict__ slot_vp,
+                                                                   uint32_t* __restrict__ cursor, uint32_t gx, uint32_t gy,
+                                                                   const uint32_t* __restrict__ info)
+{
+    __shared__ uint32_t h[LDS_WINDOW ? kAggWindow : 1];
+    __shared__ uint32_t wave_incl[kAggThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tpv = gx * gy;
+    const int vp = blockIdx.x * kAggThreads + tid;
+    const uint32_t view0 = (uint32_t)((blockIdx.x * kAggThreads) / (uint32_t)P);
+    const uint32_t touched = vp < VP ? gs.tiles_touched[vp] : 0;
+    uint32_t incl = touched;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += t;
+    }
+    if (lane == 63) wave_incl[wave] = incl;
+    if (LDS_WINDOW)
+        for (uint32_t i = tid; i < 2 * tpv; i += kAggThreads) h[i] = 0;
+    __syncthreads();
+    // block_sums are per kGaussBlock = 256 Gaussians = 4 waves: this workgroup covers four of those blocks
+    uint32_t wave_off = 0;
+    for (uint32_t w = wave & ~3u; w < wave; w++) wave_off += wave_incl[w];
+    const uint32_t blk = (uint32_t)vp / kGaussBlock;
+    const uint32_t incl_global = vp < VP ? gs.block_sums[blk] + wave_off + incl : 0;
+    const bool voided = info && info[2];       // sync-free form: capacity or bucket overflow -- nothing is binned
+    if (vp < VP) {
+        gs.point_offsets[vp] = incl_global;    // inclusive, as the reference stores it
+        if (voided) gs.tiles_touched[vp] = 0;  // ... and the backward pass (instance_sum_kernel) gathers nothing either
+    }
+    uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0, view = 0;
+    const bool live = !voided && agg_rect(vp, VP, P, radii, gs, gx, gy, x0, y0, x1, y1, view);
+    if (LDS_WINDOW) {
+        if (live)
+            for (uint32_t y = y0; y < y1; y++)
+                for (uint32_t x = x0; x < x1; x++) atomicAdd(&h[(view - view0) * tpv + y * gx + x], 1u);
+        __syncthreads();
+        const uint32_t tiles_total_hi = (uint32_t)((VP + P - 1) / P) * tpv;
+        for (uint32_t i = tid; i < 2 * tpv; i += kAggThreads) {
+            const uint32_t c = h[i], t = view0 * tpv + i;
+            if (c && t < tiles_total_hi) h[i] = atomicAdd(&cursor[t], c);      // this workgroup's piece of the bucket starts here
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+    uint32_t off = incl_global - touched;
+    const uint32_t depth_bits = __float_as_uint(gs.rgbd[vp].w);
     for (uint32_t y = y0; y < y1; y++)
-        for (uint32_t x = x0; x < x1; x++) atomicAdd(&ranges[view_tile0 + y * gx + x].x, 1u);
+        for (uint32_t x = x0; x < x1; x++) {
+            const uint32_t pos = LDS_WINDOW ? atomicAdd(&h[(view - view0) * tpv + y * gx + x], 1u)
+                                            : atomicAdd(&cursor[view * tpv + y * gx + x], 1u);
+            // key = depth bits << 32 | slot: the per-tile sort orders by depth and, for equal depths, by slot = by Gaussian
+            // index, which is the order the reference's stable sort leaves (duplicateWithKeys emits in index order)
+            bkeys[pos] = ((uint64_t)depth_bits << 32) | off;
+            slot_vp[off] = (uint32_t)vp;
+            off++;
+        }
 }
 
 // One workgroup: exclusive scan of the tile counts -> ranges[t] = [start, end) ((0, 0) for an empty tile, as the reference's
@@ -455,66 +543,118 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(uint2* __restrict__ ran
     if (tid == 0) stats[0] = carry_s;
 }
 
-// One workgroup per tile: the bucket's keys (depth bits << 32 | slot; unique, so any correct sort gives the one order) through
-// a bitonic network in LDS; the epilogue writes what the radix path's sort + tile_ranges_kernel leave: keys[pos] = tile << 32 |
-// depth bits, slot_of[pos] = slot, point_list[pos] = the slot's Gaussian.  Padding keys are all ones (a real key's depth has
-// its sign bit clear).  Steps whose partner distance is below 8 run on the 8 consecutive elements a thread owns, in registers:
-// no barrier, no LDS traffic.
+// One workgroup per tile sorts the bucket's keys (depth bits << 32 | slot; unique, so the order is unique) and writes what the
+// radix path's sort + tile_ranges_kernel leave: keys[pos] = tile << 32 | depth bits, slot_of[pos] = slot, point_list[pos] = the
+// slot's Gaussian.
+//
+// Not a comparison network: the first two forms of this kernel were bitonic networks in LDS (one level per barrier: 0.21 ms per
+// 8-view launch; three levels per LDS round trip with compile-time strides: 0.195 ms) and both were VALU-bound -- O(n log^2 n)
+// compare-exchanges are ~90 M wave instructions per launch on the benchmark scene, as many as the backward blend issues.
+// This form is a COUNTING sort on a monotone quantisation of the depth, made exact by ranking inside the quantisation cells:
+//   1. min / max of the tile's depth bits (positive floats order like their bit patterns);
+//   2. cell q = floor((d - min) * B / (max - min + 1)) in [0, B), B = the list length rounded up to a power of two (>= 256), so a
+//      cell holds one key on average; the map is monotone (integer -> float conversion, multiplication by a positive constant
+//      and truncation all are), hence keys of different cells are already in their final relative order;
+//   3. count per cell (LDS atomics, low half of a 32-bit word), exclusive scan (high half = the cell's start), scatter into the
+//      cell (LDS atomic on the low half again: position = start + old count) -- the order INSIDE a cell is whatever the atomics give;
+//   4. every key ranks itself among the m keys of its cell by full 64-bit comparison (m is 1-2 typically; two thin depth
+//      clusters at the ends of the range -- a garment's front and back -- give m of a few dozen; all depths equal gives m = n:
+//      n^2 / 256 comparisons per thread, ~15 us for that one tile at n = 1700: slow, never wrong, never serial) and writes its
+//      outputs at start + rank.
+// ~60 instructions per key instead of ~1300; 48 KiB of LDS (keys 32 KiB, cells 16 KiB): three workgroups per CU.
 __global__ __launch_bounds__(256) void tile_sort_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ bkeys,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list,
                                                         uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ slot_vp)
 {
-    __shared__ uint64_t sk[kBucketMax];
-    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint64_t sk[kBucketMax];        // the keys, grouped by cell
+    __shared__ uint32_t cell[kBucketMax];      // per cell: count (low 16 bits) | start (high 16 bits)
+    __shared__ uint32_t red[8];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
-    uint32_t np2 = 8;
-    while (np2 < n) np2 <<= 1;
-    for (uint32_t i = tid; i < np2; i += 256) sk[i] = i < n ? bkeys[rg.x + i] : ~0ull;
-    __syncthreads();
-    const uint32_t chunks = np2 >> 3;                   // 8-element chunks, chunk c owned by thread c % 256
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        uint32_t j = k >> 1;
-        for (; j >= 8; j >>= 1) {
-            for (uint32_t i = tid; i < (np2 >> 1); i += 256) {
-                const uint32_t lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
-                const uint64_t a = sk[lo], b = sk[hi];
-                const bool up = (lo & k) == 0;
-                if ((a > b) == up) { sk[lo] = b; sk[hi] = a; }
-            }
-            __syncthreads();
-        }
-        // j = 4, 2, 1 (or fewer for k < 16): inside the thread's own chunks
-        for (uint32_t c = tid; c < chunks; c += 256) {
-            uint64_t v[8];
+    uint32_t B = 256;
+    while (B < n) B <<= 1;
+    // the thread's keys (i = tid + 256 e) stay in registers: ONE trip to global memory instead of one per pass
+    constexpr int kPer = kBucketMax / 256;
+    uint64_t mine[kPer];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = sk[c * 8 + e];
-            const bool up_c = ((c * 8) & k) == 0;      // k >= 8: one direction for the whole chunk
-#pragma unroll
-            for (uint32_t jj = 4; jj > 0; jj >>= 1) {
-                if (jj <= j) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        if ((e & jj) == 0) {
-                            const bool up = k >= 8 ? up_c : (((c * 8 + e) & k) == 0);
-                            const uint64_t a = v[e], b = v[e | jj];
-                            if ((a > b) == up) { v[e] = b; v[e | jj] = a; }
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; e++) sk[c * 8 + e] = v[e];
-        }
-        __syncthreads();
+    for (int e = 0; e < kPer; e++) {
+        const uint32_t i = tid + 256u * e;
+        mine[e] = i < n ? bkeys[rg.x + i] : ~0ull;
     }
-    for (uint32_t i = tid; i < n; i += 256) {
-        const uint64_t key = sk[i];
+    // 1. depth range
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+        if (tid + 256u * e < n) {
+            const uint32_t d = (uint32_t)(mine[e] >> 32);
+            dmin = min(dmin, d);
+            dmax = max(dmax, d);
+        }
+    }
+    for (uint32_t i = tid; i < B; i += 256) cell[i] = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, off, 64));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, off, 64));
+    }
+    if (lane == 0) { red[wave] = dmin; red[4 + wave] = dmax; }
+    __syncthreads();
+    dmin = min(min(red[0], red[1]), min(red[2], red[3]));
+    dmax = max(max(red[4], red[5]), max(red[6], red[7]));
+    const float scale = (float)B / (float)(dmax - dmin + 1u);
+    auto cell_of = [&](uint32_t d) { return min(B - 1u, (uint32_t)((float)(d - dmin) * scale)); };
+    // 2. + 3a. counts
+#pragma unroll
+    for (int e = 0; e < kPer; e++)
+        if (tid + 256u * e < n) atomicAdd(&cell[cell_of((uint32_t)(mine[e] >> 32))], 1u);
+    __syncthreads();
+    // 3b. exclusive scan over the B cells: thread t owns the epb consecutive cells t * epb ...
+    {
+        const uint32_t epb = B >> 8;
+        uint32_t local = 0;
+        for (uint32_t e = 0; e < epb; e++) local += cell[tid * epb + e];
+        uint32_t incl = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        __syncthreads();                       // red[] is read above by every thread
+        if (lane == 63) red[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - local;
+        for (uint32_t w = 0; w < wave; w++) run += red[w];
+        for (uint32_t e = 0; e < epb; e++) {
+            const uint32_t c = cell[tid * epb + e];
+            cell[tid * epb + e] = run << 16;   // count restarts at 0: the scatter below counts again
+            run += c;
+        }
+    }
+    __syncthreads();
+    // 3c. scatter into the cells
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+        if (tid + 256u * e < n) {
+            const uint64_t key = mine[e];
+            const uint32_t old = atomicAdd(&cell[cell_of((uint32_t)(key >> 32))], 1u);
+            sk[(old >> 16) + (old & 0xffffu)] = key;
+        }
+    }
+    __syncthreads();
+    // 4. rank inside the cell, write the outputs
+    for (uint32_t p = tid; p < n; p += 256) {
+        const uint64_t key = sk[p];
+        const uint32_t c = cell[cell_of((uint32_t)(key >> 32))];
+        const uint32_t start = c >> 16, m = c & 0xffffu;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < m; j++) rank += sk[start + j] < key ? 1u : 0u;
+        const uint32_t pos = rg.x + start + rank;
         const uint32_t slot = (uint32_t)key;
-        keys[rg.x + i] = ((uint64_t)tile << 32) | (key >> 32);
-        slot_of[rg.x + i] = slot;
-        point_list[rg.x + i] = slot_vp[slot];
+        keys[pos] = ((uint64_t)tile << 32) | (key >> 32);
+        slot_of[pos] = slot;
+        point_list[pos] = slot_vp[slot];
     }
 }
 
@@ -542,9 +682,14 @@ void launch_tile_count(hipStream_t s, int VP, int P, const int* radii, GeomState
                        int tiles_x, int tiles_y)
 {
     (void)hipMemsetAsync(ranges, 0, (size_t)tiles_total * sizeof(uint2), s);
-    const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
-    hipLaunchKernelGGL(tile_count_kernel, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, ranges, (uint32_t)tiles_x,
-                       (uint32_t)tiles_y);
+    const uint32_t nblk = (uint32_t)((VP + kAggThreads - 1) / kAggThreads);
+    // the LDS window needs a workgroup's 1024 Gaussians inside two consecutive views and two views' tiles inside the window
+    if (2u * tiles_x * tiles_y <= kAggWindow && (uint32_t)P >= kAggThreads)
+        hipLaunchKernelGGL(tile_count_kernel<true>, dim3(nblk), dim3(kAggThreads), 0, s, VP, P, radii, g, ranges, (uint32_t)tiles_x,
+                           (uint32_t)tiles_y);
+    else
+        hipLaunchKernelGGL(tile_count_kernel<false>, dim3(nblk), dim3(kAggThreads), 0, s, VP, P, radii, g, ranges, (uint32_t)tiles_x,
+                           (uint32_t)tiles_y);
 }
 
 void launch_tile_scan(hipStream_t s, uint2* ranges, uint32_t tiles_total, uint32_t* cursor, uint32_t* stats, uint32_t* info)
@@ -555,9 +700,13 @@ void launch_tile_scan(hipStream_t s, uint2* ranges, uint32_t tiles_total, uint32
 void launch_tile_scatter(hipStream_t s, int VP, int P, const int* radii, GeomState g, uint64_t* bucket_keys, uint32_t* slot_vp,
                          uint32_t* cursor, int tiles_x, int tiles_y, const uint32_t* info)
 {
-    const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
-    hipLaunchKernelGGL(duplicate_kernel<true>, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, bucket_keys,
-                       (uint32_t*)nullptr, slot_vp, (uint4*)nullptr, (uint32_t)tiles_x, (uint32_t)tiles_y, info, cursor);
+    const uint32_t nblk = (uint32_t)((VP + kAggThreads - 1) / kAggThreads);
+    if (2u * tiles_x * tiles_y <= kAggWindow && (uint32_t)P >= kAggThreads)
+        hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(nblk), dim3(kAggThreads), 0, s, VP, P, radii, g, bucket_keys, slot_vp,
+                           cursor, (uint32_t)tiles_x, (uint32_t)tiles_y, info);
+    else
+        hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(nblk), dim3(kAggThreads), 0, s, VP, P, radii, g, bucket_keys, slot_vp,
+                           cursor, (uint32_t)tiles_x, (uint32_t)tiles_y, info);
 }
 
 void launch_tile_sort(hipStream_t s, const uint2* ranges, uint32_t tiles_total, const uint64_t* bucket_keys, uint64_t* keys,
@@ -576,8 +725,8 @@ void launch_duplicate(hipStream_t s, int VP, int P, const int* radii, GeomState 
                       uint32_t* vals_out, uint32_t* slot_vp, uint4* rowpos, int tiles_x, int tiles_y, const uint32_t* info)
 {
     const uint32_t nblk = (uint32_t)((VP + kGaussBlock - 1) / kGaussBlock);
-    hipLaunchKernelGGL(duplicate_kernel<false>, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, keys_out, vals_out,
-                       slot_vp, rowpos, (uint32_t)tiles_x, (uint32_t)tiles_y, info, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(duplicate_kernel, dim3(nblk), dim3(kGaussBlock), 0, s, VP, P, radii, g, keys_out, vals_out,
+                       slot_vp, rowpos, (uint32_t)tiles_x, (uint32_t)tiles_y, info);
 }
 
 // Sorts (keys, vals) of length R on the low plan.total_bits bits.  The unsorted input sits in

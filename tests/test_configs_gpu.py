@@ -477,6 +477,49 @@ def test_config4_lora_backward_on_the_lora_stream_gives_the_callers_stream_gradi
     assert worst_ls > 0.99 and worst_ls > worst_self - 5e-3, (worst_self, worst_ls)
 
 
+def test_config4_three_stream_schedule_against_one_stream_at_bit_level_where_the_step_is_reproducible(monkeypatch):
+    """The round-5 review's missing bar: cosines would let a race that perturbs one adapter by 1e-3 through.  At the trained
+    state, with FIXED noise and timesteps, the one-stream schedule is run twice and the three-stream schedule (frozen | LoRA
+    no-grad | training pass on their own streams, backward on the LoRA stream) once, on fresh objects each.  Whatever the
+    one-stream schedule reproduces bit for bit between its two runs (latents, image gradient, LoRA loss, every adapter
+    gradient -- the library's stream-K GEMMs decide that, tools/lora_grad_repro.py), the three-stream schedule must reproduce bit
+    for bit too; what it does not reproduce exactly must agree across schedules to within four times the one-stream run-to-run
+    difference at the worst element."""
+    from garmentdreamer_amd.guidance import sd_vsd
+    _, _, train32, _ = _trained_fp32_vsd()
+    runs = {}
+    for name, conc, ls in (("one", False, False), ("one again", False, False), ("three", True, True)):
+        monkeypatch.setattr(sd_vsd, "_CONCURRENT", conc)
+        gd, lora, train, q = _vsd_objects(_KW_U, _KW_V, torch.bfloat16, graphs=True)
+        with torch.no_grad():
+            for p16, p32 in zip(train, train32):
+                p16.copy_(p32.to(p16.dtype))
+        runs[name] = [_vsd_step(gd, q, train, seed=80 + i, lora_stream=ls) for i in range(3)]      # step 0 captures, 1-2 replay
+        assert gd.use_hip_graphs
+        del gd, lora, train, q
+        torch.cuda.empty_cache()
+    exact, total, worst_ratio = 0, 0, 0.0
+    for it in range(3):
+        a, b, c = runs["one"][it], runs["one again"][it], runs["three"][it]
+        items = [("dL/dimage", a[0], b[0], c[0]), ("latents", a[1], b[1], c[1]),
+                 ("lora loss", torch.tensor(a[2]), torch.tensor(b[2]), torch.tensor(c[2]))]
+        items += [(f"adapter grad {i}", a[3][i], b[3][i], c[3][i]) for i in sorted(a[3]) if i in b[3] and i in c[3]]
+        for name, x1, x2, y in items:
+            total += 1
+            d_self = float((x1 - x2).abs().max())
+            d_cross = float((x1 - y).abs().max())
+            if d_self == 0.0:
+                exact += 1
+                assert d_cross == 0.0, f"iteration {it}, {name}: reproducible on one stream, differs on three ({d_cross:.3e})"
+            else:
+                scale = float(x1.abs().max()) + 1e-30
+                worst_ratio = max(worst_ratio, d_cross / d_self)
+                assert d_cross <= 4.0 * d_self + 1e-5 * scale, f"iteration {it}, {name}: {d_cross:.3e} vs run-to-run {d_self:.3e}"
+    parity_report.record("configs[4] VSD step, reduced width, trained adapters: three-stream vs one-stream schedule, element level",
+                         "step", quantities=total, bitwise_reproducible_on_one_stream=exact, worst_cross_over_self=worst_ratio)
+    assert exact > 0, "nothing of the step is bitwise reproducible: the bit-level half of this test did not run"
+
+
 def test_config4_two_lora_training_passes_after_one_train_step_see_the_optimizer_step_in_between(monkeypatch):
     """trainer.py's K loop: ``lora_train_loss`` -> backward -> optimizer step TWICE after one ``train_step``, the optimizer on the
     caller's stream (the reference's unedited sequence).  The training pass runs on its own stream behind an event recorded after
