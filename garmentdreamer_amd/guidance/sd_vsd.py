@@ -165,10 +165,39 @@ class StableDiffusionVSD(nn.Module):
         name = "_side_train" if train and _THREE_STREAMS else "_side"
         st = getattr(self, name, None)
         if st is None or st.device != device:
-            # default priority: a high-priority training stream (priority=-1) measured 61 ms per iteration against 25 (round 5)
-            st = torch.cuda.Stream(device=device)
+            # default priority: a high-priority training stream (priority=-1) measured 61 ms per iteration against 25 (round 5);
+            # not one of the graphs' capture streams, nor the other side stream (torch's stream pool wraps around, _capture_stream)
+            taken = set(getattr(self, "_capture_handles", ()))
+            for other in ("_side", "_side_train"):
+                o = getattr(self, other, None)
+                if o is not None:
+                    taken.add(o.cuda_stream)
+            for _ in range(64):
+                st = torch.cuda.Stream(device=device)
+                if st.cuda_stream not in taken:
+                    break
             setattr(self, name, st)
         return st
+
+    def _capture_stream(self, device):
+        """A capture stream no other graph of this guidance (and neither of its LoRA side streams) uses: the library GEMMs'
+        workspace is keyed by the stream a call was CAPTURED on, and graphs that replay concurrently must not share one.
+        torch.cuda.Stream() hands out a pool of 32 streams per device round-robin, so after enough graph keys two 'new' streams
+        are the same stream -- draw until the handle is unused (and say so if the pool is exhausted)."""
+        used = getattr(self, "_capture_handles", None)
+        if used is None:
+            used = self._capture_handles = set()
+        for name in ("_side", "_side_train"):
+            st = getattr(self, name, None)
+            if st is not None:
+                used.add(st.cuda_stream)
+        for _ in range(64):
+            st = torch.cuda.Stream(device=device)
+            if st.cuda_stream not in used and st.cuda_stream != torch.cuda.current_stream(device).cuda_stream:
+                used.add(st.cuda_stream)
+                return st
+        raise RuntimeError("StableDiffusionVSD: no unused capture stream left (torch's pool of 32 streams per device is shared by "
+                           "every graph key of this guidance): concurrently replayed graphs would share a library-GEMM workspace")
 
     def _graphs_failed(self, err):
         import warnings
@@ -197,7 +226,7 @@ class StableDiffusionVSD(nn.Module):
                 g = torch.cuda.CUDAGraph()
                 # ... and its own CAPTURE stream: the library GEMMs' workspace (stream-K partial tiles) is keyed by the stream the
                 # call was captured on, so two graphs captured on torch's default capture stream would share one
-                cap = torch.cuda.Stream(device=dev)
+                cap = self._capture_stream(dev)
                 with torch.cuda.graph(g, stream=cap), torch.no_grad():
                     out = fn(*static)
             entry = self._graphs[key] = (g, static, out, cap)
@@ -227,7 +256,7 @@ class StableDiffusionVSD(nn.Module):
             # backward graph and the LoRA UNet's training graphs may replay concurrently.  make_graphed_callables captures on
             # torch.cuda.graph's class-level default capture stream: swapped for the duration of the call
             from .. import nn_ops
-            cap = torch.cuda.Stream(device=tensors[0].device)
+            cap = self._capture_stream(tensors[0].device)
             prev_cap = torch.cuda.graph.default_capture_stream
             torch.cuda.graph.default_capture_stream = cap
             try:
@@ -327,6 +356,8 @@ class StableDiffusionVSD(nn.Module):
             # caller runs in between): it waits for THIS event on its own stream
             self._ev_latents = torch.cuda.Event()
             self._ev_latents.record(torch.cuda.current_stream(latents.device))
+            # the event orders the training stream behind THESE latents only: lora_train_loss checks it is handed them
+            self._ev_latents_id = (latents.data_ptr(), latents._version)
         if timesteps is not None:
             t = timesteps.to(self.device).long()
         elif t5:
@@ -399,8 +430,11 @@ class StableDiffusionVSD(nn.Module):
             ev = getattr(self, "_ev_latents", None)
             self._ev_latents = None            # good for ONE call: a second training pass after the same train_step (trainer.py's
             #                                    K loop) must also see the optimizer step the caller ran in between on ITS stream
-            if ev is None or timesteps is not None or noise is not None:
-                side.wait_stream(cur)          # caller-made inputs (tests) / repeated call: everything the caller queued so far
+            same = getattr(self, "_ev_latents_id", None) == (latents.data_ptr(), latents._version)
+            if ev is None or not same or timesteps is not None or noise is not None:
+                # caller-made inputs (tests) / repeated call / latents that are NOT train_step's output (a replay buffer, re-encoded
+                # latents produced later on the caller's stream): everything the caller queued so far
+                side.wait_stream(cur)
             else:
                 side.wait_event(ev)
             ctx = torch.cuda.stream(side)
