@@ -4,9 +4,9 @@
 # Writes the raw counters, the kernel durations and the derived figures to $1 (default gpurun_out/mfma_util_check.txt).
 out=${1:-gpurun_out/mfma_util_check.txt}; mkdir -p $(dirname $out)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-[ -x ablate/mfma_util_probe ] || hipcc --offload-arch=gfx950 -O3 -o ablate/mfma_util_probe tools/probes/mfma_util_probe.hip
+[ -x /tmp/mfma_util_probe ] || hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_util_probe tools/probes/mfma_util_probe.hip
 rm -rf /tmp/mup
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/mup -o p -- ablate/mfma_util_probe 2 100000 > /tmp/mup.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/mup -o p -- /tmp/mfma_util_probe 2 100000 > /tmp/mup.log 2>&1
 python - "$out" <<'PY'
 import csv, glob, sys, collections
 out = open(sys.argv[1], "w")

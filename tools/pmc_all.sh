@@ -28,7 +28,7 @@ for _n, _d in (("--gaussians", 100000), ("--views", 8), ("--res", 512)):
     _a.add_argument(_n, type=int, default=_d)
 _w, _ = _a.parse_known_args(sys.argv[2:])
 N_SIMDS, N_XCDS = 1024.0, 8.0      # MI355X: 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is reported summed over the 8 XCDs
-KEEP = ("render_backward", "render_forward", "preprocess", "instance_sum", "radix_", "duplicate", "tile_ranges", "conv3x3", "conv_splitk",
+KEEP = ("render_backward", "render_forward", "preprocess", "instance_sum", "radix_", "duplicate", "tile_ranges", "tile_count", "tile_scan", "tile_scatter", "tile_sort", "gemm256", "conv3x3", "conv_splitk",
         "gn_", "attn_", "geglu", "add_layernorm", "adam", "activate", "sds_", "vae_prologue", "sparsity", "gemm_", "xattn")
 def short(name):
     n = name.replace("(anonymous namespace)::", "").replace("gd::", "")
