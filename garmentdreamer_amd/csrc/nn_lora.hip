@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/gd_nn.h"
 
@@ -358,9 +359,96 @@ __global__ __launch_bounds__(256) void lora_colreduce_pair_finish_kernel(ColPair
     *dst = p.acc ? *dst + s : s;
 }
 
+// The weight gradients of MANY adapters in one launch per stage (round 6): the 128-260 adapted projections of a LoRA UNet backward
+// each ended with a pair-reduction launch and its finish launch of ~5 us -- 2.6 ms of launch-bound kernels on the training chain of
+// the NeTF iteration, none of whose results anybody reads before the optimizer step.  The backward nodes now only RECORD their
+// problem (gd_nn_lora_colreduce_group_desc), and the last one launches the table, 32 adapters per launch: blockIdx.z = 2 * adapter + (0: d up, 1: d down),
+// grids sized for the largest adapter, workgroups beyond an adapter's own extent leave at once.  Same bodies, same summation
+// orders: bit-identical to the per-adapter launches.
+struct ColGroupEntry {
+    ColPair p;
+    int M, rows, chunks, pad;
+};
+
+constexpr int kGroupChunk = 32;        // adapters per launch: the table travels BY VALUE in the kernel arguments (3 KiB of the 4 KiB
+struct ColGroupArgs {                  // limit) -- no device table, no host-to-device copy, nothing that a hipGraph capture forbids
+    ColGroupEntry e[kGroupChunk];
+};
+
+__global__ __launch_bounds__(256) void lora_colreduce_group_kernel(const ColGroupArgs args)
+{
+    __shared__ float sred[3][32][64];
+    const ColGroupEntry& e = args.e[blockIdx.z >> 1];
+    const int z = blockIdx.z & 1;
+    if ((int)blockIdx.x * 64 >= e.p.J8[z] || (int)blockIdx.y >= e.chunks) return;   // whole workgroup
+    colreduce_body(e.p.a[z], e.p.v[z], e.p.part[z], e.M, e.p.J8[z], e.rows, blockIdx.y, blockIdx.x, sred);
+}
+
+__global__ __launch_bounds__(256) void lora_colreduce_group_finish_kernel(const ColGroupArgs args)
+{
+    const ColGroupEntry& e = args.e[blockIdx.y];
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = 4 * 8 * e.p.J8[0], n1 = 4 * 8 * e.p.J8[1];
+    if (i >= n0 + n1) return;
+    const int z = i >= n0;
+    if (z) i -= n0;
+    const int J = 8 * e.p.J8[z];
+    const float s = chunk_sum(e.p.part[z], (size_t)4 * J, i, e.chunks);
+    const int r = i / J, j = i - r * J;
+    float* dst = e.p.g[z] + (z == 0 ? (size_t)j * 4 + r : (size_t)i);          // d up as [N][4], d down as [4][K]
+    *dst = e.p.acc ? *dst + s : s;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t gd_nn_lora_colreduce_group_entry_bytes(void) { return sizeof(ColGroupEntry); }
+
+int gd_nn_lora_colreduce_group_desc(void* entry, const void* dy, const float* hs, const void* x, const float* dh, float* scratch,
+                                    float* d_up, float* d_down, int64_t M, int N, int K, int accumulate, int* grid_xyz)
+{
+    if (!entry || !dy || !hs || !x || !dh || !scratch || !d_up || !d_down || !grid_xyz)
+        return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce_group_desc: null pointer");
+    if (M <= 0 || M > 0x7fffffff / 4 || N <= 0 || K <= 0 || (N & 7) || (K & 7))
+        return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce_group_desc: need M > 0, N % 8 == 0, K % 8 == 0");
+    ColGroupEntry e;
+    e.rows = chunk_rows(M);
+    e.chunks = (int)((M + e.rows - 1) / e.rows);
+    e.M = (int)M;
+    e.pad = 0;
+    e.p.a[0] = (const u32x4*)dy; e.p.v[0] = (const float4*)hs; e.p.part[0] = scratch; e.p.g[0] = d_up; e.p.J8[0] = N / 8;
+    e.p.a[1] = (const u32x4*)x; e.p.v[1] = (const float4*)dh; e.p.part[1] = scratch + (size_t)e.chunks * 4 * N; e.p.g[1] = d_down;
+    e.p.J8[1] = K / 8;
+    e.p.acc = accumulate ? 1 : 0;
+    memcpy(entry, &e, sizeof(e));
+    const int jmax = N > K ? N / 8 : K / 8;
+    grid_xyz[0] = (jmax + 63) / 64;             // stage 1: x
+    grid_xyz[1] = e.chunks;                     // stage 1: y
+    grid_xyz[2] = (4 * (N + K) + 255) / 256;    // stage 2: x
+    return GD_NN_OK;
+}
+
+int gd_nn_lora_colreduce_group_launch(void* stream, const void* table_host, int n_entries, int grid1_x, int grid1_y, int grid2_x)
+{
+    if (!table_host || n_entries <= 0 || grid1_x <= 0 || grid1_y <= 0 || grid2_x <= 0)
+        return fail(GD_NN_ERR_INVALID_ARG, "lora_colreduce_group_launch: bad arguments");
+    const ColGroupEntry* t = (const ColGroupEntry*)table_host;
+    // stage 1 of every chunk, then stage 2 of every chunk: the finish launches read what the reduction launches wrote
+    for (int pass = 0; pass < 2; pass++)
+        for (int i0 = 0; i0 < n_entries; i0 += kGroupChunk) {
+            const int n = n_entries - i0 < kGroupChunk ? n_entries - i0 : kGroupChunk;
+            ColGroupArgs a;
+            memcpy(a.e, t + i0, sizeof(ColGroupEntry) * (size_t)n);
+            if (pass == 0)
+                hipLaunchKernelGGL(lora_colreduce_group_kernel, dim3(grid1_x, grid1_y, 2 * n), dim3(256), 0, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL(lora_colreduce_group_finish_kernel, dim3(grid2_x, n), dim3(256), 0, (hipStream_t)stream, a);
+        }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GD_NN_ERR_HIP, hipGetErrorString(e));
+    return GD_NN_OK;
+}
 
 const char* gd_nn_lora_last_error(void) { return g_err; }
 

@@ -139,6 +139,12 @@ class FlatAdam:
 
     @torch.no_grad()
     def step(self):
+        from . import nn_ops
+        pending = nn_ops.lora_groups_pending()
+        if pending:
+            # grouped weight-gradient launch (nn_ops.LoraGradGroup) that never happened: a backward pass did not reach every
+            # adapted projection of its forward pass -- stepping now would use gradients that miss those adapters
+            raise RuntimeError(f"FlatAdam.step: {pending} LoRA weight-gradient problems were recorded but never launched")
         self.step_count += 1
         flat = self._flat_set
         if flat:

@@ -711,6 +711,14 @@ class LoraUNet2DConditionModel(UNet2DConditionModel):
             p.requires_grad_(True)
         return train
 
+    def forward(self, sample, timestep, encoder_hidden_states, **kwargs):
+        # training pass: the weight gradients of all adapted projections leave through ONE grouped launch per stage at the end
+        # of the backward pass (nn_ops.LoraGradGroup) instead of two ~5 us launches per projection
+        if torch.is_grad_enabled() and sample.is_cuda:
+            with nn_ops.lora_grad_group():
+                return super().forward(sample, timestep, encoder_hidden_states, **kwargs)
+        return super().forward(sample, timestep, encoder_hidden_states, **kwargs)
+
     def extra_embedding(self, batch: int, c=None, shading: str = "albedo"):
         dev, dt = self.camera_emb[0].weight.device, self.camera_emb[0].weight.dtype
         if c is None:

@@ -165,32 +165,24 @@ class StableDiffusionVSD(nn.Module):
         name = "_side_train" if train and _THREE_STREAMS else "_side"
         st = getattr(self, name, None)
         if st is None or st.device != device:
-            # default priority: a high-priority training stream (priority=-1) measured 61 ms per iteration against 25 (round 5);
-            # not one of the graphs' capture streams, nor the other side stream (torch's stream pool wraps around, _capture_stream)
-            taken = set(getattr(self, "_capture_handles", ()))
-            for other in ("_side", "_side_train"):
-                o = getattr(self, other, None)
-                if o is not None:
-                    taken.add(o.cuda_stream)
-            for _ in range(64):
-                st = torch.cuda.Stream(device=device)
-                if st.cuda_stream not in taken:
-                    break
+            # default priority: a high-priority training stream (priority=-1) measured 61 ms per iteration against 25 (round 5).
+            # Created where first needed, nothing cleverer: HIP deals streams to its few hardware queues in creation order, and
+            # two attempts of round 6 to pick these streams "better" (re-drawing until distinct from the capture streams; both
+            # drawn back to back) cost 24.9 -> 28.3-29.5 ms per iteration -- the streams then shared a hardware queue with
+            # something they should overlap (GPU_MAX_HW_QUEUES=8: 52.9 ms).  A side stream never captures, so it may coincide
+            # with a capture stream without two graphs sharing a library workspace.
+            st = torch.cuda.Stream(device=device)
             setattr(self, name, st)
         return st
 
     def _capture_stream(self, device):
-        """A capture stream no other graph of this guidance (and neither of its LoRA side streams) uses: the library GEMMs'
+        """A capture stream no other graph of this guidance uses: the library GEMMs'
         workspace is keyed by the stream a call was CAPTURED on, and graphs that replay concurrently must not share one.
         torch.cuda.Stream() hands out a pool of 32 streams per device round-robin, so after enough graph keys two 'new' streams
         are the same stream -- draw until the handle is unused (and say so if the pool is exhausted)."""
         used = getattr(self, "_capture_handles", None)
         if used is None:
             used = self._capture_handles = set()
-        for name in ("_side", "_side_train"):
-            st = getattr(self, name, None)
-            if st is not None:
-                used.add(st.cuda_stream)
         for _ in range(64):
             st = torch.cuda.Stream(device=device)
             if st.cuda_stream not in used and st.cuda_stream != torch.cuda.current_stream(device).cuda_stream:

@@ -127,6 +127,9 @@ SIGNATURES = {
     "gd_nn_lora_colreduce_pair_scratch_floats": (C.c_size_t, [C.c_int64, _i, _i]),
     "gd_nn_lora_colreduce_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i]),
     "gd_nn_lora_colreduce_pair_into": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _i]),
+    "gd_nn_lora_colreduce_group_entry_bytes": (C.c_size_t, []),
+    "gd_nn_lora_colreduce_group_desc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _i, C.POINTER(C.c_int)]),
+    "gd_nn_lora_colreduce_group_launch": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "gd_nn_lora_last_error": (C.c_char_p, []),
     "gd_nn_last_error": (C.c_char_p, []),
 }
@@ -1718,6 +1721,83 @@ def _lora_row_fused(a2d, w1, w2, base2d, N, scale, backward, want_h=True):
     return y, h
 
 
+# ---- the weight gradients of all adapters of a backward pass as ONE grouped launch per stage (csrc/nn_lora.hip, round 6) ----
+_LORA_GROUPING = os.environ.get("GD_LORA_GROUP", "1") != "0"     # =0: one reduction pair per adapter (same-box A/B)
+_LORA_GROUP = [None]          # the group the adapted projections created right now belong to (lora_grad_group)
+_LORA_GROUPS_OPEN = []        # groups with recorded but unlaunched problems (weakrefs): lora_groups_pending()
+
+
+class LoraGradGroup:
+    """Collects the (dy, scale * h, x, dh) -> (d up, d down) problems of the adapted projections of ONE forward pass whose
+    gradients land in FlatAdam's sinks (nobody reads them before the optimizer step) and launches them together once the LAST
+    of them has been recorded -- every projection created inside ``lora_grad_group()`` counts, each records itself in its
+    backward.  Captured inside a hipGraph like any other launch: the table travels by value in the kernel arguments, 32
+    adapters per launch."""
+
+    def __init__(self):
+        self.expected = 0
+        self.entries = []
+        self.keep = []
+        self.grid = [0, 0, 0]
+        self.launches = 0
+
+    def add(self, dy, hs, x2d, dh, scratch, sink_up, sink_down, M, N, K):
+        L = lib()
+        eb = L.gd_nn_lora_colreduce_group_entry_bytes()
+        buf = (C.c_ubyte * eb)()
+        g3 = (C.c_int * 3)()
+        _lora_check(L.gd_nn_lora_colreduce_group_desc(buf, dy.data_ptr(), hs.data_ptr(), x2d.data_ptr(), dh.data_ptr(),
+                                                      scratch.data_ptr(), sink_up.data_ptr(), sink_down.data_ptr(), M, N, K, 1, g3),
+                    "gd_nn_lora_colreduce_group_desc")
+        if not self.entries:
+            _LORA_GROUPS_OPEN.append(weakref.ref(self))
+        self.entries.append(bytes(buf))
+        self.keep.append((dy, hs, x2d, dh, scratch))          # alive until the grouped launch has been queued
+        self.grid = [max(a, int(b)) for a, b in zip(self.grid, g3)]
+        if len(self.entries) == self.expected:
+            self.flush(dy.device)
+
+    def flush(self, device):
+        if not self.entries:
+            return
+        n = len(self.entries)
+        table = (C.c_ubyte * (n * len(self.entries[0]))).from_buffer_copy(b"".join(self.entries))
+        L = lib()
+        with torch.cuda.device(device):
+            _lora_check(L.gd_nn_lora_colreduce_group_launch(torch.cuda.current_stream(device).cuda_stream, table, n,
+                                                            self.grid[0], self.grid[1], self.grid[2]),
+                        "gd_nn_lora_colreduce_group_launch")
+        self.entries, self.keep, self.grid = [], [], [0, 0, 0]
+        self.launches += 1
+
+
+class lora_grad_group:
+    """``with lora_grad_group():`` around a forward pass under autograd: the adapted projections created inside send their
+    weight gradients through ONE grouped launch per stage at the end of the backward pass (LoraGradGroup)."""
+
+    def __enter__(self):
+        self.prev = _LORA_GROUP[0]
+        _LORA_GROUP[0] = self.group = LoraGradGroup() if _LORA_GROUPING else None
+        return self.group
+
+    def __exit__(self, *exc):
+        _LORA_GROUP[0] = self.prev
+        return False
+
+
+def lora_groups_pending() -> int:
+    """Recorded but unlaunched weight-gradient problems (a backward pass that did not reach every adapted projection of its
+    forward pass): flat_adam.FlatAdam.step refuses to step over them."""
+    n = 0
+    for r in list(_LORA_GROUPS_OPEN):
+        g = r()
+        if g is None or not g.entries:
+            _LORA_GROUPS_OPEN.remove(r)
+        else:
+            n += len(g.entries)
+    return n
+
+
 def _grad_sinks(down_w, up_w):
     """(sink of down, sink of up): fp32 tensors of the weights' shapes that RECEIVE the weight gradients in place
     (``Parameter._gd_grad_sink``, set by flat_adam.FlatAdam), or (None, None)."""
@@ -1726,6 +1806,15 @@ def _grad_sinks(down_w, up_w):
             not su.is_contiguous():
         return None, None
     return sd, su
+
+
+def _join_group(ctx, down_w, up_w):
+    """The node joins the open LoraGradGroup if its weight gradients go to sinks and both adapter halves train."""
+    grp = _LORA_GROUP[0]
+    ctx.group = None
+    if grp is not None and ctx.sinks[0] is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
+        ctx.group = grp
+        grp.expected += 1
 
 
 def _lora_backward(ctx, dy, dx_base, need_x, need_down, need_up):
@@ -1747,6 +1836,10 @@ def _lora_backward(ctx, dy, dx_base, need_x, need_down, need_up):
         if sink_down is not None and sink_up is not None:
             # the adapters' .grad are slices of ONE flat gradient buffer (flat_adam.FlatAdam): added in place by the kernel,
             # nothing returned to autograd -- no 256 gradient tensors, AccumulateGrad calls and gathers per UNet backward
+            grp = getattr(ctx, "group", None)
+            if grp is not None:            # ... and nobody reads them before the optimizer step: one grouped launch at the end
+                grp.add(dy, hs, x2d, dh, scratch, sink_up, sink_down, M, N, K)
+                return dx, None, None
             with torch.cuda.device(dy.device):
                 _lora_check(L.gd_nn_lora_colreduce_pair_into(torch.cuda.current_stream(dy.device).cuda_stream, dy.data_ptr(),
                                                              hs.data_ptr(), x2d.data_ptr(), dh.data_ptr(), scratch.data_ptr(),
@@ -1777,6 +1870,7 @@ class _LoraBranch(torch.autograd.Function):
         ctx.save_for_backward(x2d, hs, down_w, up_w)
         ctx.scale = float(scale)
         ctx.sinks = _grad_sinks(down_w, up_w)
+        _join_group(ctx, down_w, up_w)
         return y
 
     @staticmethod
@@ -1801,6 +1895,7 @@ class _LoraLinear(torch.autograd.Function):
         ctx.save_for_backward(x2d, hs, down_w, up_w, weight)
         ctx.scale = float(scale)
         ctx.sinks = _grad_sinks(down_w, up_w)
+        _join_group(ctx, down_w, up_w)
         return y
 
     @staticmethod

@@ -411,6 +411,16 @@ int gd_nn_lora_colreduce_pair(void* stream, const void* dy, const float* hs, con
  * backward never become 256 tensors on the host (netf/trainer.py:252-256: loss.backward(); lora_unet_optimizer.step()). */
 int gd_nn_lora_colreduce_pair_into(void* stream, const void* dy, const float* hs, const void* x, const float* dh, float* scratch,
                                    float* d_up, float* d_down, int64_t M, int N, int K, int accumulate);
+/* The weight gradients of MANY adapters in one launch per stage (round 6; replaces one gd_nn_lora_colreduce_pair_into per adapted
+ * projection -- 256 x 2 launches of ~5 us per LoRA UNet backward -- by 2 launches).  _group_desc fills ONE host-side table entry
+ * (gd_nn_lora_colreduce_group_entry_bytes() bytes) for an adapter, arguments as gd_nn_lora_colreduce_pair_into, and returns that
+ * adapter's grid extents {stage-1 x, stage-1 y, stage-2 x} in grid_xyz[3]; _group_launch takes the HOST table and the MAXIMA of
+ * the extents and launches 32 adapters at a time with their entries by value in the kernel arguments (no device table, no copy:
+ * safe inside a hipGraph capture).  Same kernels' bodies and summation orders: bit-identical results. */
+size_t gd_nn_lora_colreduce_group_entry_bytes(void);
+int gd_nn_lora_colreduce_group_desc(void* entry, const void* dy, const float* hs, const void* x, const float* dh, float* scratch,
+                                    float* d_up, float* d_down, int64_t M, int N, int K, int accumulate, int* grid_xyz);
+int gd_nn_lora_colreduce_group_launch(void* stream, const void* table_host, int n_entries, int grid1_x, int grid1_y, int grid2_x);
 const char* gd_nn_lora_last_error(void);
 
 const char* gd_nn_last_error(void);

@@ -1535,6 +1535,62 @@ def test_lora_gradients_land_in_the_flat_adam_sinks():
         assert torch.allclose(up.detach(), up_r.detach(), rtol=2e-6, atol=2e-7)
 
 
+def test_grouped_lora_weight_gradients_are_the_per_adapter_launches_bit_for_bit():
+    """nn_ops.lora_grad_group (round 6): the adapted projections created inside record their weight-gradient problems in their
+    backward and the LAST one launches them all, 32 per launch with the table in the kernel arguments.  A chain of 70 adapted
+    projections of four different shapes (three launches per stage), gradients into FlatAdam's sinks: the same bits as one
+    gd_nn_lora_colreduce_pair_into per adapter, twice that after a second pass (accumulation), nothing pending at the end --
+    and FlatAdam.step refuses to step over a group whose backward never reached all of its projections."""
+    from garmentdreamer_amd import nn_ops
+    from garmentdreamer_amd.flat_adam import FlatAdam
+    g = torch.Generator(DEV).manual_seed(9)
+    shapes = [(1024, 320, 320), (1024, 320, 640), (256, 640, 640), (64, 1280, 1280)]
+    layers = []
+    for i in range(70):
+        M, K, N = shapes[i % 4]
+        w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+        down = torch.nn.Parameter(torch.randn(4, K, device=DEV, generator=g) / 4)
+        up = torch.nn.Parameter(torch.randn(N, 4, device=DEV, generator=g) * 0.3)
+        x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16).requires_grad_(True)
+        dy = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+        layers.append((x, w, down, up, dy))
+    params = [p for _, _, d, u, _ in layers for p in (d, u)]
+    opt = FlatAdam(params, lr=1e-3, flat=params)
+
+    def run(grouped):
+        opt.zero_grad()
+        ctx = nn_ops.lora_grad_group() if grouped else __import__("contextlib").nullcontext()
+        with ctx as grp:
+            ys = [nn_ops.lora_linear(x, w, d, u, 0.5, (lambda t, w=w: F.linear(t, w))) for x, w, d, u, _ in layers]
+        torch.autograd.backward(ys, [dy for *_, dy in layers])
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in params], grp
+
+    ref, _ = run(False)
+    got, grp = run(True)
+    assert grp is not None and grp.expected == 70 and grp.launches == 1 and nn_ops.lora_groups_pending() == 0
+    assert all(float(r.abs().max()) > 0 for r in ref)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # accumulation across two grouped passes without zero_grad
+    with nn_ops.lora_grad_group():
+        ys = [nn_ops.lora_linear(x, w, d, u, 0.5, (lambda t, w=w: F.linear(t, w))) for x, w, d, u, _ in layers]
+    torch.autograd.backward(ys, [dy for *_, dy in layers])
+    for a, p in zip(ref, params):
+        assert torch.equal(p.grad, 2 * a)
+    # a backward pass that misses one projection leaves its group open: the optimizer says so instead of stepping
+    opt.zero_grad()
+    with nn_ops.lora_grad_group():
+        ys = [nn_ops.lora_linear(x, w, d, u, 0.5, (lambda t, w=w: F.linear(t, w))) for x, w, d, u, _ in layers]
+    torch.autograd.backward(ys[:-1], [dy for *_, dy in layers][:-1])
+    assert nn_ops.lora_groups_pending() == 69
+    with pytest.raises(RuntimeError, match="never launched"):
+        opt.step()
+    del ys
+    import gc
+    gc.collect()
+
+
 @pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (300, 1280), (77, 1024)])
 def test_training_row_passes_forward_and_backward_match_fp32_reference(rows, C):
     """GEGLU and add + LayerNorm with a gradient on the activations (the LoRA UNet's training pass; frozen norm parameters):
